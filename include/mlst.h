@@ -1,0 +1,180 @@
+/*
+ * mlst.h -- C-ABI of the MI355X MLST-typing engine (libmlst_hip.so).
+ *
+ * The reference (SegataLab/metamlst) has no FFI for this path: the seams it offers are a
+ * process pipe and Python functions.  Each entry point below names the
+ * reference site it replaces.  Plain pointers and sizes only; the caller owns every
+ * buffer; the library never returns owned memory.  Every function returns 0 on success
+ * or a negative MLST_E_* code, with text available from mlst_last_error().  A handle is
+ * bound to one GPU and is not thread-safe; distinct handles are independent.
+ *
+ * Binding from the reference's language (Python) is ctypes: see INTEGRATION.md.
+ */
+#ifndef MLST_H
+#define MLST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLST_OK              0
+#define MLST_E_INVALID      -1   /* bad argument / bad state */
+#define MLST_E_NOGPU        -2   /* no usable HIP device: the product path has no CPU fallback */
+#define MLST_E_HIP          -3   /* a HIP runtime call failed */
+#define MLST_E_CAPACITY     -4   /* retained-read / item / worklist capacity exceeded */
+#define MLST_E_LIMIT        -5   /* input exceeds a packed-format limit (mlst_policy.h) */
+
+typedef struct mlst_handle mlst_handle;
+
+/* Engine parameters.  Defaults (mlst_default_params) are the reference's:
+ * minscore/max_xm/min_read_len = argparse defaults metamlst.py:39-41; minqual/mincov =
+ * cmseq call metaMLST_functions.py:258; scoring = bowtie2 --very-sensitive-local [NOT IN TREE]. */
+typedef struct mlst_params {
+    int32_t minscore;          /* accept record iff AS >= minscore            metamlst.py:115 */
+    int32_t max_xm;            /* ... and field15 <= max_xm                   metamlst.py:115 */
+    int32_t min_read_len;      /* ... and len(SEQ) >= min_read_len            metamlst.py:115 */
+    int32_t minqual;           /* pileup base quality floor                   metaMLST_functions.py:258 */
+    int32_t mincov;            /* informational (applied host side)           metaMLST_functions.py:258 */
+    int32_t match_bonus;       /* bowtie2 --ma */
+    int32_t mm_max, mm_min;    /* bowtie2 --mp MX,MN */
+    int32_t n_penalty;         /* bowtie2 --np */
+    int32_t gap_open, gap_ext; /* bowtie2 --rdg/--rfg (symmetric) */
+    int32_t gbar;              /* bowtie2 --gbar */
+    int32_t band_w;            /* banded Smith-Waterman half width */
+    int32_t gap_trigger_mm;    /* see mlst_policy.h; <0 = always banded SW */
+    int32_t xm_field_quirk;    /* 1 = emulate metamlst.py:110 positional parse (Q1) */
+    int32_t reserved0;
+    double  minscore_const;    /* bowtie2 --score-min G,const,coef */
+    double  minscore_coef;
+    uint64_t max_retained_reads; /* capacity of the on-locus read store (0 = default) */
+    uint64_t max_items;          /* capacity of the (read,locus,strand,diag) item list (0 = default) */
+    uint64_t max_pair_results;   /* capacity of the per-(item,allele) result arena (0 = default) */
+} mlst_params;
+
+/* counters[] layout of mlst_get_allele_stats */
+enum {
+    MLST_CNT_TOTAL_RECORDS = 0,  /* totalReads   metamlst.py:130 (alignment records, Q13) */
+    MLST_CNT_IGNORED       = 1,  /* ignoredReads metamlst.py:129 */
+    MLST_CNT_READS_SEEN    = 2,  /* reads submitted */
+    MLST_CNT_CANDIDATES    = 3,  /* reads that passed the seed sieve */
+    MLST_CNT_RETAINED      = 4,  /* reads with at least one exact seed (kept for pass 2) */
+    MLST_CNT_ITEMS         = 5,  /* (read,locus,strand,diag) work items */
+    MLST_CNT_DP_PAIRS      = 6,  /* (item,allele) pairs sent to banded SW */
+    MLST_CNT_N             = 8
+};
+
+void mlst_default_params(mlst_params* p);
+
+/* Create / destroy an engine bound to HIP device `device`.  Fails with MLST_E_NOGPU when
+ * no device is present (there is no CPU path in this library). */
+int  mlst_create(int device, const mlst_params* p, mlst_handle** out);
+void mlst_destroy(mlst_handle* h);
+const char* mlst_last_error(const mlst_handle* h);   /* h may be NULL: last create error */
+
+/* Load the allele reference.  Replaces dump_db_to_fasta + bowtie2-build
+ * (metaMLST_functions.py:149-161, metamlst-index.py:222-247).
+ *   ascii_concat : all allele sequences concatenated (bytes as stored in alleles.sequence)
+ *   off[n+1]     : byte offsets into ascii_concat
+ *   locus_id[n]  : dense locus index 0..L-1; alleles of one locus must be contiguous
+ *   species_id[n], allele_no[n] : carried for the caller (alleles.bacterium / alleleVariant)
+ */
+int mlst_load_reference(mlst_handle* h, const uint8_t* ascii_concat, const uint64_t* off,
+                        const uint32_t* locus_id, const uint32_t* species_id,
+                        const int32_t* allele_no, uint32_t n_alleles);
+
+/* Pass 1 over one batch of reads held in HOST memory (FASTQ fields as read from the file):
+ * seed sieve -> exact seeds -> extension against every allele of the hit locus ->
+ * per-allele {sum AS, hits}.  Replaces bowtie2 -a ... | samtools view + the hit
+ * accumulator loop metamlst.py:96-130.  On-locus reads are retained on the GPU for pass 2.
+ *   bases  : ASCII bases concatenated;  quals : ASCII Phred+33 concatenated (same offsets)
+ *   off[n+1]; paired != 0 means reads 2k and 2k+1 are mates (share a QNAME, Q3). */
+int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uint8_t* quals,
+                      const uint64_t* off, uint64_t n_reads, int paired);
+
+/* Same, with the three arrays already in DEVICE memory (GPU-side FASTQ decode feeds this). */
+int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
+                             const uint64_t* d_off, uint64_t n_reads, uint32_t max_len, int paired);
+
+/* Pack ASCII reads (device) into the resident format (device): 2-bit bases in fixed-stride
+ * rows of words_per_read uint32 (base k at bits 2(k%16) of word k/16, A=0 C=1 G=2 T=3),
+ * quality rows of qual_stride bytes holding raw Phred with bit 7 set for a non-ACGT base,
+ * and uint16 lengths.  This is the layout SURVEY.md 8(d) prices at 38+150 B per 150 bp read. */
+int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
+                           const uint64_t* d_off, uint64_t n_reads,
+                           uint32_t* d_packed, uint8_t* d_qual_rows, uint16_t* d_lens,
+                           uint32_t words_per_read, uint32_t qual_stride);
+
+/* Pass 1 over a batch already resident in the packed format (the benchmark's timed entry). */
+int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packed, const uint8_t* d_qual_rows,
+                              const uint16_t* d_lens, uint64_t n_reads,
+                              uint32_t words_per_read, uint32_t qual_stride, int paired);
+
+/* Read back pass-1 statistics.  Replaces the `cel` / `sequenceBank` dictionaries of
+ * metamlst.py:116-127.  Any pointer may be NULL.
+ *   sum_score[n_alleles]  int64  : sum of AS over accepted records of the allele
+ *   n_hits[n_alleles]     uint32 : number of accepted records
+ *   locus_read_len_sum[L] uint64 : sum of len(SEQ) over reads with an accepted record on the locus
+ *   locus_first_read[L]   uint64 : smallest read index with an accepted record (UINT64_MAX if none; Q6)
+ *   counters[MLST_CNT_N]  uint64 */
+int mlst_get_allele_stats(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits,
+                          uint64_t* locus_read_len_sum, uint64_t* locus_first_read,
+                          uint64_t* counters);
+
+/* Multi-GPU: copy the additive statistics to / from a caller-owned DEVICE buffer so the
+ * host can all-reduce them with torch.distributed (RCCL).  Layout of d_sum (int64):
+ * [sum_score(n_alleles) | n_hits(n_alleles) | locus_read_len_sum(L) | counters(MLST_CNT_N)];
+ * d_min (int64, reduce with MIN): [locus_first_read(L)] (INT64_MAX if none). */
+int mlst_stats_flat_sizes(mlst_handle* h, uint64_t* n_sum, uint64_t* n_min);
+int mlst_export_stats_device(mlst_handle* h, int64_t* d_sum, int64_t* d_min);
+int mlst_import_stats_device(mlst_handle* h, const int64_t* d_sum, const int64_t* d_min);
+
+/* Pass 2: pileup of the retained reads against one chosen allele per locus.  Replaces
+ * cmseq get_base_stats over pysam pileup (metaMLST_functions.py:255-259).
+ *   chosen_allele_idx[n] : indices into the loaded allele list (at most one per locus)
+ *   counts : uint32[sum(len(chosen))][4] A,C,G,T, alleles in the order given.
+ * A base is counted iff its record has AS >= minscore and XM <= max_xm (true XM),
+ * Phred >= minqual and base in ACGT. */
+int mlst_pileup(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n, uint32_t* counts);
+int mlst_pileup_device(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n,
+                       uint32_t* d_counts /* device, n_cols*4, zeroed by the call */, uint64_t* n_cols);
+
+/* Allele match: Hamming distance of `query` against every allele of `locus`, semantics of
+ * stringDiff (metaMLST_functions.py:230-234: zip truncates, length difference not counted),
+ * as used by metamlst-merge.py:177-181.  Outputs the first allele (load order) within z,
+ * or -1, and the number of alleles within z. */
+int mlst_hamming_le(mlst_handle* h, uint32_t locus, const uint8_t* query, uint32_t len,
+                    uint32_t z, int32_t* first_allele_idx, uint32_t* n_within);
+/* Full distance vector (dist[n_alleles_of_locus]) for tests and reports. */
+int mlst_hamming_all(mlst_handle* h, uint32_t locus, const uint8_t* query, uint32_t len,
+                     uint32_t* dist);
+
+/* Forget reads and statistics, keep the reference (next sample). */
+int mlst_reset_sample(mlst_handle* h);
+
+/* ---- introspection (tests, bench) ---- */
+typedef struct mlst_item {     /* one (read, locus, strand, diagonal) unit of extension work */
+    uint64_t read_index;       /* index of the read in submission order */
+    uint32_t locus;
+    int32_t  diag;             /* allele position minus (oriented) read position */
+    uint16_t strand;           /* 1 = read reverse-complemented */
+    uint16_t votes;
+    uint32_t reserved;
+} mlst_item;
+int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint64_t* n);
+
+/* Per-kernel device time measured with HIP events on the engine's stream.
+ * which: 0=sieve 1=seed 2=extend 3=banded-SW 4=accumulate 5=pileup 6=pack */
+int mlst_set_profiling(mlst_handle* h, int on);
+int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms, uint64_t* launches);
+int mlst_reset_kernel_time(mlst_handle* h);
+/* Bytes of the device-resident index structures: [0]=allele arena [1]=sieve [2]=seed table */
+int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]);
+/* Block until all work queued on the engine's stream is done. */
+int mlst_synchronize(mlst_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+"""SQLite access helpers of the MLST hot path.
+
+Host-side counterparts of the thin SQL wrappers in metaMLST_functions.py (same names,
+argument meaning and return values) so the typing / merge logic reads like the reference.
+Not accelerated: these are a handful of indexed lookups per sample (SURVEY.md section 2,
+"DB access helpers").  Schema: metamlst-index.py:62-65.
+"""
+from __future__ import annotations
+
+import sqlite3
+
+
+class metaMLST_db:
+    """metaMLST_functions.py:428-481 (connection holder + defineProfile method)."""
+
+    def __init__(self, dbPath: str):
+        # metaMLST_functions.py:433-440
+        self.conn = sqlite3.connect(dbPath)
+        self.conn.row_factory = sqlite3.Row
+        self.cursor = self.conn.cursor()
+
+    def closeConnection(self) -> None:
+        self.conn.close()
+
+    def getGeneNames(self, profile: str) -> list[str]:
+        # metaMLST_functions.py:465-469
+        return [row["geneName"] for row in self.cursor.execute("SELECT geneName FROM genes WHERE bacterium = ?", (profile,))]
+
+    def defineProfile(self, geneList):
+        # metaMLST_functions.py:472-481
+        recs = []
+        result = None
+        for allele in geneList:
+            self.cursor.execute("SELECT recID FROM alleles WHERE bacterium||'_'||gene||'_'||alleleVariant = ?", (allele,))
+            result = self.cursor.fetchone()
+            if result:
+                recs.append(str(result["recID"]))
+        return _profile_query(self.cursor, recs) if result else [(0, 0)]
+
+
+def _profile_query(cursor, recs):
+    """The profile-matching SQL shared by both defineProfile variants
+    (metaMLST_functions.py:216 and :481): profiles sharing the maximum number of the given
+    alleles, with the share of alleles matched as an int percentage."""
+    inlist = ",".join(recs)
+    q = ("SELECT profileCode, COUNT(*) as T FROM profiles WHERE alleleCode IN (" + inlist + ") GROUP BY profileCode "
+         "HAVING T = (SELECT COUNT(*)  FROM profiles WHERE alleleCode IN (" + inlist + ") GROUP BY profileCode "
+         "ORDER BY COUNT(*) DESC LIMIT 1) ORDER BY T DESC")
+    return [(row["profileCode"], int((float(row["T"]) / float(len(recs))) * 100)) for row in cursor.execute(q)]
+
+
+def defineProfile(conn, geneList):
+    """metaMLST_functions.py:205-216 (module-level variant used by metamlst-merge.py:205).
+    Quirk Q9: only the LAST label's lookup decides the [(0,0)] fallback."""
+    recs = []
+    e = None
+    result = None
+    for allele in geneList:
+        e = conn.cursor()
+        e.execute("SELECT recID FROM alleles WHERE bacterium||'_'||gene||'_'||alleleVariant = ?", (allele,))
+        result = e.fetchone()
+        if result:
+            recs.append(str(result["recID"]))
+    return _profile_query(e, recs) if result else [(0, 0)]
+
+
+def sequenceExists(conn, bacterium, sequence) -> bool:
+    # metaMLST_functions.py:168-172
+    e = conn.cursor()
+    e.execute("SELECT 1 FROM alleles WHERE sequence = ? AND bacterium = ?", (str(sequence), bacterium))
+    return len(e.fetchall()) > 0
+
+
+def sequenceFind(conn, bacterium, sequence):
+    # metaMLST_functions.py:196-203 -- returns the GENE name (display only) or 0
+    e = conn.cursor()
+    e.execute("SELECT gene,alleleVariant FROM alleles WHERE sequence = ? AND bacterium = ?", (str(sequence), bacterium))
+    res = e.fetchone()
+    return res["gene"] if res else 0
+
+
+def sequenceLocate(conn, bacterium, sequence) -> str:
+    # metaMLST_functions.py:218-222
+    e = conn.cursor()
+    e.execute("SELECT alleleVariant FROM alleles WHERE sequence = ? AND bacterium = ?", (str(sequence), bacterium))
+    return str(e.fetchone()["alleleVariant"])
+
+
+def sequencesGetAll(conn, bacterium, gene) -> dict:
+    # metaMLST_functions.py:224-228
+    e = conn.cursor()
+    e.execute("SELECT sequence,alleleVariant FROM alleles WHERE gene = ? AND bacterium = ?", (gene, bacterium))
+    return dict((x["alleleVariant"], x["sequence"]) for x in e.fetchall())
+
+
+def db_getUnalSequence(conn, bacterium, gene, allele):
+    # metaMLST_functions.py:186-194
+    e = conn.cursor()
+    unalobj = e.execute("SELECT sequence FROM alleles WHERE bacterium = ? AND gene = ? AND alleleVariant = ?",
+                        (bacterium, gene, allele)).fetchone()
+    return unalobj["sequence"] if unalobj is not None else None
+
+
+def db_getOrganisms(conn, bacterium=None):
+    # metaMLST_functions.py:422-426
+    e = conn.cursor()
+    t = dict((elem["organismkey"], (elem["label"] if elem["label"] is not None else "(" + elem["organismkey"] + ")"))
+             for elem in e.execute("SELECT label,organismkey,COUNT(DISTINCT profileCode) AS totalProfiles FROM organisms,profiles "
+                                   "WHERE organismkey = bacterium GROUP BY label,organismkey"))
+    return t[bacterium] if bacterium else t
+
+
+def stringDiff(s1, s2) -> int:
+    """metaMLST_functions.py:230-234, restated for host-side checks of short strings.
+    The allele-match scan itself runs on the GPU (mlst_hamming_le)."""
+    c = 0
+    for a, b in zip(s1, s2):
+        if a != b:
+            c += 1
+    return c

@@ -1,0 +1,254 @@
+"""ctypes binding of libmlst_hip.so (include/mlst.h) -- the only compute path of the package.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present the
+constructor raises.  The oracle under oracle/ is test infrastructure and is never
+imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .index import AlleleIndex
+from .typing import SampleStats
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmlst_hip.so")
+
+MLST_CNT_N = 8
+CNT_TOTAL_RECORDS, CNT_IGNORED, CNT_READS_SEEN, CNT_CANDIDATES, CNT_RETAINED, CNT_ITEMS, CNT_DP_PAIRS = range(7)
+KERNELS = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup", "pack")
+
+
+class MlstParams(C.Structure):
+    """struct mlst_params (include/mlst.h)."""
+    _fields_ = [("minscore", C.c_int32), ("max_xm", C.c_int32), ("min_read_len", C.c_int32),
+                ("minqual", C.c_int32), ("mincov", C.c_int32), ("match_bonus", C.c_int32),
+                ("mm_max", C.c_int32), ("mm_min", C.c_int32), ("n_penalty", C.c_int32),
+                ("gap_open", C.c_int32), ("gap_ext", C.c_int32), ("gbar", C.c_int32),
+                ("band_w", C.c_int32), ("gap_trigger_mm", C.c_int32), ("xm_field_quirk", C.c_int32),
+                ("reserved0", C.c_int32), ("minscore_const", C.c_double), ("minscore_coef", C.c_double),
+                ("max_retained_reads", C.c_uint64), ("max_items", C.c_uint64), ("max_pair_results", C.c_uint64)]
+
+
+class MlstItem(C.Structure):
+    """struct mlst_item (include/mlst.h)."""
+    _fields_ = [("read_index", C.c_uint64), ("locus", C.c_uint32), ("diag", C.c_int32),
+                ("strand", C.c_uint16), ("votes", C.c_uint16), ("reserved", C.c_uint32)]
+
+
+def default_params() -> MlstParams:
+    """Defaults of mlst_policy.h, usable without loading the library (tests, oracle)."""
+    p = MlstParams()
+    p.minscore, p.max_xm, p.min_read_len, p.minqual, p.mincov = 80, 5, 50, 20, 1
+    p.match_bonus, p.mm_max, p.mm_min, p.n_penalty = 2, 6, 2, 1
+    p.gap_open, p.gap_ext, p.gbar, p.band_w = 5, 3, 4, 8
+    p.gap_trigger_mm, p.xm_field_quirk = 12, 1
+    p.minscore_const, p.minscore_coef = 20.0, 8.0
+    p.max_retained_reads = p.max_items = p.max_pair_results = 0
+    return p
+
+
+class MlstError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Load libmlst_hip.so and declare every prototype of include/mlst.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise MlstError("HIP engine library not built: %s is missing (run __graft_entry__.build()); "
+                        "there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    vp, u8p, u64p, u32p, i32p, i64p, u16p = (C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+    H = C.c_void_p
+    sig = {
+        "mlst_default_params": (None, [C.POINTER(MlstParams)]),
+        "mlst_create": (C.c_int, [C.c_int, C.POINTER(MlstParams), C.POINTER(H)]),
+        "mlst_destroy": (None, [H]),
+        "mlst_last_error": (C.c_char_p, [H]),
+        "mlst_load_reference": (C.c_int, [H, u8p, u64p, u32p, u32p, i32p, C.c_uint32]),
+        "mlst_submit_reads": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_int]),
+        "mlst_submit_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_int]),
+        "mlst_pack_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, u32p, u8p, u16p, C.c_uint32, C.c_uint32]),
+        "mlst_submit_packed_device": (C.c_int, [H, u32p, u8p, u16p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
+        "mlst_get_allele_stats": (C.c_int, [H, i64p, u32p, u64p, u64p, u64p]),
+        "mlst_stats_flat_sizes": (C.c_int, [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "mlst_export_stats_device": (C.c_int, [H, i64p, i64p]),
+        "mlst_import_stats_device": (C.c_int, [H, i64p, i64p]),
+        "mlst_pileup": (C.c_int, [H, u32p, C.c_uint32, u32p]),
+        "mlst_pileup_device": (C.c_int, [H, u32p, C.c_uint32, u32p, C.POINTER(C.c_uint64)]),
+        "mlst_hamming_le": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
+        "mlst_hamming_all": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, u32p]),
+        "mlst_reset_sample": (C.c_int, [H]),
+        "mlst_get_items": (C.c_int, [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "mlst_set_profiling": (C.c_int, [H, C.c_int]),
+        "mlst_get_kernel_time": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "mlst_reset_kernel_time": (C.c_int, [H]),
+        "mlst_get_index_bytes": (C.c_int, [H, C.POINTER(C.c_uint64)]),
+        "mlst_synchronize": (C.c_int, [H]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = the library does not export the ABI
+        fn.restype, fn.argtypes = res, args
+    lib._mlst_symbols = tuple(sig)
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One GPU's typing engine.  Mirrors the reference's per-sample flow:
+    load_reference (index) -> submit_reads* (alignment + hit accumulation) -> stats ->
+    pileup (consensus counts) -> hamming_le (allele match)."""
+
+    def __init__(self, device: int = 0, params: MlstParams | None = None):
+        self.lib = load_library()
+        self.params = params or default_params()
+        self._h = C.c_void_p()
+        rc = self.lib.mlst_create(int(device), C.byref(self.params), C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.mlst_last_error(None)
+            raise MlstError("mlst_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self.device = device
+        self.index: AlleleIndex | None = None
+
+    def close(self):
+        if self._h:
+            self.lib.mlst_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.mlst_last_error(self._h)
+            raise MlstError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    # ---- reference ----
+    def load_reference(self, index: AlleleIndex):
+        self.index = index
+        self._check(self.lib.mlst_load_reference(self._h, _ptr(index.ascii_concat), _ptr(index.off), _ptr(index.locus_id),
+                                                 _ptr(index.species_id), _ptr(index.allele_no), index.n_alleles),
+                    "mlst_load_reference")
+
+    # ---- pass 1 ----
+    def submit_reads(self, bases: np.ndarray, quals: np.ndarray, off: np.ndarray, paired: bool = False):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        self._check(self.lib.mlst_submit_reads(self._h, _ptr(bases), _ptr(quals), _ptr(off), len(off) - 1, int(paired)),
+                    "mlst_submit_reads")
+
+    def submit_reads_device(self, d_bases: int, d_quals: int, d_off: int, n_reads: int, max_len: int, paired: bool = False):
+        self._check(self.lib.mlst_submit_reads_device(self._h, d_bases, d_quals, d_off, n_reads, max_len, int(paired)),
+                    "mlst_submit_reads_device")
+
+    def pack_reads_device(self, d_bases: int, d_quals: int, d_off: int, n_reads: int, d_packed: int, d_qual_rows: int,
+                          d_lens: int, words_per_read: int, qual_stride: int):
+        self._check(self.lib.mlst_pack_reads_device(self._h, d_bases, d_quals, d_off, n_reads, d_packed, d_qual_rows, d_lens,
+                                                    words_per_read, qual_stride), "mlst_pack_reads_device")
+
+    def submit_packed_device(self, d_packed: int, d_qual_rows: int, d_lens: int, n_reads: int, words_per_read: int,
+                             qual_stride: int, paired: bool = False):
+        self._check(self.lib.mlst_submit_packed_device(self._h, d_packed, d_qual_rows, d_lens, n_reads, words_per_read,
+                                                       qual_stride, int(paired)), "mlst_submit_packed_device")
+
+    def stats(self) -> SampleStats:
+        nA, nL = self.index.n_alleles, self.index.n_loci
+        s = SampleStats(np.zeros(nA, np.int64), np.zeros(nA, np.uint32), np.zeros(nL, np.uint64),
+                        np.zeros(nL, np.uint64), np.zeros(MLST_CNT_N, np.uint64))
+        self._check(self.lib.mlst_get_allele_stats(self._h, _ptr(s.sum_score), _ptr(s.n_hits), _ptr(s.locus_len_sum),
+                                                   _ptr(s.locus_first), _ptr(s.counters)), "mlst_get_allele_stats")
+        return s
+
+    def flat_sizes(self) -> tuple[int, int]:
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.mlst_stats_flat_sizes(self._h, C.byref(a), C.byref(b)), "mlst_stats_flat_sizes")
+        return int(a.value), int(b.value)
+
+    def export_stats_device(self, d_sum: int, d_min: int):
+        self._check(self.lib.mlst_export_stats_device(self._h, d_sum, d_min), "mlst_export_stats_device")
+
+    def import_stats_device(self, d_sum: int, d_min: int):
+        self._check(self.lib.mlst_import_stats_device(self._h, d_sum, d_min), "mlst_import_stats_device")
+
+    # ---- pass 2 ----
+    def pileup(self, chosen: list[int]) -> dict[int, np.ndarray]:
+        """{allele idx: uint32[len, 4]} for the chosen alleles (A,C,G,T columns)."""
+        ch = np.ascontiguousarray(chosen, dtype=np.uint32)
+        lens = [int(self.index.off[a + 1] - self.index.off[a]) for a in chosen]
+        counts = np.zeros((sum(lens), 4), np.uint32)
+        self._check(self.lib.mlst_pileup(self._h, _ptr(ch), len(chosen), _ptr(counts)), "mlst_pileup")
+        out, at = {}, 0
+        for a, L in zip(chosen, lens):
+            out[int(a)] = counts[at:at + L]
+            at += L
+        return out
+
+    def pileup_device(self, chosen: list[int], d_counts: int) -> int:
+        ch = np.ascontiguousarray(chosen, dtype=np.uint32)
+        n = C.c_uint64()
+        self._check(self.lib.mlst_pileup_device(self._h, _ptr(ch), len(chosen), d_counts, C.byref(n)), "mlst_pileup_device")
+        return int(n.value)
+
+    # ---- allele match ----
+    def hamming_le(self, locus: int, query: bytes, z: int) -> tuple[int, int]:
+        q = np.frombuffer(query, dtype=np.uint8)
+        first, nw = C.c_int32(), C.c_uint32()
+        self._check(self.lib.mlst_hamming_le(self._h, locus, _ptr(q) if len(q) else None, len(q), z, C.byref(first), C.byref(nw)),
+                    "mlst_hamming_le")
+        return int(first.value), int(nw.value)
+
+    def hamming_all(self, locus: int, query: bytes) -> np.ndarray:
+        q = np.frombuffer(query, dtype=np.uint8)
+        d = np.zeros(int(self.index.locus_count[locus]), np.uint32)
+        self._check(self.lib.mlst_hamming_all(self._h, locus, _ptr(q) if len(q) else None, len(q), _ptr(d)), "mlst_hamming_all")
+        return d
+
+    # ---- misc ----
+    def reset_sample(self):
+        self._check(self.lib.mlst_reset_sample(self._h), "mlst_reset_sample")
+
+    def items(self, cap: int = 1 << 20) -> np.ndarray:
+        buf = (MlstItem * cap)()
+        n = C.c_uint64()
+        self._check(self.lib.mlst_get_items(self._h, C.cast(buf, C.c_void_p), cap, C.byref(n)), "mlst_get_items")
+        k = min(cap, int(n.value))
+        return np.array([(b.read_index, b.locus, b.strand, b.diag, b.votes) for b in buf[:k]], dtype=np.int64).reshape(-1, 5)
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.mlst_set_profiling(self._h, int(on)), "mlst_set_profiling")
+
+    def kernel_time(self, which: int | str) -> tuple[float, int]:
+        w = KERNELS.index(which) if isinstance(which, str) else which
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.lib.mlst_get_kernel_time(self._h, w, C.byref(ms), C.byref(n)), "mlst_get_kernel_time")
+        return float(ms.value), int(n.value)
+
+    def reset_kernel_time(self):
+        self._check(self.lib.mlst_reset_kernel_time(self._h), "mlst_reset_kernel_time")
+
+    def index_bytes(self) -> list[int]:
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.mlst_get_index_bytes(self._h, out), "mlst_get_index_bytes")
+        return [int(x) for x in out]
+
+    def synchronize(self):
+        self._check(self.lib.mlst_synchronize(self._h), "mlst_synchronize")

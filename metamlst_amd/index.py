@@ -1,0 +1,105 @@
+"""SQLite allele table -> flat arrays for mlst_load_reference.
+
+Counterpart of dump_db_to_fasta (metaMLST_functions.py:149-161: every allele with
+sequence <> '', contig name bacterium_gene_alleleVariant) feeding bowtie2-build
+(metamlst-index.py:222-247).  Here the "index" is built on the GPU side by
+mlst_load_reference; this module only orders the alleles so that each locus is contiguous
+and keeps the maps back to (species, gene, alleleVariant).
+"""
+from __future__ import annotations
+
+import sqlite3
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class AlleleIndex:
+    species: list[str]                      # species_id -> organism key
+    loci: list[tuple[str, str]]             # locus id -> (species, gene)
+    locus_id: np.ndarray                    # uint32[n_alleles]
+    species_id: np.ndarray                  # uint32[n_alleles]
+    allele_no: np.ndarray                   # int32[n_alleles]  (alleles.alleleVariant)
+    rec_id: np.ndarray                      # int64[n_alleles]  (alleles.recID)
+    off: np.ndarray                         # uint64[n_alleles+1]
+    ascii_concat: np.ndarray                # uint8
+    locus_begin: np.ndarray                 # int64[n_loci]
+    locus_count: np.ndarray                 # int64[n_loci]
+    locus_species: np.ndarray               # uint32[n_loci]
+    locus_maxlen: np.ndarray                # int64[n_loci]  (SELECT LENGTH(sequence) ... ORDER BY L DESC LIMIT 1, metamlst.py:225)
+
+    @property
+    def n_alleles(self) -> int:
+        return int(self.locus_id.shape[0])
+
+    @property
+    def n_loci(self) -> int:
+        return len(self.loci)
+
+    def sequence(self, a: int) -> str:
+        return self.ascii_concat[int(self.off[a]):int(self.off[a + 1])].tobytes().decode()
+
+    def label(self, a: int) -> str:
+        sp, gene = self.loci[int(self.locus_id[a])]
+        return "%s_%s_%d" % (sp, gene, int(self.allele_no[a]))
+
+    def locus_index(self, species: str, gene: str) -> int:
+        return self._locus_map[(species, gene)]
+
+    def __post_init__(self):
+        self._locus_map = {k: i for i, k in enumerate(self.loci)}
+
+
+def load_index(db_path: str, species_filter: list[str] | None = None) -> AlleleIndex:
+    """Read alleles as dump_db_to_fasta does (sequence <> ''), optionally restricted to
+    the --filter species (metamlst.py:114 applies the filter per record; not loading the
+    other species' alleles is equivalent for every output of the path)."""
+    conn = sqlite3.connect(db_path)
+    q = "SELECT recID,bacterium,gene,alleleVariant,sequence FROM alleles WHERE sequence <> ''"
+    rows = conn.execute(q).fetchall()
+    conn.close()
+    if species_filter:
+        keep = set(species_filter)
+        rows = [r for r in rows if r[1] in keep]
+    # contiguous loci; allele order inside a locus = (alleleVariant, recID)
+    rows.sort(key=lambda r: (r[1], r[2], int(r[3]), r[0]))
+    species, loci = [], []
+    sp_map, lo_map = {}, {}
+    n = len(rows)
+    locus_id = np.zeros(n, np.uint32)
+    species_id = np.zeros(n, np.uint32)
+    allele_no = np.zeros(n, np.int32)
+    rec_id = np.zeros(n, np.int64)
+    off = np.zeros(n + 1, np.uint64)
+    chunks = []
+    for i, (rid, sp, gene, av, seq) in enumerate(rows):
+        if sp not in sp_map:
+            sp_map[sp] = len(species)
+            species.append(sp)
+        key = (sp, gene)
+        if key not in lo_map:
+            lo_map[key] = len(loci)
+            loci.append(key)
+        locus_id[i] = lo_map[key]
+        species_id[i] = sp_map[sp]
+        allele_no[i] = int(av)
+        rec_id[i] = rid
+        b = seq.encode()
+        chunks.append(b)
+        off[i + 1] = off[i] + np.uint64(len(b))
+    ascii_concat = np.frombuffer(b"".join(chunks), dtype=np.uint8).copy() if chunks else np.zeros(0, np.uint8)
+    nl = len(loci)
+    locus_begin = np.zeros(nl, np.int64)
+    locus_count = np.zeros(nl, np.int64)
+    locus_species = np.zeros(nl, np.uint32)
+    locus_maxlen = np.zeros(nl, np.int64)
+    lens = (off[1:] - off[:-1]).astype(np.int64)
+    for l in range(nl):
+        idx = np.nonzero(locus_id == l)[0]
+        locus_begin[l] = idx[0]
+        locus_count[l] = len(idx)
+        locus_species[l] = species_id[idx[0]]
+        locus_maxlen[l] = lens[idx].max()
+    return AlleleIndex(species, loci, locus_id, species_id, allele_no, rec_id, off, ascii_concat,
+                       locus_begin, locus_count, locus_species, locus_maxlen)

@@ -1,0 +1,183 @@
+"""Host side of the ST call: counterpart of metamlst-merge.py:93-341.
+
+Parses the .nfo lines written by the typing run, matches every reconstructed locus to the
+database (exact match, recurring new sequence, or new allele accepted when some database
+allele of the locus is within `z` mismatches), resolves the ST with defineProfile and writes
+merged/<species>_ST.txt and merged/<species>_report.txt.
+
+The only heavy step -- the stringDiff scan over every allele of a locus
+(metamlst-merge.py:177-181) -- is delegated to `matcher`, which in the product is the GPU
+Hamming kernel (Engine.hamming_le).  Sequence outputs (--outseqformat, MUSCLE) are out of scope.
+"""
+from __future__ import annotations
+
+import os
+
+from . import db as mdb
+
+
+def parse_nfo_folder(folder: str, filter: str | None = None) -> dict:
+    """metamlst-merge.py:93-107.  cel[organism] = [({label: (SEQ.upper(), acc, snp%)}, sample), ...].
+    Note the species filter here is a SUBSTRING test on the raw option string (Q12)."""
+    cel: dict = {}
+    for file in sorted(os.listdir(folder)):
+        if file.split(".")[-1] != "nfo":
+            continue
+        for line in open(folder + "/" + file, "r"):
+            organism = line.split()[0]
+            sampleName = line.split()[1]
+            genes = line.split()[2::]
+            if filter and organism not in filter:
+                continue
+            if organism not in cel:
+                cel[organism] = []
+            cel[organism].append((dict((x.split("::")[0], (x.split("::")[1].upper(), x.split("::")[2], x.split("::")[3]))
+                                       for x in genes), sampleName))
+    return cel
+
+
+class EngineMatcher:
+    """`matcher` backed by the GPU engine: is any loaded allele of (species, gene) within z of seq?"""
+
+    def __init__(self, engine, index):
+        self.engine, self.index = engine, index
+
+    def __call__(self, bacterium: str, geneName: str, geneSeq: str, z: int) -> bool:
+        locus = self.index.locus_index(bacterium, geneName)
+        first, _ = self.engine.hamming_le(locus, geneSeq.encode(), z)
+        return first >= 0
+
+
+def call_species(database: mdb.metaMLST_db, bacterium: str, bactRecord: list, z: int | None, matcher) -> dict:
+    """metamlst-merge.py:112-240 for one organism.  Returns the tables the writers need."""
+    conn, cursor = database.conn, database.cursor
+    oldProfiles: dict = {}
+    genesBase: dict = {}
+    encounteredProfiles: dict = {}
+    isolates: list = []
+    newSequences: dict = {}
+    lastProfile = 100000                                                     # merge:134
+    lastGenes = dict((row["gene"], 100000) for row in cursor.execute(
+        "SELECT gene, MAX(alleleVariant) as maxGene FROM alleles WHERE bacterium = ? GROUP BY gene", (bacterium,)))   # merge:136
+    for row in cursor.execute("SELECT profileCode,gene,alleleVariant FROM profiles,alleles WHERE alleleCode = alleles.recID "
+                              "AND alleles.bacterium = ?", (bacterium,)):     # merge:140-142
+        if row["profileCode"] not in oldProfiles:
+            oldProfiles[row["profileCode"]] = [0, {}]
+        oldProfiles[row["profileCode"]][1][row["gene"]] = row["alleleVariant"]
+
+    for bacteriumLine, sampleRecord in bactRecord:                            # merge:144
+        profileLine = {}
+        newAlleles = []
+        flagRecurrent = False
+        sum_of_accuracies = 0.0
+        for geneLabel, (geneSeq, geneAccur, percent_snps) in bacteriumLine.items():
+            geneOrganism, geneName, geneAllele = geneLabel.split("_")
+            sum_of_accuracies += float(geneAccur)
+            if geneSeq == "" or mdb.sequenceExists(conn, bacterium, geneSeq):     # merge:157
+                if geneSeq != "":
+                    geneAllele = mdb.sequenceLocate(conn, bacterium, geneSeq)
+                profileLine[geneName] = (geneAllele, 0)
+            elif geneSeq in genesBase:                                            # merge:164
+                profileLine[geneName] = (genesBase[geneSeq].split("_")[2], 2)
+                flagRecurrent = True
+            else:                                                                 # merge:168-196
+                geneCategoryCode = 1
+                if z is not None:
+                    geneCategoryCode = 3
+                    # stringDiff(geneSeq, '') == 0: an allele row with an empty sequence accepts anything
+                    empty = cursor.execute("SELECT 1 FROM alleles WHERE gene = ? AND bacterium = ? AND sequence = ''",
+                                           (geneName, bacterium)).fetchone()
+                    if (empty and 0 <= z) or matcher(bacterium, geneName, geneSeq, z):
+                        geneCategoryCode = 1
+                geneNewAlleleNumber = str(lastGenes[geneName] + 1)
+                lastGenes[geneName] += 1
+                geneNewLabel = geneOrganism + "_" + geneName + "_" + geneNewAlleleNumber
+                genesBase[geneSeq] = geneNewLabel
+                profileLine[geneName] = (geneNewAlleleNumber, geneCategoryCode)
+                newAlleles.append(geneName)
+                newSequences.setdefault(geneName, []).append((geneNewLabel, geneSeq))
+
+        meanAccuracy = sum_of_accuracies / float(len(bacteriumLine))              # merge:199
+        if len(newAlleles) == 0:
+            if not flagRecurrent:
+                tryDefine = mdb.defineProfile(conn, [bacterium + "_" + k + "_" + v[0] for k, v in profileLine.items()])
+                if tryDefine and tryDefine[0][1] == 100:                          # merge:207
+                    oldProfiles[tryDefine[0][0]][0] += 1
+                    isolates.append((tryDefine[0][0], meanAccuracy, sampleRecord))
+                    continue
+            foundExistant = 0
+            for key, (element, abundance, isNewProfile) in encounteredProfiles.items():
+                if [k + str(v[0]) for k, v in sorted(profileLine.items())] == [k + str(v[0]) for k, v in sorted(element.items())]:
+                    foundExistant = key
+            if foundExistant:
+                encounteredProfiles[foundExistant][1] += 1
+                isolates.append((foundExistant, meanAccuracy, sampleRecord))
+            else:
+                lastProfile += 1
+                encounteredProfiles[lastProfile] = [profileLine, 1, 2]
+                isolates.append((lastProfile, meanAccuracy, sampleRecord))
+        else:
+            lastProfile += 1                                                      # merge:229
+            profileCategoryCode = 1
+            if z is not None:
+                for k, (v, cat) in profileLine.items():
+                    if cat == 3:
+                        profileCategoryCode = 3
+                        break
+            encounteredProfiles[lastProfile] = [profileLine, 1, profileCategoryCode]
+            if profileCategoryCode != 3:
+                isolates.append((lastProfile, meanAccuracy, sampleRecord))
+    return dict(oldProfiles=oldProfiles, encounteredProfiles=encounteredProfiles, isolates=isolates,
+                lastGenes=lastGenes, newSequences=newSequences)
+
+
+def write_species(folder: str, bacterium: str, tables: dict, meta: str | None = None, idField: int = 0) -> None:
+    """metamlst-merge.py:119,253-292 (<sp>_ST.txt) and :298-341 (<sp>_report.txt)."""
+    oldProfiles, encounteredProfiles = tables["oldProfiles"], tables["encounteredProfiles"]
+    isolates, lastGenes = tables["isolates"], tables["lastGenes"]
+    with open(folder + "/merged/" + bacterium + "_ST.txt", "w", newline="") as profil:
+        profil.write("ST\t" + "\t".join([x for x in sorted(lastGenes.keys())]) + "\r\n")
+        for profileCode, (hits, profile) in oldProfiles.items():
+            profil.write(str(profileCode) + "\t" + "\t".join([str(v) for k, v in sorted(profile.items())]) + "\r\n")
+        for profileID, (profile, hits, profileCategoryCode) in encounteredProfiles.items():
+            if profileCategoryCode not in [1, 2]:
+                continue
+            profil.write(str(profileID) + "\t" + "\t".join([str(v[0]) for k, v in sorted(profile.items())]) + "\n")
+    identifiers = {}
+    p1line = False
+    keys = []
+    if meta:
+        for line in open(meta):
+            if line == "":
+                continue
+            if not p1line:
+                p1line = True
+                keys = [str(x).strip() for x in line.split("\t")]
+            else:
+                l = line.strip().split("\t")
+                if len(l) == len(keys):
+                    identifiers[l[idField]] = dict((keys[i], l[i]) for i in range(0, len(keys)))
+    with open(folder + "/merged/" + bacterium + "_report.txt", "w", newline="") as isolafil:
+        isolafil.write("ST\tConfidence\t" + "\t".join(keys) + "\n")
+        for profileST, meanAccur, sampleName in isolates:
+            if sampleName.endswith(".fna"):
+                sampleName = sampleName.split(".")[0]
+            if sampleName in identifiers:
+                strl = [identifiers[sampleName][ky] for ky in keys]
+                isolafil.write(str(profileST) + "\t" + str(round(meanAccur, 2)) + "\t" + "\t".join(strl) + "\n")
+            else:
+                isolafil.write(str(profileST) + "\t" + str(round(meanAccur, 2)) + "\t" + str(sampleName) + "\n")
+
+
+def merge_folder(folder: str, database: mdb.metaMLST_db, matcher, z: int | None = 5, filter: str | None = None,
+                 meta: str | None = None, idField: int = 0) -> dict:
+    """The whole metamlst-merge.py run for one folder of .nfo files.  Returns {species: tables}."""
+    if not os.path.isdir(folder + "/merged"):
+        os.makedirs(folder + "/merged")
+    cel = parse_nfo_folder(folder, filter)
+    out = {}
+    for bacterium, bactRecord in cel.items():
+        tables = call_species(database, bacterium, bactRecord, z, matcher)
+        write_species(folder, bacterium, tables, meta, idField)
+        out[bacterium] = tables
+    return out

@@ -1,0 +1,227 @@
+"""Seeded synthetic inputs for the MLST-typing hot path.
+
+The real metamlstDB_2022 is downloaded at first run by the reference
+(metaMLST_functions.py:39-57) and is not available offline, so tests and the
+benchmark use a schema-compatible SQLite database (tables as created at
+metamlst-index.py:62-65), isolate genomes with the alleles of a chosen ST embedded,
+and Illumina-like reads sampled from them.  Everything is a pure function of its seed.
+"""
+from __future__ import annotations
+
+import sqlite3
+from dataclasses import dataclass, field
+
+import numpy as np
+
+SEED = 20221
+ECOLI_LOCI = [("adk", 536), ("fumC", 469), ("gyrB", 460), ("icd", 518),
+              ("mdh", 452), ("purA", 478), ("recA", 510)]
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+_COMP[:] = ord("N")
+for _a, _b in zip(b"ACGTacgt", b"TGCAtgca"):
+    _COMP[_a] = _b
+
+
+def create_schema(conn: sqlite3.Connection) -> None:
+    """The four tables of the MetaMLST database, as created at metamlst-index.py:62-65."""
+    c = conn.cursor()
+    c.execute("CREATE TABLE IF NOT EXISTS organisms (organismkey varchar(255), label VARCHAR(255), PRIMARY KEY(organismkey))")
+    c.execute("CREATE TABLE IF NOT EXISTS genes (geneName varchar(255), bacterium VARCHAR(255), PRIMARY KEY(geneName,bacterium))")
+    c.execute("CREATE TABLE IF NOT EXISTS alleles (recID INTEGER PRIMARY KEY AUTOINCREMENT,bacterium varchar(255), gene VARCHAR(255), sequence TEXT, alignedSequence TEXT, alleleVariant INT)")
+    c.execute("CREATE TABLE IF NOT EXISTS profiles (recID INTEGER PRIMARY KEY AUTOINCREMENT, profileCode INTEGER, bacterium VARCHAR(255), alleleCode INTEGER)")
+    conn.commit()
+
+
+def gen_locus_alleles(rng: np.random.Generator, length: int, n_alleles: int, max_div: float = 0.03,
+                      snp_lo: int = 1, snp_hi: int = 8, indel_every: int = 0) -> list[np.ndarray]:
+    """Alleles of one locus: a random root and a random tree with snp_lo..snp_hi SNPs per edge,
+    every allele within max_div of the root, all distinct.  indel_every > 0 additionally gives
+    every indel_every-th allele a 1-3 bp deletion (exercises the banded Smith-Waterman path)."""
+    root = rng.integers(0, 4, size=length, dtype=np.uint8)
+    alleles = [root]
+    ndiff = [0]
+    seen = {root.tobytes()}
+    budget = max(snp_lo, int(max_div * length))
+    guard = 0
+    while len(alleles) < n_alleles:
+        guard += 1
+        if guard > 200 * n_alleles:
+            raise RuntimeError("allele generator cannot reach the requested count")
+        p = int(rng.integers(len(alleles)))
+        k = int(rng.integers(snp_lo, snp_hi + 1))
+        if ndiff[p] + k > budget:
+            continue
+        child = alleles[p].copy()
+        pos = rng.choice(len(child), size=k, replace=False)
+        child[pos] = (child[pos] + rng.integers(1, 4, size=k, dtype=np.uint8)) % 4
+        if indel_every and len(alleles) % indel_every == 0 and len(child) == length:
+            dl = int(rng.integers(1, 4))
+            at = int(rng.integers(60, len(child) - 60))
+            child = np.delete(child, np.arange(at, at + dl))
+        b = child.tobytes()
+        if b in seen:
+            continue
+        seen.add(b)
+        alleles.append(child)
+        ndiff.append(ndiff[p] + k)
+    return alleles
+
+
+@dataclass
+class SynthDB:
+    path: str
+    species: list[str]
+    loci: dict[str, list[tuple[str, int]]]                 # species -> [(gene, length)]
+    n_alleles: dict[tuple[str, str], int] = field(default_factory=dict)
+    profiles: dict[str, np.ndarray] = field(default_factory=dict)   # species -> int array [n_st, n_loci] (allele numbers)
+
+
+def make_db(path: str, species_loci: dict[str, list[tuple[str, int]]], alleles_per_locus: int,
+            n_profiles: int, seed: int = SEED, indel_every: int = 0, max_div: float = 0.03) -> SynthDB:
+    """Write a schema-compatible SQLite database.  Allele numbers run 1..alleles_per_locus;
+    sequence type k (1-based) is a random allele tuple (profiles rows point at alleles.recID)."""
+    rng = np.random.default_rng(seed)
+    conn = sqlite3.connect(path)
+    create_schema(conn)
+    cur = conn.cursor()
+    db = SynthDB(path=path, species=list(species_loci), loci=species_loci)
+    for sp, loci in species_loci.items():
+        cur.execute("INSERT INTO organisms (organismkey,label) VALUES (?,?)", (sp, "Synthetic " + sp))
+        recid = {}
+        for gene, length in loci:
+            cur.execute("INSERT INTO genes (geneName,bacterium) VALUES (?,?)", (gene, sp))
+            alleles = gen_locus_alleles(rng, length, alleles_per_locus, max_div=max_div, indel_every=indel_every)
+            db.n_alleles[(sp, gene)] = len(alleles)
+            for k, a in enumerate(alleles, start=1):
+                s = _ACGT[a].tobytes().decode()
+                cur.execute("INSERT INTO alleles (bacterium,gene,sequence,alignedSequence,alleleVariant) VALUES (?,?,?,?,?)",
+                            (sp, gene, s, s, k))
+                recid[(gene, k)] = cur.lastrowid
+        prof = np.stack([rng.integers(1, db.n_alleles[(sp, g)] + 1, size=n_profiles) for g, _ in loci], axis=1)
+        # distinct profiles only
+        _, first = np.unique(prof, axis=0, return_index=True)
+        prof = prof[np.sort(first)]
+        db.profiles[sp] = prof
+        rows = []
+        for st, tup in enumerate(prof, start=1):
+            for (gene, _), al in zip(loci, tup):
+                rows.append((st, sp, recid[(gene, int(al))]))
+        cur.executemany("INSERT INTO profiles (profileCode,bacterium,alleleCode) VALUES (?,?,?)", rows)
+    conn.commit()
+    conn.close()
+    return db
+
+
+def make_ecoli_db(path: str, alleles_per_locus: int = 1430, n_profiles: int = 5000, seed: int = SEED,
+                  indel_every: int = 0) -> SynthDB:
+    """DB-ecoli of SURVEY.md 8(d): 7 loci with Achtman-scheme lengths, ~10 k alleles."""
+    return make_db(path, {"ecoli": list(ECOLI_LOCI)}, alleles_per_locus, n_profiles, seed, indel_every)
+
+
+def make_full_db(path: str, n_species: int = 150, alleles_per_locus: int = 300, n_profiles: int = 200,
+                 seed: int = SEED) -> SynthDB:
+    """DB-full of SURVEY.md 8(d): stand-in for metamlstDB_2022 (n_species x 7 loci, lengths U[400,600])."""
+    rng = np.random.default_rng(seed + 1)
+    sl = {}
+    for s in range(n_species):
+        sl["sp%03d" % s] = [("g%d" % g, int(rng.integers(400, 601))) for g in range(7)]
+    return make_db(path, sl, alleles_per_locus, n_profiles, seed)
+
+
+def allele_sequence(db_path: str, species: str, gene: str, allele: int) -> str:
+    conn = sqlite3.connect(db_path)
+    row = conn.execute("SELECT sequence FROM alleles WHERE bacterium=? AND gene=? AND alleleVariant=?",
+                       (species, gene, allele)).fetchone()
+    conn.close()
+    return row[0]
+
+
+def make_genome(db: SynthDB, species: str, allele_tuple, size: int = 4_600_000, seed: int = SEED,
+                mutate: dict[str, list[tuple[int, str]]] | None = None) -> tuple[np.ndarray, dict[str, int]]:
+    """An isolate genome: uniform-random ACGT with the given alleles embedded at spread-out
+    positions on the forward strand.  mutate = {gene: [(pos, base), ...]} plants SNPs in the
+    embedded copy (a novel allele).  Returns (ASCII uint8 array, {gene: start})."""
+    rng = np.random.default_rng(seed + 7)
+    g = _ACGT[rng.integers(0, 4, size=size, dtype=np.uint8)]
+    loci = db.loci[species]
+    starts = {}
+    slot = size // (len(loci) + 1)
+    for k, ((gene, _), al) in enumerate(zip(loci, allele_tuple)):
+        seq = np.frombuffer(allele_sequence(db.path, species, gene, int(al)).encode(), dtype=np.uint8).copy()
+        if mutate and gene in mutate:
+            for pos, base in mutate[gene]:
+                seq[pos] = ord(base)
+        at = slot * (k + 1) + int(rng.integers(0, 1000))
+        g[at:at + len(seq)] = seq
+        starts[gene] = at
+    return g, starts
+
+
+def sample_reads(genome: np.ndarray, n_reads: int, read_len: int = 150, seed: int = SEED,
+                 err_rate: float = 0.001, q_good: int = 40, q_bad: int = 15,
+                 region: tuple[int, int] | None = None) -> tuple[np.ndarray, np.ndarray]:
+    """Single-end reads uniform over both strands; Phred q_good everywhere except substitution
+    errors (rate err_rate) reported at q_bad.  Returns (bases[n, L], quals[n, L]) as ASCII
+    (quals Phred+33).  region=(lo, hi) restricts read starts (used to build on-locus fixtures)."""
+    rng = np.random.default_rng(seed + 13)
+    lo, hi = (0, len(genome) - read_len) if region is None else (max(0, region[0]), min(region[1], len(genome) - read_len))
+    start = rng.integers(lo, hi + 1, size=n_reads)
+    idx = start[:, None] + np.arange(read_len)[None, :]
+    bases = genome[idx]
+    rev = rng.random(n_reads) < 0.5
+    bases[rev] = _COMP[bases[rev][:, ::-1]]
+    quals = np.full((n_reads, read_len), q_good + 33, dtype=np.uint8)
+    if err_rate > 0:
+        err = rng.random((n_reads, read_len)) < err_rate
+        ne = int(err.sum())
+        if ne:
+            code = np.searchsorted(_ACGT, bases[err])
+            bases[err] = _ACGT[(code + rng.integers(1, 4, size=ne)) % 4]
+            quals[err] = q_bad + 33
+    return bases, quals
+
+
+def sample_pairs(genome: np.ndarray, n_pairs: int, read_len: int = 150, insert_mean: float = 300.0,
+                 insert_sd: float = 30.0, seed: int = SEED, err_rate: float = 0.001,
+                 region: tuple[int, int] | None = None) -> tuple[np.ndarray, np.ndarray]:
+    """Paired-end 2 x read_len, insert ~ N(mean, sd) (mates may overlap).  Mates are interleaved:
+    rows 2k and 2k+1.  cfg5 of SURVEY.md 8(d)."""
+    rng = np.random.default_rng(seed + 17)
+    ins = np.clip(rng.normal(insert_mean, insert_sd, size=n_pairs).astype(np.int64), read_len, None)
+    lo, hi = (0, len(genome) - int(ins.max())) if region is None else (max(0, region[0]), min(region[1], len(genome) - int(ins.max())))
+    start = rng.integers(lo, hi + 1, size=n_pairs)
+    i1 = start[:, None] + np.arange(read_len)[None, :]
+    i2 = (start + ins - read_len)[:, None] + np.arange(read_len)[None, :]
+    m1 = genome[i1]
+    m2 = _COMP[genome[i2][:, ::-1]]
+    flip = rng.random(n_pairs) < 0.5
+    m1f, m2f = m1.copy(), m2.copy()
+    m1f[flip], m2f[flip] = m2[flip], m1[flip]
+    bases = np.empty((2 * n_pairs, read_len), dtype=np.uint8)
+    bases[0::2], bases[1::2] = m1f, m2f
+    quals = np.full(bases.shape, 40 + 33, dtype=np.uint8)
+    if err_rate > 0:
+        err = rng.random(bases.shape) < err_rate
+        ne = int(err.sum())
+        if ne:
+            code = np.searchsorted(_ACGT, bases[err])
+            bases[err] = _ACGT[(code + rng.integers(1, 4, size=ne)) % 4]
+            quals[err] = 15 + 33
+    return bases, quals
+
+
+def flatten_reads(bases: np.ndarray, quals: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """[n, L] arrays -> (bases concat, quals concat, uint64 offsets[n+1]) for mlst_submit_reads."""
+    n, L = bases.shape
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    return np.ascontiguousarray(bases).reshape(-1), np.ascontiguousarray(quals).reshape(-1), off
+
+
+def ragged_reads(reads: list[bytes], quals: list[bytes]) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Variable-length reads -> concatenated arrays + offsets."""
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    b = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if reads else np.zeros(0, np.uint8)
+    q = np.frombuffer(b"".join(quals), dtype=np.uint8).copy() if quals else np.zeros(0, np.uint8)
+    return b, q, off

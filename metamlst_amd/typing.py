@@ -1,0 +1,286 @@
+"""Host side of the typing run: counterpart of metamlst.py:133-289.
+
+The GPU engine replaces bowtie2 + samtools + pysam + cmseq and hands back exact integer
+statistics; everything with floating point or text formatting stays here in Python so that
+`round()` and `str(float)` behave exactly as in the reference (SURVEY.md 8a rows a3-a8 and
+quirks Q5-Q8, Q13, Q14).  Console colouring (metamlst_print, bcolors) is out of scope.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import db as mdb
+from .index import AlleleIndex
+
+
+@dataclass
+class TypingArgs:
+    """argparse defaults of metamlst.py:34-49."""
+    penalty: int = 100
+    minscore: int = 80
+    max_xM: int = 5
+    min_read_len: int = 50
+    min_accuracy: float = 0.90
+    nloci: int = 100
+    a: bool = False
+    quiet: bool = True
+    filter: str | None = None
+    log: bool = False
+    debug: bool = False
+
+
+@dataclass
+class SampleStats:
+    """What pass 1 returns (mlst_get_allele_stats): the content of `cel` and `sequenceBank`
+    (metamlst.py:116-127) as exact integers."""
+    sum_score: np.ndarray      # int64[n_alleles]
+    n_hits: np.ndarray         # uint32[n_alleles]
+    locus_len_sum: np.ndarray  # uint64[n_loci]
+    locus_first: np.ndarray    # uint64[n_loci]
+    counters: np.ndarray       # uint64[MLST_CNT_N]
+
+
+class SeqRecordLite:
+    """The three SeqRecord fields buildConsensus fills (metaMLST_functions.py:276)."""
+    __slots__ = ("seq", "id", "description", "seqLen")
+
+    def __init__(self, seq: str, id: str, description: str):
+        self.seq, self.id, self.description, self.seqLen = seq, id, description, None
+
+
+NO_READ = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def compile_cel(index: AlleleIndex, st: SampleStats, penalty: int) -> dict:
+    """metamlst.py:133-151.  cel[species][gene][allele] = (localScore, nHits, round(avg, 1)).
+    An allele is present iff it has an accepted record; dict orders follow first appearance in
+    the read stream (Q6): species by their earliest locus, genes by locus_first, alleles by number."""
+    loci_hit = [l for l in range(index.n_loci) if st.locus_first[l] != NO_READ]
+    loci_hit.sort(key=lambda l: (int(st.locus_first[l]), l))
+    cel: dict = {}
+    for l in loci_hit:
+        sp, gene = index.loci[l]
+        b, c = int(index.locus_begin[l]), int(index.locus_count[l])
+        nh = st.n_hits[b:b + c]
+        hit = np.nonzero(nh)[0]
+        if hit.size == 0:
+            continue
+        maxLen = int(nh[hit].max())
+        geneInfo = {}
+        for k in hit:
+            a = b + int(k)
+            geneLen = int(nh[k])
+            localScore = int(st.sum_score[a])
+            if geneLen != maxLen:
+                localScore = localScore - (maxLen - geneLen) * penalty
+            averageScore = float(localScore) / float(geneLen)
+            geneInfo[str(int(index.allele_no[a]))] = (localScore, geneLen, round(averageScore, 1))
+        cel.setdefault(sp, {})[gene] = geneInfo
+    return cel
+
+
+def pick_alleles(cel_species: dict, speciesKey: str) -> list[tuple[str, str]]:
+    """metamlst.py:244 without the SQL: per gene the label of the allele with the highest
+    rounded average, ties resolved by the lowest integer allele number (Q5)."""
+    out = []
+    for g1, g2 in cel_species.items():
+        best = max(avg1 for (_, _, avg1) in g2.values())
+        cands = [k for k, (_, _, avg) in g2.items() if avg == best]
+        k = sorted(cands, key=lambda x: int(x))[0]
+        out.append((g1, k))
+    return out
+
+
+def pick_alleles_fast(index: AlleleIndex, st: SampleStats, penalty: int) -> dict[int, int]:
+    """Same decision as compile_cel + pick_alleles for every locus at once: {locus: allele idx}.
+    Exactness: Python's round(x, 1) is correctly rounded and monotone, so the winning rounded
+    average is round(max x); only alleles with x within 0.11 of the maximum can tie with it, and
+    those few are rounded with Python's own round()."""
+    chosen = {}
+    nh_all = st.n_hits.astype(np.int64)
+    for l in range(index.n_loci):
+        if st.locus_first[l] == NO_READ:
+            continue
+        b, c = int(index.locus_begin[l]), int(index.locus_count[l])
+        nh = nh_all[b:b + c]
+        hit = np.nonzero(nh)[0]
+        if hit.size == 0:
+            continue
+        nhh = nh[hit]
+        local = st.sum_score[b:b + c][hit] - (nhh.max() - nhh) * penalty
+        x = local.astype(np.float64) / nhh.astype(np.float64)
+        near = np.nonzero(x >= x.max() - 0.11)[0]
+        best, best_no, best_a = None, None, None
+        for t in near:
+            r = round(float(int(local[t])) / float(int(nhh[t])), 1)
+            a = b + int(hit[t])
+            no = int(index.allele_no[a])
+            if best is None or r > best or (r == best and no < best_no):
+                best, best_no, best_a = r, no, a
+        chosen[l] = best_a
+    return chosen
+
+
+def consensus_from_counts(counts: np.ndarray, mincov: int = 1, none_char: str = "N") -> list[str]:
+    """cmseq reference_free_consensus over get_base_stats [NOT IN TREE]: a column with fewer
+    than mincov counted bases is none_char, else the majority base; ties resolve in the order
+    A < C < G < T (policy MLST_TIE_ORDER).  dominant_frq_thrsh=0.4 has no effect on the string."""
+    tot = counts.sum(axis=1)
+    arg = counts.argmax(axis=1)          # first maximum = alphabetical order of "ACGT"
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[arg]
+    letters = np.where(tot >= mincov, letters, ord(none_char)).astype(np.uint8)
+    return list(letters.tobytes().decode())
+
+
+def build_consensus(chromosomeList: dict, counts_by_label: dict, mincov: int = 1) -> list[SeqRecordLite]:
+    """buildConsensus (metaMLST_functions.py:249-281) with the cmseq call replaced by the
+    engine's pileup counts.  Gap-fill: 'N' -> lower-cased database base (CI += 1); a consensus
+    base differing from the database base counts as a SNP (Q11)."""
+    seqRec = []
+    for chromo, nucleots in chromosomeList.items():
+        rSequen = consensus_from_counts(counts_by_label[chromo], mincov)
+        dbSequen = chromosomeList[chromo]
+        cIndex = 0
+        SNPs = 0
+        for i, ch in enumerate(rSequen):
+            if ch == "N":
+                rSequen[i] = dbSequen[i].lower()
+                cIndex += 1
+            elif rSequen[i] != dbSequen[i]:
+                SNPs += 1
+        seqRec.append(SeqRecordLite("".join(rSequen), chromo, "CI::" + str(cIndex) + "_SP::" + str(SNPs)))
+    return seqRec
+
+
+@dataclass
+class SpeciesResult:
+    species: str
+    detected: list[str]
+    missing: list[str]
+    passed_nloci: bool
+    closest: dict = field(default_factory=dict)     # gene -> (avg, hits, [allele strs], coverage)
+    chosen: list[tuple[str, str]] = field(default_factory=list)   # (label, sequence)
+    loci_report: list[dict] = field(default_factory=list)
+    written: bool = False
+    nfo_line: str | None = None
+    newProfile: int = 0
+
+
+def nfo_line(speciesKey: str, fileName: str, consenSeq: list[SeqRecordLite]) -> str:
+    """metamlst.py:285, byte for byte (float formatting quirks such as 98.50999999999999 included)."""
+    return (speciesKey + "\t" + fileName + "\t" + "\t".join(
+        [recd.id + "::" + str(recd.seq) + "::"
+         + str(round(1 - float(recd.description.split("_")[0].split("::")[1]) / float(recd.seqLen), 4) * 100) + "::"
+         + str(round(float(recd.description.split("_")[1].split("::")[1]) / float(recd.seqLen), 4) * 100)
+         for recd in consenSeq]) + "\r\n")
+
+
+def sample_name(path: str) -> str:
+    """metamlst.py:89: basename up to the first '.' (Q13)."""
+    return path.split("/")[-1].split(".")[0]
+
+
+def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.metaMLST_db, fileName: str,
+                args: TypingArgs | None = None, out_dir: str | None = None) -> list[SpeciesResult]:
+    """metamlst.py:133-289 for one sample.
+
+    pileup_fn(list of allele indices) -> {allele idx: uint32[len, 4]} is pass 2 of the engine
+    (mlst_pileup).  When out_dir is given the .nfo line is appended to <out_dir>/<fileName>.nfo
+    (append mode as metamlst.py:284)."""
+    args = args or TypingArgs()
+    cursor = database.cursor
+    cel = compile_cel(index, st, args.penalty)
+    results: list[SpeciesResult] = []
+    plan = []
+    for speciesKey, species in cel.items():
+        # metamlst.py:184-206 locus presence gate
+        tVar = dict([(row["geneName"], 0) for row in cursor.execute("SELECT geneName FROM genes WHERE bacterium = ?", (speciesKey,))])
+        if len(tVar) < len(species.keys()):
+            raise SystemExit("Database is broken for " + speciesKey)      # metamlst.py:188-190 exits
+        for sk in species.keys():
+            tVar[sk] = 1
+        vals = sum(tVar.values())
+        res = SpeciesResult(speciesKey,
+                            detected=[sk for (sk, v) in sorted(tVar.items()) if v == 1],
+                            missing=[sk for (sk, v) in sorted(tVar.items()) if v == 0],
+                            passed_nloci=int((float(vals) / float(len(tVar))) * 100) >= args.nloci)
+        results.append(res)
+        if not res.passed_nloci:
+            continue
+        # metamlst.py:213-230 closest alleles + coverage
+        for geneKey, geneInfo in sorted(species.items(), key=lambda x: x[0]):
+            minValue = max([avg for (val, leng, avg) in geneInfo.values()])
+            aElements = {k: v for k, v in geneInfo.items() if v[2] == minValue}
+            l = index.locus_index(speciesKey, geneKey)
+            genL = int(index.locus_maxlen[l])
+            coverage = int(st.locus_len_sum[l])
+            res.closest[geneKey] = (minValue, list(aElements.values())[0][1],
+                                    sorted(aElements.keys(), key=lambda x: int(x)),
+                                    round(float(coverage) / float(genL), 2))
+        # metamlst.py:244 choice
+        for g1, k in pick_alleles(species, speciesKey):
+            l = index.locus_index(speciesKey, g1)
+            b = int(index.locus_begin[l])
+            a = b + int(np.nonzero(index.allele_no[b:b + int(index.locus_count[l])] == int(k))[0][0])
+            res.chosen.append((speciesKey + "_" + g1 + "_" + k, index.sequence(a)))
+            plan.append((res, a))
+    # pass 2 once for every species that passed (identical to one buildConsensus per species)
+    counts = pileup_fn([a for _, a in plan]) if plan else {}
+    for res in results:
+        if not res.passed_nloci:
+            continue
+        chromosomeList = dict(res.chosen)
+        by_label = {}
+        for (r2, a) in plan:
+            if r2 is res:
+                by_label[index.label(a)] = counts[a]
+        consenSeq = build_consensus(chromosomeList, by_label, mincov=1)
+        finWrite = 1
+        for l in sorted(consenSeq, key=lambda x: x.id):
+            holes = str(l.description.split("_")[0].split("::")[1])
+            snps = int(l.description.split("_")[1].split("::")[1])
+            leng = str(len(l.seq))
+            leng_ns = str(round(1 - float(holes) / float(leng), 4) * 100) + " %"
+            l.seqLen = len(l.seq)
+            if (1 - float(holes) / float(leng)) <= args.min_accuracy:      # metamlst.py:262 (Q7: <=)
+                finWrite = 0
+            if snps > 0:
+                seqFind = mdb.sequenceFind(database.conn, res.species, l.seq)   # mixed case (Q8)
+                if seqFind:
+                    newAllele = seqFind
+                else:
+                    newAllele = "NEW"
+                    res.newProfile = 1
+            else:
+                newAllele = "--"
+                if not args.a:
+                    l.seq = ""
+            res.loci_report.append(dict(locus=l.id.split("_")[1], ref=l.id.split("_")[2], length=leng, ns=holes,
+                                        snps=snps, confidence=leng_ns, notes=newAllele))
+        if finWrite:
+            res.written = True
+            res.nfo_line = nfo_line(res.species, fileName, consenSeq)
+            if out_dir is not None:
+                if not os.path.isdir(out_dir):
+                    os.mkdir(out_dir)
+                with open(out_dir + "/" + fileName + ".nfo", "a", newline="") as profil:
+                    profil.write(res.nfo_line)
+    return results
+
+
+def log_table(index: AlleleIndex, st: SampleStats, args: TypingArgs, sample_path: str) -> str:
+    """The --log table of metamlst.py:159-172 (a cheap per-allele parity probe)."""
+    cel = compile_cel(index, st, args.penalty)
+    out = ["SAMPLE:\t\t\t\t\t" + sample_path + "\r\n", "VERSION:\t\t\t\t\t1.1\r\n",
+           "PENALTY:\t\t\t\t" + repr(args.penalty) + "\r\n", "MIN-THRESHOLD SCORE:\t\t\t\t" + repr(args.minscore) + "\r\n",
+           "TOTAL ALIGNED READS:\t\t\t\t" + repr(int(st.counters[0])) + "\r\n",
+           " - OF WHICH IGNORED:\t\t\t\t" + repr(int(st.counters[1])) + " BAM READS\r\n\r\n"
+           "------------------------------  RESULTS ------------------------------\r\n"]
+    for speciesKey, species in cel.items():
+        for geneKey, geneInfo in species.items():
+            for geneInfoKey, (score, geneLen, average) in sorted(geneInfo.items(), key=lambda x: x[1]):
+                out.append("\t".join(map(str, [speciesKey, geneKey, geneInfoKey, score, geneLen, average])) + "\r\n")
+    return "".join(out)
