@@ -150,7 +150,7 @@ class Oracle:
     def hamming_le(self, locus: int, query: bytes, z: int):
         d = self.hamming_all(locus, query)
         w = np.nonzero(d <= z)[0]
-        return (int(w[0]) if len(w) else -1), int(len(w))
+        return (int(self.index.locus_begin[locus]) + int(w[0]) if len(w) else -1), int(len(w))
 
 
 def string_diff(s1: bytes, s2: bytes) -> int:

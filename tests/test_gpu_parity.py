@@ -1,0 +1,163 @@
+"""GPU parity tests: the HIP engine (through the C-ABI) against the CPU oracle, bit exact."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+import oracle_lib
+from metamlst_amd import synth
+from metamlst_amd.engine import Engine, default_params
+from metamlst_amd.typing import build_consensus, pick_alleles_fast
+
+pytestmark = pytest.mark.gpu
+
+
+def both(idx, params=None):
+    eng = Engine(0, params)
+    eng.load_reference(idx)
+    return eng, oracle_lib.Oracle(idx, params)
+
+
+def run_both(eng, orc, fb, fq, off):
+    eng.reset_sample()
+    eng.submit_reads(fb, fq, off)
+    orc.submit_reads(fb, fq, off)
+    s = eng.stats()
+    so, items_o = orc.stats(want_items=1 << 18)
+    fx.assert_stats_equal(s, so)
+    assert np.array_equal(fx.sorted_items(eng.items(1 << 18)), fx.sorted_items(items_o))
+    return s, so
+
+
+def check_pileup(eng, orc, idx, s):
+    chosen = sorted(pick_alleles_fast(idx, s, 100).values())
+    pc, po = eng.pileup(chosen), orc.pileup(chosen)
+    assert set(pc) == set(po)
+    for a in pc:
+        assert np.array_equal(pc[a], po[a]), "pileup differs for allele %d" % a
+    return chosen, pc
+
+
+def test_ecoli_isolate_pass1_and_pileup():
+    db, idx = fx.ecoli_small(80)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 5)
+    eng, orc = both(idx)
+    s, _ = run_both(eng, orc, fb, fq, off)
+    assert s.counters[0] > 1000
+    chosen, pc = check_pileup(eng, orc, idx, s)
+    # the closest allele may be a rounded-average tie (Q5); the consensus must spell the planted allele
+    for a in chosen:
+        gene = idx.loci[int(idx.locus_id[a])][1]
+        true_no = int(db.profiles["ecoli"][5][[g for g, _ in db.loci["ecoli"]].index(gene)])
+        rec = build_consensus({idx.label(a): idx.sequence(a)}, {idx.label(a): pc[a]})[0]
+        assert rec.seq.upper() == synth.allele_sequence(db.path, "ecoli", gene, true_no)
+
+
+def test_indel_alleles_exercise_banded_sw():
+    db, idx = fx.ecoli_small(60, indel_every=4)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 2, n_reads=15000, genome=150_000)
+    eng, orc = both(idx)
+    s, _ = run_both(eng, orc, fb, fq, off)
+    assert s.counters[6] > 0, "no pair reached the banded Smith-Waterman"
+    check_pileup(eng, orc, idx, s)
+
+
+def test_always_banded_policy():
+    p = default_params()
+    p.gap_trigger_mm = -1
+    db, idx = fx.ecoli_small(12, indel_every=3)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 1, n_reads=3000, genome=60_000)
+    eng, orc = both(idx, p)
+    s, _ = run_both(eng, orc, fb, fq, off)
+    check_pileup(eng, orc, idx, s)
+
+
+def test_ragged_reads_with_n_and_short_reads():
+    db, idx = fx.ecoli_small(40)
+    rng = np.random.default_rng(7)
+    g, starts = synth.make_genome(db, "ecoli", db.profiles["ecoli"][0], size=60_000)
+    reads, quals = [], []
+    for k in range(6000):
+        L = int(rng.integers(1, 301))
+        at = int(rng.integers(0, len(g) - L))
+        r = bytearray(g[at:at + L].tobytes())
+        if k % 2:
+            r = bytearray(synth._COMP[np.frombuffer(bytes(r), np.uint8)[::-1]].tobytes())
+        q = bytearray(rng.integers(2, 42, size=L).astype(np.uint8) + 33)
+        if k % 5 == 0 and L > 3:
+            for p in rng.integers(0, L, size=2):
+                r[p] = ord("N")
+                q[p] = 2 + 33
+        reads.append(bytes(r))
+        quals.append(bytes(q))
+    fb, fq, off = synth.ragged_reads(reads, quals)
+    eng, orc = both(idx)
+    s, _ = run_both(eng, orc, fb, fq, off)
+    assert s.counters[0] > 0
+    check_pileup(eng, orc, idx, s)
+
+
+def test_empty_batch_and_no_hits():
+    db, idx = fx.ecoli_small(40)
+    eng, orc = both(idx)
+    eng.submit_reads(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    s = eng.stats()
+    assert s.sum_score.sum() == 0 and s.counters[0] == 0
+    rng = np.random.default_rng(3)
+    b = synth._ACGT[rng.integers(0, 4, size=(2000, 150))]
+    q = np.full_like(b, 40 + 33)
+    fb, fq, off = synth.flatten_reads(b, q)
+    run_both(eng, orc, fb, fq, off)
+
+
+def test_batches_equal_single_submission():
+    db, idx = fx.ecoli_small(80)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 7, n_reads=12000)
+    eng, orc = both(idx)
+    s1, _ = run_both(eng, orc, fb, fq, off)
+    eng.reset_sample()
+    n = len(off) - 1
+    for lo, hi in ((0, 5000), (5000, 5001), (5001, n)):
+        o = off[lo:hi + 1]
+        eng.submit_reads(fb[int(o[0]):int(o[-1])], fq[int(o[0]):int(o[-1])], o - o[0])
+    fx.assert_stats_equal(eng.stats(), s1)
+
+
+def test_multi_species_metagenome():
+    db, idx = fx.multi_species(3, 25)
+    parts = []
+    for k, sp in enumerate(db.species):
+        g, _ = synth.make_genome(db, sp, db.profiles[sp][k], size=80_000, seed=100 + k)
+        parts.append(synth.sample_reads(g, 6000, seed=200 + k))
+    b = np.concatenate([p[0] for p in parts])
+    q = np.concatenate([p[1] for p in parts])
+    perm = np.random.default_rng(5).permutation(len(b))
+    fb, fq, off = synth.flatten_reads(b[perm], q[perm])
+    eng, orc = both(idx)
+    s, _ = run_both(eng, orc, fb, fq, off)
+    chosen, pc = check_pileup(eng, orc, idx, s)
+    by_locus = {idx.loci[int(idx.locus_id[a])]: a for a in chosen}
+    for k, sp in enumerate(db.species):
+        for (gname, _), al in zip(db.loci[sp], db.profiles[sp][k]):
+            a = by_locus[(sp, gname)]
+            rec = build_consensus({idx.label(a): idx.sequence(a)}, {idx.label(a): pc[a]})[0]
+            assert rec.seq.upper() == synth.allele_sequence(db.path, sp, gname, int(al))
+
+
+def test_hamming_matches_stringdiff():
+    db, idx = fx.ecoli_small(80, indel_every=5)
+    eng, orc = both(idx)
+    rng = np.random.default_rng(11)
+    for locus in (0, 3, 6):
+        base = idx.sequence(int(idx.locus_begin[locus]) + 17)
+        for trial in range(4):
+            s = bytearray(base.encode())
+            for p in rng.integers(0, len(s), size=trial * 3):
+                s[p] = ord("ACGT"[int(rng.integers(4))])
+            if trial == 2:
+                s = s[:-25]
+            if trial == 3:
+                s = s + b"ACGTACGT"
+            q = bytes(s)
+            assert np.array_equal(eng.hamming_all(locus, q), orc.hamming_all(locus, q))
+            assert eng.hamming_le(locus, q, 5) == orc.hamming_le(locus, q, 5)
+    assert eng.hamming_le(0, b"", 0)[1] == int(idx.locus_count[0])     # zip with '' -> 0 mismatches
