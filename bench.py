@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mreads/s aligned + ST-typed (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full typing pass over one resident batch of reads: seed sieve -> exact seeds ->
+extension against every allele -> hit accumulation -> allele choice -> pileup -> consensus ->
+.nfo line -> allele match + ST call.  At N=1 the workload is BASELINE.json configs[1]
+(10 M 150 bp SE reads, E. coli-like database: 7 loci, ~10 k alleles); at N>1 every rank holds
+its own 10 M-read shard of the same isolate (weak scaling), the two all-reduces of
+metamlst_amd/dist.py run over RCCL, and rank 0 runs the host tail.
+
+Reads are synthesised on the GPU before the timed region and are resident in HBM in the packed
+format of SURVEY.md 8(d) (2-bit bases + Phred rows); the timed region contains no H2D copy of
+reads.  The JSON line also carries the roofline of the dominant kernel (HIP events on the
+engine's stream) and the CPU oracle timed on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_BASES = 40      # 2-bit bases of a 150 bp read, rounded to the 10-word row the sieve streams
+ALG_BYTES_SURVEY = 188    # 38 B 2-bit bases + 150 B Phred per 150 bp read
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--alleles", type=int, default=1430, help="alleles per locus")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--genome", type=int, default=4_600_000)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
+    ap.add_argument("--st-row", type=int, default=11)
+    return ap.parse_args()
+
+
+def synth_reads_gpu(eng, torch, device, genome: np.ndarray, n_reads: int, L: int, seed: int, chunk: int = 1 << 19):
+    """Reads of SURVEY.md 8(d) cfg1/cfg2 made on the GPU: uniform starts, both strands, Phred 40 except
+    0.1 % substitution errors at Phred 15; packed with the engine's own pack kernel (mlst_pack_reads_device)."""
+    wpr = (L + 15) // 16
+    wpr += wpr & 1
+    qstride = (L + 7) & ~7
+    g = torch.from_numpy(genome).to(device)
+    comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    code = torch.zeros(256, dtype=torch.int64, device=device)
+    for k, a in enumerate(b"ACGT"):
+        code[a] = k
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    packed = torch.zeros(n_reads * wpr + 4, dtype=torch.int32, device=device)
+    qrows = torch.zeros(n_reads * qstride, dtype=torch.uint8, device=device)
+    lens = torch.zeros(n_reads + 2, dtype=torch.int16, device=device)
+    ar = torch.arange(L, device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    for c0 in range(0, n_reads, chunk):
+        n = min(chunk, n_reads - c0)
+        start = torch.randint(0, len(genome) - L + 1, (n,), generator=gen, device=device)
+        b = g[start[:, None] + ar[None, :]]
+        rev = torch.rand(n, generator=gen, device=device) < 0.5
+        b = torch.where(rev[:, None], comp[b.flip(1).long()], b)
+        err = torch.rand((n, L), generator=gen, device=device) < 0.001
+        sub = acgt[(code[b.long()] + torch.randint(1, 4, (n, L), generator=gen, device=device)) % 4]
+        b = torch.where(err, sub, b).contiguous()
+        q = torch.where(err, torch.tensor(15 + 33, dtype=torch.uint8, device=device),
+                        torch.tensor(40 + 33, dtype=torch.uint8, device=device)).contiguous()
+        off = (torch.arange(n + 1, device=device, dtype=torch.int64) * L).contiguous()
+        torch.cuda.synchronize(device)
+        eng.pack_reads_device(b.data_ptr(), q.data_ptr(), off.data_ptr(), n, packed.data_ptr() + c0 * wpr * 4,
+                              qrows.data_ptr() + c0 * qstride, lens.data_ptr() + c0 * 2, wpr, qstride)
+        eng.synchronize()
+        del b, q, err, sub, start, rev, off
+    return packed, qrows, lens, wpr, qstride
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from metamlst_amd import db as mdb
+    from metamlst_amd import synth
+    from metamlst_amd.dist import DeviceStatsPort, allreduce_pileup, allreduce_stats, split_counts
+    from metamlst_amd.engine import Engine
+    from metamlst_amd.index import load_index
+    from metamlst_amd.merge import EngineMatcher, SpeciesSession, parse_nfo_line
+    from metamlst_amd.typing import SampleStats, type_sample
+
+    # ---- database + isolate (same on every rank: seeded)
+    tmp = tempfile.mkdtemp(prefix="mlst_bench_%d_" % rank)
+    db_path = os.path.join(tmp, "ecoli.db")
+    t0 = time.time()
+    sdb = synth.make_ecoli_db(db_path, alleles_per_locus=args.alleles, n_profiles=5000)
+    idx = load_index(db_path)
+    database = mdb.metaMLST_db(db_path)
+    st_tuple = sdb.profiles["ecoli"][args.st_row]
+    genome, _ = synth.make_genome(sdb, "ecoli", st_tuple, size=args.genome)
+    eng = Engine(local_rank)
+    eng.load_reference(idx)
+    t_setup = time.time() - t0
+    packed, qrows, lens, wpr, qstride = synth_reads_gpu(eng, torch, device, genome, args.reads, args.read_len,
+                                                        seed=synth.SEED + 1000 * rank)
+    port = DeviceStatsPort(eng, device)
+    matcher = EngineMatcher(eng, idx)
+    true_st = args.st_row + 1
+    # merge-run prologue (metamlst-merge.py:119-142) happens once per run of many samples: untimed setup
+    cache = mdb.DbCache(database.conn)
+    sessions = {sp: SpeciesSession(database, sp, 5, matcher, cache) for sp in idx.species} if rank == 0 else {}
+
+    def step():
+        eng.reset_sample()
+        eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), args.reads, wpr, qstride)
+        if world > 1:
+            allreduce_stats(port, device)
+        st = eng.stats()
+
+        def pileup_fn(chosen):
+            if world > 1:
+                n_cols = sum(int(idx.off[a + 1] - idx.off[a]) for a in chosen)
+                return split_counts(idx, chosen, allreduce_pileup(port, chosen, n_cols, device))
+            return eng.pileup(chosen)
+
+        res = type_sample(idx, st, pileup_fn, database, "sample", fast=True, cache=cache)
+        out = {}
+        if rank == 0:
+            for r in res:
+                if r.written:       # .nfo line -> allele match + ST call (per-sample body of metamlst-merge.py:144-240)
+                    organism, (bacteriumLine, sampleRecord) = parse_nfo_line(r.nfo_line)
+                    out[organism] = sessions[organism].add_sample(bacteriumLine, sampleRecord)
+        return out, st
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    eng.set_profiling(True)
+    eng.reset_kernel_time()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st_call, stats = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    kernels = {k: eng.kernel_time(k) for k in ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup")}
+    eng.set_profiling(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    total_reads = args.reads * world
+    value = total_reads / (dt / args.steps) / 1e6
+    # ---- roofline of the dominant kernel
+    dom = max(kernels, key=lambda k: kernels[k][0])
+    per_launch = {k: (kernels[k][0] / max(1, kernels[k][1])) for k in kernels}
+    sieve_ms = per_launch["sieve"]
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "sieve_pmc.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    achieved = args.reads * ALG_BYTES_BASES / (sieve_ms * 1e-3) / 1e9 if sieve_ms > 0 else 0.0
+    roofline = {"kernel": "k_sieve", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "alg_bytes_per_read": ALG_BYTES_BASES, "reads_per_launch": args.reads, "avg_launch_ms": round(sieve_ms, 4),
+                "achieved_at_188B_per_read": round(args.reads * ALG_BYTES_SURVEY / (sieve_ms * 1e-3) / 1e9, 1) if sieve_ms > 0 else 0.0,
+                "dominant_by_time": dom}
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same workload, all host cores
+    cpu = None
+    conc = {"st_called": st_call.get("ecoli"), "st_planted": true_st, "st_match": st_call.get("ecoli") == true_st}
+    if args.cpu_seconds > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        cores = os.cpu_count() or 1
+        orc = oracle_lib.Oracle(idx, threads=cores)
+        n_probe = 200_000
+        b, q = synth.sample_reads(genome, n_probe, read_len=args.read_len, seed=99)
+        fb, fq, off = synth.flatten_reads(b, q)
+        orc.submit_reads(fb, fq, off)
+        t1 = time.perf_counter()
+        orc.stats()
+        probe = time.perf_counter() - t1
+        n_cpu = int(min(4_000_000, max(n_probe, n_probe * args.cpu_seconds / max(probe, 1e-3))))
+        b, q = synth.sample_reads(genome, n_cpu, read_len=args.read_len, seed=101)
+        fb, fq, off = synth.flatten_reads(b, q)
+        orc.submit_reads(fb, fq, off)
+        from metamlst_amd.typing import pick_alleles_fast
+        cpu_dt, reps = 0.0, 0
+        while cpu_dt < args.cpu_seconds and reps < 64:      # repeat the bounded sample until ~cpu_seconds of CPU work
+            t1 = time.perf_counter()
+            so = orc.stats()
+            ch = sorted(pick_alleles_fast(idx, so, 100).values())
+            po = orc.pileup(ch)
+            cpu_dt += time.perf_counter() - t1
+            reps += 1
+        cpu = {"value": round(n_cpu * reps / cpu_dt / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "port",
+               "sample": "%d reads of the same isolate/DB x %d passes, oracle pass 1 + allele choice + pileup, OpenMP x %d threads, %.1f s"
+                         % (n_cpu, reps, cores, cpu_dt)}
+        # parity of the GPU engine with the oracle on that very sample
+        eng.reset_sample()
+        eng.submit_reads(fb, fq, off)
+        sg = eng.stats()
+        pg = eng.pileup(ch)
+        same = bool(np.array_equal(sg.sum_score, so.sum_score) and np.array_equal(sg.n_hits, so.n_hits)
+                    and all(np.array_equal(pg[a], po[a]) for a in ch))
+        conc["gpu_equals_cpu_oracle_on_sample"] = same
+        conc["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1) if cpu["value"] > 0 else None
+
+    out = {"metric": "Mreads/s aligned+ST-typed, metamlstDB_2022; ST concordance vs CPU ref",
+           "value": round(value, 2), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "int32", "data": "synthetic",
+           "config": {"workload": "cfg2: %d x %d bp SE reads per GPU, one E. coli-like isolate (%.1f Mb), synthetic DB 7 loci x %d alleles "
+                                  "(metamlstDB_2022 is not available offline)" % (args.reads, args.read_len, args.genome / 1e6, args.alleles),
+                      "reads_per_gpu": args.reads, "n_alleles": int(idx.n_alleles), "parallelism": "reads sharded x%d" % world,
+                      "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (wpr * 4, qstride)},
+           "roofline": roofline, "cpu_baseline": cpu, "concordance": conc,
+           "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
+           "counters": {"records": int(stats.counters[0]), "ignored": int(stats.counters[1]), "candidates": int(stats.counters[3]),
+                        "retained": int(stats.counters[4]), "items": int(stats.counters[5]), "banded_sw_pairs": int(stats.counters[6])},
+           "index_bytes": dict(zip(("allele_arena", "sieve", "seed_table"), eng.index_bytes()[:3])),
+           "setup_s": round(t_setup, 1)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,3 +118,54 @@ def stringDiff(s1, s2) -> int:
         if a != b:
             c += 1
     return c
+
+
+class DbCache:
+    """In-memory lookups with the same answers as the SQL helpers above, built once per database
+    connection.  The reference issues un-indexed full-table scans per locus per sample
+    (sequenceExists / sequenceLocate / defineProfile); with the alignment on the GPU those scans
+    would dominate a typing pass.  Equivalence with the SQL versions is tested in
+    tests/test_merge_host.py.  Rows are visited in rowid order, which is the order SQLite returns
+    them for these un-ordered queries, so `fetchone()` semantics (first row wins) are kept."""
+
+    def __init__(self, conn):
+        self.conn = conn
+        self.seq_first: dict = {}       # (bacterium, sequence) -> (gene, alleleVariant) of the first row
+        self.label_rec: dict = {}       # 'bacterium_gene_alleleVariant' -> recID of the first row
+        self.prof_by_allele: dict = {}  # alleleCode -> [profileCode, ...] (one per profiles row)
+        for row in conn.execute("SELECT recID,bacterium,gene,sequence,alleleVariant FROM alleles ORDER BY recID"):
+            self.seq_first.setdefault((row["bacterium"], row["sequence"]), (row["gene"], row["alleleVariant"]))
+            self.label_rec.setdefault("%s_%s_%s" % (row["bacterium"], row["gene"], row["alleleVariant"]), row["recID"])
+        for row in conn.execute("SELECT profileCode,alleleCode FROM profiles ORDER BY recID"):
+            self.prof_by_allele.setdefault(row["alleleCode"], []).append(row["profileCode"])
+
+    def sequenceExists(self, bacterium, sequence) -> bool:
+        return (bacterium, str(sequence)) in self.seq_first
+
+    def sequenceFind(self, bacterium, sequence):
+        r = self.seq_first.get((bacterium, str(sequence)))
+        return r[0] if r else 0
+
+    def sequenceLocate(self, bacterium, sequence) -> str:
+        return str(self.seq_first[(bacterium, str(sequence))][1])
+
+    def defineProfile(self, geneList):
+        """Module-level defineProfile (metaMLST_functions.py:205-216) including Q9: the LAST label
+        decides the [(0,0)] fallback.  Profiles tied on the match count come out in ascending
+        profileCode order (SQLite's GROUP BY order for this query)."""
+        recs = []
+        result = None
+        for allele in geneList:
+            result = self.label_rec.get(allele)
+            if result is not None:
+                recs.append(result)
+        if result is None:
+            return [(0, 0)]
+        count: dict = {}
+        for r in set(recs):            # SQL `IN (...)` ignores duplicate recIDs
+            for pc in self.prof_by_allele.get(r, ()):
+                count[pc] = count.get(pc, 0) + 1
+        if not count:
+            return []
+        top = max(count.values())
+        return [(pc, int((float(top) / float(len(recs))) * 100)) for pc in sorted(count) if count[pc] == top]

@@ -1,0 +1,78 @@
+"""Multi-GPU typing: one process per GPU, reads sharded by contiguous index range, no
+data-path collective.  Every cross-read quantity of the path is additive, so
+two small all-reduces make the result independent of the GPU count:
+
+  1. after pass 1:  SUM over ranks of {sum_score, n_hits, locus_read_len_sum, counters},
+                    MIN over ranks of locus_first_read          -> every rank picks the same alleles
+  2. after pass 2:  SUM of the pileup counts                    -> rank 0 runs the host tail
+
+torch.distributed does the plumbing: backend "nccl" (= RCCL over xGMI) on device tensors that
+the engine fills / reads through mlst_export_stats_device / mlst_import_stats_device, or
+"gloo" on host tensors in the CPU tests.  Message sizes are KB..MB, i.e. latency bound.
+The reference has no counterpart (single process); the integer sums make 1 vs N GPUs bit identical.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+INT64_MAX = np.iinfo(np.int64).max
+
+
+def shard_range(n_units: int, rank: int, world: int, pair: bool = False) -> tuple[int, int]:
+    """Contiguous read-index range of `rank`; mates (2k, 2k+1) stay together when pair=True."""
+    q = n_units // 2 if pair else n_units
+    lo = (q * rank) // world
+    hi = (q * (rank + 1)) // world
+    return (2 * lo, 2 * hi) if pair else (lo, hi)
+
+
+class DeviceStatsPort:
+    """Adapter between metamlst_amd.engine.Engine and torch tensors on its GPU."""
+
+    def __init__(self, engine, device: torch.device):
+        self.engine, self.device = engine, device
+
+    def flat_sizes(self):
+        return self.engine.flat_sizes()
+
+    def export_stats(self, t_sum: torch.Tensor, t_min: torch.Tensor):
+        self.engine.export_stats_device(t_sum.data_ptr(), t_min.data_ptr())
+
+    def import_stats(self, t_sum: torch.Tensor, t_min: torch.Tensor):
+        torch.cuda.synchronize(self.device)
+        self.engine.import_stats_device(t_sum.data_ptr(), t_min.data_ptr())
+
+    def pileup_into(self, chosen: list[int], t_counts: torch.Tensor) -> int:
+        return self.engine.pileup_device(chosen, t_counts.data_ptr())
+
+
+def allreduce_stats(port, device: torch.device, group=None) -> None:
+    """Collective 1: make every rank's pass-1 statistics the whole-job statistics."""
+    n_sum, n_min = port.flat_sizes()
+    t_sum = torch.empty(n_sum, dtype=torch.int64, device=device)
+    t_min = torch.empty(max(1, n_min), dtype=torch.int64, device=device)
+    port.export_stats(t_sum, t_min)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t_sum, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(t_min, op=dist.ReduceOp.MIN, group=group)
+    port.import_stats(t_sum, t_min)
+
+
+def allreduce_pileup(port, chosen: list[int], n_cols: int, device: torch.device, group=None) -> np.ndarray:
+    """Collective 2: whole-job pileup counts uint32[n_cols, 4] (returned on the host)."""
+    t = torch.zeros(max(1, n_cols) * 4, dtype=torch.int32, device=device)
+    port.pileup_into(chosen, t)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy().view(np.uint32).reshape(-1, 4)[:n_cols]
+
+
+def split_counts(index, chosen: list[int], counts: np.ndarray) -> dict[int, np.ndarray]:
+    out, at = {}, 0
+    for a in chosen:
+        L = int(index.off[a + 1] - index.off[a])
+        out[int(a)] = counts[at:at + L]
+        at += L
+    return out

@@ -48,24 +48,46 @@ class EngineMatcher:
         return first >= 0
 
 
-def call_species(database: mdb.metaMLST_db, bacterium: str, bactRecord: list, z: int | None, matcher) -> dict:
-    """metamlst-merge.py:112-240 for one organism.  Returns the tables the writers need."""
-    conn, cursor = database.conn, database.cursor
-    oldProfiles: dict = {}
-    genesBase: dict = {}
-    encounteredProfiles: dict = {}
-    isolates: list = []
-    newSequences: dict = {}
-    lastProfile = 100000                                                     # merge:134
-    lastGenes = dict((row["gene"], 100000) for row in cursor.execute(
-        "SELECT gene, MAX(alleleVariant) as maxGene FROM alleles WHERE bacterium = ? GROUP BY gene", (bacterium,)))   # merge:136
-    for row in cursor.execute("SELECT profileCode,gene,alleleVariant FROM profiles,alleles WHERE alleleCode = alleles.recID "
-                              "AND alleles.bacterium = ?", (bacterium,)):     # merge:140-142
-        if row["profileCode"] not in oldProfiles:
-            oldProfiles[row["profileCode"]] = [0, {}]
-        oldProfiles[row["profileCode"]][1][row["gene"]] = row["alleleVariant"]
+class SpeciesSession:
+    """metamlst-merge.py:112-240 for one organism, split the way the reference runs it: the
+    prologue (:119-142, all known profiles of the organism) happens once per merge run, then
+    add_sample() is the body of the per-sample loop (:144-240).  State (new allele / new profile
+    numbering, recurring sequences, isolates) carries across samples exactly as in the script."""
 
-    for bacteriumLine, sampleRecord in bactRecord:                            # merge:144
+    def __init__(self, database: mdb.metaMLST_db, bacterium: str, z: int | None, matcher, cache: mdb.DbCache | None = None):
+        self.database, self.bacterium, self.z, self.matcher = database, bacterium, z, matcher
+        self.cache = cache
+        cursor = database.cursor
+        self.oldProfiles: dict = {}
+        self.genesBase: dict = {}
+        self.encounteredProfiles: dict = {}
+        self.isolates: list = []
+        self.newSequences: dict = {}
+        self.lastProfile = 100000                                                # merge:134
+        self.lastGenes = dict((row["gene"], 100000) for row in cursor.execute(
+            "SELECT gene, MAX(alleleVariant) as maxGene FROM alleles WHERE bacterium = ? GROUP BY gene", (bacterium,)))   # merge:136
+        self.has_empty = set(row["gene"] for row in cursor.execute(
+            "SELECT DISTINCT gene FROM alleles WHERE bacterium = ? AND sequence = ''", (bacterium,)))
+        for row in cursor.execute("SELECT profileCode,gene,alleleVariant FROM profiles,alleles WHERE alleleCode = alleles.recID "
+                                  "AND alleles.bacterium = ?", (bacterium,)):     # merge:140-142
+            if row["profileCode"] not in self.oldProfiles:
+                self.oldProfiles[row["profileCode"]] = [0, {}]
+            self.oldProfiles[row["profileCode"]][1][row["gene"]] = row["alleleVariant"]
+
+    # the three per-sample database questions, SQL (reference) or cached (same answers)
+    def _exists(self, seq):
+        return self.cache.sequenceExists(self.bacterium, seq) if self.cache else mdb.sequenceExists(self.database.conn, self.bacterium, seq)
+
+    def _locate(self, seq):
+        return self.cache.sequenceLocate(self.bacterium, seq) if self.cache else mdb.sequenceLocate(self.database.conn, self.bacterium, seq)
+
+    def _define(self, labels):
+        return self.cache.defineProfile(labels) if self.cache else mdb.defineProfile(self.database.conn, labels)
+
+    def add_sample(self, bacteriumLine: dict, sampleRecord: str):
+        """One iteration of the loop at merge:144.  Returns the ST appended to `isolates` (or None
+        when the sample's profile is rejected)."""
+        bacterium, z = self.bacterium, self.z
         profileLine = {}
         newAlleles = []
         flagRecurrent = False
@@ -73,62 +95,82 @@ def call_species(database: mdb.metaMLST_db, bacterium: str, bactRecord: list, z:
         for geneLabel, (geneSeq, geneAccur, percent_snps) in bacteriumLine.items():
             geneOrganism, geneName, geneAllele = geneLabel.split("_")
             sum_of_accuracies += float(geneAccur)
-            if geneSeq == "" or mdb.sequenceExists(conn, bacterium, geneSeq):     # merge:157
+            if geneSeq == "" or self._exists(geneSeq):                            # merge:157
                 if geneSeq != "":
-                    geneAllele = mdb.sequenceLocate(conn, bacterium, geneSeq)
+                    geneAllele = self._locate(geneSeq)
                 profileLine[geneName] = (geneAllele, 0)
-            elif geneSeq in genesBase:                                            # merge:164
-                profileLine[geneName] = (genesBase[geneSeq].split("_")[2], 2)
+            elif geneSeq in self.genesBase:                                       # merge:164
+                profileLine[geneName] = (self.genesBase[geneSeq].split("_")[2], 2)
                 flagRecurrent = True
             else:                                                                 # merge:168-196
                 geneCategoryCode = 1
                 if z is not None:
                     geneCategoryCode = 3
-                    # stringDiff(geneSeq, '') == 0: an allele row with an empty sequence accepts anything
-                    empty = cursor.execute("SELECT 1 FROM alleles WHERE gene = ? AND bacterium = ? AND sequence = ''",
-                                           (geneName, bacterium)).fetchone()
-                    if (empty and 0 <= z) or matcher(bacterium, geneName, geneSeq, z):
+                    # stringDiff(geneSeq, '') == 0 <= z: an allele row with an empty sequence accepts anything;
+                    # every other row of the locus is scanned on the GPU (mlst_hamming_le)
+                    if (geneName in self.has_empty and 0 <= z) or self.matcher(bacterium, geneName, geneSeq, z):
                         geneCategoryCode = 1
-                geneNewAlleleNumber = str(lastGenes[geneName] + 1)
-                lastGenes[geneName] += 1
+                geneNewAlleleNumber = str(self.lastGenes[geneName] + 1)
+                self.lastGenes[geneName] += 1
                 geneNewLabel = geneOrganism + "_" + geneName + "_" + geneNewAlleleNumber
-                genesBase[geneSeq] = geneNewLabel
+                self.genesBase[geneSeq] = geneNewLabel
                 profileLine[geneName] = (geneNewAlleleNumber, geneCategoryCode)
                 newAlleles.append(geneName)
-                newSequences.setdefault(geneName, []).append((geneNewLabel, geneSeq))
+                self.newSequences.setdefault(geneName, []).append((geneNewLabel, geneSeq))
 
         meanAccuracy = sum_of_accuracies / float(len(bacteriumLine))              # merge:199
         if len(newAlleles) == 0:
             if not flagRecurrent:
-                tryDefine = mdb.defineProfile(conn, [bacterium + "_" + k + "_" + v[0] for k, v in profileLine.items()])
+                tryDefine = self._define([bacterium + "_" + k + "_" + v[0] for k, v in profileLine.items()])
                 if tryDefine and tryDefine[0][1] == 100:                          # merge:207
-                    oldProfiles[tryDefine[0][0]][0] += 1
-                    isolates.append((tryDefine[0][0], meanAccuracy, sampleRecord))
-                    continue
+                    self.oldProfiles[tryDefine[0][0]][0] += 1
+                    self.isolates.append((tryDefine[0][0], meanAccuracy, sampleRecord))
+                    return tryDefine[0][0]
             foundExistant = 0
-            for key, (element, abundance, isNewProfile) in encounteredProfiles.items():
+            for key, (element, abundance, isNewProfile) in self.encounteredProfiles.items():
                 if [k + str(v[0]) for k, v in sorted(profileLine.items())] == [k + str(v[0]) for k, v in sorted(element.items())]:
                     foundExistant = key
             if foundExistant:
-                encounteredProfiles[foundExistant][1] += 1
-                isolates.append((foundExistant, meanAccuracy, sampleRecord))
-            else:
-                lastProfile += 1
-                encounteredProfiles[lastProfile] = [profileLine, 1, 2]
-                isolates.append((lastProfile, meanAccuracy, sampleRecord))
-        else:
-            lastProfile += 1                                                      # merge:229
-            profileCategoryCode = 1
-            if z is not None:
-                for k, (v, cat) in profileLine.items():
-                    if cat == 3:
-                        profileCategoryCode = 3
-                        break
-            encounteredProfiles[lastProfile] = [profileLine, 1, profileCategoryCode]
-            if profileCategoryCode != 3:
-                isolates.append((lastProfile, meanAccuracy, sampleRecord))
-    return dict(oldProfiles=oldProfiles, encounteredProfiles=encounteredProfiles, isolates=isolates,
-                lastGenes=lastGenes, newSequences=newSequences)
+                self.encounteredProfiles[foundExistant][1] += 1
+                self.isolates.append((foundExistant, meanAccuracy, sampleRecord))
+                return foundExistant
+            self.lastProfile += 1
+            self.encounteredProfiles[self.lastProfile] = [profileLine, 1, 2]
+            self.isolates.append((self.lastProfile, meanAccuracy, sampleRecord))
+            return self.lastProfile
+        self.lastProfile += 1                                                     # merge:229
+        profileCategoryCode = 1
+        if z is not None:
+            for k, (v, cat) in profileLine.items():
+                if cat == 3:
+                    profileCategoryCode = 3
+                    break
+        self.encounteredProfiles[self.lastProfile] = [profileLine, 1, profileCategoryCode]
+        if profileCategoryCode != 3:
+            self.isolates.append((self.lastProfile, meanAccuracy, sampleRecord))
+            return self.lastProfile
+        return None
+
+    def tables(self) -> dict:
+        return dict(oldProfiles=self.oldProfiles, encounteredProfiles=self.encounteredProfiles, isolates=self.isolates,
+                    lastGenes=self.lastGenes, newSequences=self.newSequences)
+
+
+def parse_nfo_line(line: str):
+    """One line of a .nfo file -> (organism, ({label: (SEQ.upper(), acc, snp%)}, sample)); merge:99-107."""
+    organism = line.split()[0]
+    sampleName = line.split()[1]
+    genes = line.split()[2::]
+    return organism, (dict((x.split("::")[0], (x.split("::")[1].upper(), x.split("::")[2], x.split("::")[3])) for x in genes), sampleName)
+
+
+def call_species(database: mdb.metaMLST_db, bacterium: str, bactRecord: list, z: int | None, matcher,
+                 cache: mdb.DbCache | None = None) -> dict:
+    """metamlst-merge.py:112-240 for one organism.  Returns the tables the writers need."""
+    sess = SpeciesSession(database, bacterium, z, matcher, cache)
+    for bacteriumLine, sampleRecord in bactRecord:                                # merge:144
+        sess.add_sample(bacteriumLine, sampleRecord)
+    return sess.tables()
 
 
 def write_species(folder: str, bacterium: str, tables: dict, meta: str | None = None, idField: int = 0) -> None:

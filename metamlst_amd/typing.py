@@ -124,21 +124,43 @@ def pick_alleles_fast(index: AlleleIndex, st: SampleStats, penalty: int) -> dict
     return chosen
 
 
+def _consensus_bytes(counts: np.ndarray, mincov: int = 1, none_char: str = "N") -> np.ndarray:
+    tot = counts.sum(axis=1)
+    arg = counts.argmax(axis=1)          # first maximum = alphabetical order of "ACGT"
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[arg]
+    return np.where(tot >= mincov, letters, ord(none_char)).astype(np.uint8)
+
+
 def consensus_from_counts(counts: np.ndarray, mincov: int = 1, none_char: str = "N") -> list[str]:
     """cmseq reference_free_consensus over get_base_stats [NOT IN TREE]: a column with fewer
     than mincov counted bases is none_char, else the majority base; ties resolve in the order
     A < C < G < T (policy MLST_TIE_ORDER).  dominant_frq_thrsh=0.4 has no effect on the string."""
-    tot = counts.sum(axis=1)
-    arg = counts.argmax(axis=1)          # first maximum = alphabetical order of "ACGT"
-    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[arg]
-    letters = np.where(tot >= mincov, letters, ord(none_char)).astype(np.uint8)
-    return list(letters.tobytes().decode())
+    return list(_consensus_bytes(counts, mincov, none_char).tobytes().decode())
 
 
 def build_consensus(chromosomeList: dict, counts_by_label: dict, mincov: int = 1) -> list[SeqRecordLite]:
     """buildConsensus (metaMLST_functions.py:249-281) with the cmseq call replaced by the
-    engine's pileup counts.  Gap-fill: 'N' -> lower-cased database base (CI += 1); a consensus
-    base differing from the database base counts as a SNP (Q11)."""
+    engine's pileup counts.  Gap-fill (:265-273): 'N' -> lower-cased database base (CI += 1); a
+    consensus base differing from the database base counts as a SNP (Q11).  The per-position loop
+    of the reference is done with array operations; build_consensus_loop below is the literal
+    restatement the tests compare it with."""
+    seqRec = []
+    for chromo, nucleots in chromosomeList.items():
+        cons = _consensus_bytes(counts_by_label[chromo], mincov)
+        dbarr = np.frombuffer(chromosomeList[chromo].encode("latin-1"), dtype=np.uint8)
+        if len(dbarr) != len(cons):
+            return build_consensus_loop(chromosomeList, counts_by_label, mincov)
+        isN = cons == ord("N")
+        upper = (dbarr >= 65) & (dbarr <= 90)
+        out = np.where(isN, np.where(upper, dbarr + 32, dbarr), cons).astype(np.uint8)
+        cIndex = int(isN.sum())
+        SNPs = int(((cons != dbarr) & ~isN).sum())
+        seqRec.append(SeqRecordLite(out.tobytes().decode("latin-1"), chromo, "CI::" + str(cIndex) + "_SP::" + str(SNPs)))
+    return seqRec
+
+
+def build_consensus_loop(chromosomeList: dict, counts_by_label: dict, mincov: int = 1) -> list[SeqRecordLite]:
+    """Literal per-position form of metaMLST_functions.py:257-276."""
     seqRec = []
     for chromo, nucleots in chromosomeList.items():
         rSequen = consensus_from_counts(counts_by_label[chromo], mincov)
@@ -183,16 +205,32 @@ def sample_name(path: str) -> str:
     return path.split("/")[-1].split(".")[0]
 
 
+def _detected_loci(index: AlleleIndex, st: SampleStats) -> dict:
+    """{species: {gene: None}} in the same first-appearance order as compile_cel, without the
+    per-allele tuples (fast path)."""
+    loci_hit = [l for l in range(index.n_loci) if st.locus_first[l] != NO_READ]
+    loci_hit.sort(key=lambda l: (int(st.locus_first[l]), l))
+    out: dict = {}
+    for l in loci_hit:
+        sp, gene = index.loci[l]
+        out.setdefault(sp, {})[gene] = None
+    return out
+
+
 def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.metaMLST_db, fileName: str,
-                args: TypingArgs | None = None, out_dir: str | None = None) -> list[SpeciesResult]:
+                args: TypingArgs | None = None, out_dir: str | None = None, fast: bool = False,
+                cache: mdb.DbCache | None = None) -> list[SpeciesResult]:
     """metamlst.py:133-289 for one sample.
 
     pileup_fn(list of allele indices) -> {allele idx: uint32[len, 4]} is pass 2 of the engine
     (mlst_pileup).  When out_dir is given the .nfo line is appended to <out_dir>/<fileName>.nfo
-    (append mode as metamlst.py:284)."""
+    (append mode as metamlst.py:284).  fast=True skips the per-allele `cel` table and the
+    closest-allele listing (display only) and picks alleles with pick_alleles_fast; the .nfo
+    line is identical (tests/test_typing_host.py)."""
     args = args or TypingArgs()
     cursor = database.cursor
-    cel = compile_cel(index, st, args.penalty)
+    cel = _detected_loci(index, st) if fast else compile_cel(index, st, args.penalty)
+    fast_choice = pick_alleles_fast(index, st, args.penalty) if fast else None
     results: list[SpeciesResult] = []
     plan = []
     for speciesKey, species in cel.items():
@@ -209,6 +247,12 @@ def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.me
                             passed_nloci=int((float(vals) / float(len(tVar))) * 100) >= args.nloci)
         results.append(res)
         if not res.passed_nloci:
+            continue
+        if fast:
+            for g1 in species.keys():
+                a = fast_choice[index.locus_index(speciesKey, g1)]
+                res.chosen.append((index.label(a), index.sequence(a)))
+                plan.append((res, a))
             continue
         # metamlst.py:213-230 closest alleles + coverage
         for geneKey, geneInfo in sorted(species.items(), key=lambda x: x[0]):
@@ -248,7 +292,8 @@ def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.me
             if (1 - float(holes) / float(leng)) <= args.min_accuracy:      # metamlst.py:262 (Q7: <=)
                 finWrite = 0
             if snps > 0:
-                seqFind = mdb.sequenceFind(database.conn, res.species, l.seq)   # mixed case (Q8)
+                seqFind = (cache.sequenceFind(res.species, l.seq) if cache else
+                           mdb.sequenceFind(database.conn, res.species, l.seq))   # mixed case (Q8)
                 if seqFind:
                     newAllele = seqFind
                 else:
