@@ -212,14 +212,14 @@ def write_species(folder: str, bacterium: str, tables: dict, meta: str | None = 
 
 
 def merge_folder(folder: str, database: mdb.metaMLST_db, matcher, z: int | None = 5, filter: str | None = None,
-                 meta: str | None = None, idField: int = 0) -> dict:
+                 meta: str | None = None, idField: int = 0, cache: mdb.DbCache | None = None) -> dict:
     """The whole metamlst-merge.py run for one folder of .nfo files.  Returns {species: tables}."""
     if not os.path.isdir(folder + "/merged"):
         os.makedirs(folder + "/merged")
     cel = parse_nfo_folder(folder, filter)
     out = {}
     for bacterium, bactRecord in cel.items():
-        tables = call_species(database, bacterium, bactRecord, z, matcher)
+        tables = call_species(database, bacterium, bactRecord, z, matcher, cache)
         write_species(folder, bacterium, tables, meta, idField)
         out[bacterium] = tables
     return out

@@ -77,9 +77,10 @@ class Oracle:
     def n_keys(self) -> int:
         return int(lib().orc_ref_n_keys(self._r))
 
-    def submit_reads(self, bases, quals, off, paired=False):
+    def submit_reads(self, bases, quals, off, paired=False, read_base: int = 0):
         self._reads = (np.ascontiguousarray(bases, np.uint8), np.ascontiguousarray(quals, np.uint8),
                        np.ascontiguousarray(off, np.uint64))
+        self._read_base = read_base
 
     def stats(self, want_items: int = 0):
         b, q, off = self._reads
@@ -88,7 +89,7 @@ class Oracle:
                         np.zeros(nL, np.uint64), np.zeros(MLST_CNT_N, np.uint64))
         items = (MlstItem * max(1, want_items))()
         n_items = C.c_uint64()
-        rc = lib().orc_pass1(self._r, _p(b), _p(q), _p(off), len(off) - 1, 0, _p(s.sum_score), _p(s.n_hits),
+        rc = lib().orc_pass1(self._r, _p(b), _p(q), _p(off), len(off) - 1, getattr(self, '_read_base', 0), _p(s.sum_score), _p(s.n_hits),
                              _p(s.locus_len_sum), _p(s.locus_first), _p(s.counters),
                              C.cast(items, C.c_void_p) if want_items else None, want_items, C.byref(n_items), self.threads)
         if rc != 0:
