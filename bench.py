@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--genome", type=int, default=4_600_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--st-row", type=int, default=11)
+    ap.add_argument("--calibrate", action="store_true",
+                    help="before the timed region copy the Phred rows 3x with torch (a known-size wide coalesced stream) "
+                         "so a rocprofv3 --pmc FETCH_SIZE pass of this command can be calibrated")
     return ap.parse_args()
 
 
@@ -139,12 +142,22 @@ def main():
     cache = mdb.DbCache(database.conn)
     sessions = {sp: SpeciesSession(database, sp, 5, matcher, cache) for sp in idx.species} if rank == 0 else {}
 
+    if args.calibrate:
+        for _ in range(3):
+            _c = qrows.clone()
+        torch.cuda.synchronize(device)
+        del _c
+    host_ms = {"submit": 0.0, "stats": 0.0, "typing+pileup": 0.0, "st_call": 0.0}
+
     def step():
+        t_a = time.perf_counter()
         eng.reset_sample()
         eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), args.reads, wpr, qstride)
         if world > 1:
             allreduce_stats(port, device)
+        t_b = time.perf_counter()
         st = eng.stats()
+        t_c = time.perf_counter()
 
         def pileup_fn(chosen):
             if world > 1:
@@ -153,12 +166,18 @@ def main():
             return eng.pileup(chosen)
 
         res = type_sample(idx, st, pileup_fn, database, "sample", fast=True, cache=cache)
+        t_d = time.perf_counter()
         out = {}
         if rank == 0:
             for r in res:
                 if r.written:       # .nfo line -> allele match + ST call (per-sample body of metamlst-merge.py:144-240)
                     organism, (bacteriumLine, sampleRecord) = parse_nfo_line(r.nfo_line)
                     out[organism] = sessions[organism].add_sample(bacteriumLine, sampleRecord)
+        t_e = time.perf_counter()
+        host_ms["submit"] += (t_b - t_a) * 1e3
+        host_ms["stats"] += (t_c - t_b) * 1e3        # includes waiting for the pass-1 kernels
+        host_ms["typing+pileup"] += (t_d - t_c) * 1e3
+        host_ms["st_call"] += (t_e - t_d) * 1e3
         return out, st
 
     def fence():
@@ -172,6 +191,8 @@ def main():
         step()
     eng.set_profiling(True)
     eng.reset_kernel_time()
+    for k in host_ms:
+        host_ms[k] = 0.0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -263,6 +284,7 @@ def main():
                       "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (wpr * 4, qstride)},
            "roofline": roofline, "cpu_baseline": cpu, "concordance": conc,
            "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
+           "host_ms_per_step": {k: round(v / args.steps, 4) for k, v in host_ms.items()},
            "counters": {"records": int(stats.counters[0]), "ignored": int(stats.counters[1]), "candidates": int(stats.counters[3]),
                         "retained": int(stats.counters[4]), "items": int(stats.counters[5]), "banded_sw_pairs": int(stats.counters[6])},
            "index_bytes": dict(zip(("allele_arena", "sieve", "seed_table"), eng.index_bytes()[:3])),

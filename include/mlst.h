@@ -45,7 +45,7 @@ typedef struct mlst_params {
     int32_t band_w;            /* banded Smith-Waterman half width */
     int32_t gap_trigger_mm;    /* see mlst_policy.h; <0 = always banded SW */
     int32_t xm_field_quirk;    /* 1 = emulate metamlst.py:110 positional parse (Q1) */
-    int32_t reserved0;
+    int32_t gap_trigger_clip;  /* see mlst_policy.h */
     double  minscore_const;    /* bowtie2 --score-min G,const,coef */
     double  minscore_coef;
     uint64_t max_retained_reads; /* capacity of the on-locus read store (0 = default) */

@@ -36,9 +36,12 @@
 #define MLST_MAX_CAND           8   /* distinct (locus,strand,diag) vote bins kept per read, first-seen order */
 #define MLST_MIN_VOTES          1   /* seeds needed on the winning diagonal */
 #define MLST_DEF_BAND_W         8   /* banded SW half-width around the voted diagonal */
-#define MLST_DEF_GAP_TRIGGER_MM 12  /* banded SW runs iff ungapped full-overlap mismatches > this
-                                       and the ungapped local score reaches the bowtie2 floor;
+#define MLST_DEF_GAP_TRIGGER_MM 12  /* banded SW runs iff the seed diagonal looks broken by an indel:
+                                       ungapped full-overlap mismatches > this, the ungapped local score
+                                       reaches the bowtie2 floor, and ... (next constant);
                                        a negative value means "always run banded SW" */
+#define MLST_DEF_GAP_TRIGGER_CLIP 8 /* ... the ungapped local alignment leaves at least this many overlap
+                                       columns unaligned (an indel clips the alignment; scattered SNPs do not) */
 #define MLST_DEF_XM_FIELD_QUIRK 1   /* metamlst.py:110 reads SAM column 15 by position: it is XM only
                                        when XS:i is present (read has >= 2 records), else XO (Q1) */
 

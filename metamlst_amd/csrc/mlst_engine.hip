@@ -28,11 +28,12 @@ typedef unsigned int u32;
 typedef unsigned short u16;
 typedef unsigned char u8;
 typedef long long i64;
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));   // native vector: accepted by the nontemporal builtins
 
 #define RW  (MLST_MAX_READ_LEN / 16)     // words of a retained read row (20)
 #define RQ  MLST_MAX_READ_LEN            // bytes of a retained quality row
 #define KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
-#define MAX_W 16                          // largest supported band half width
+#define MAX_W 15                          // largest supported band half width (band <= 31 cells: one 64-bit base window)
 #define NEGP MLST_P_NEG
 #define P0   MLST_P0
 
@@ -83,8 +84,12 @@ struct Counters {
     u64 err;             // bit0 retained overflow, bit1 item overflow, bit2 result overflow, bit3 dp overflow
     u64 cnt[MLST_CNT_N];
 };
+// item_state bits
+#define IS_SINGLE 1   /* the read has exactly one work item */
+#define IS_DONE   2   /* accumulated by k_extend (fused path) */
+#define IS_ACC    4   /* at least one accepted record */
 struct KParams {
-    int minscore, max_xm, min_read_len, minqual, match_bonus, n_penalty, open_p, ext_p, gbar, band_w, trig, quirk;
+    int minscore, max_xm, min_read_len, minqual, match_bonus, n_penalty, open_p, ext_p, gbar, band_w, trig, quirk, clip;
 };
 struct EngineDev {
     // reference
@@ -97,7 +102,7 @@ struct EngineDev {
     long long* sum_score; u32* n_hits; u64* locus_len; u64* locus_first;
     Counters* ctr;
     u32* ret_bases; u8* ret_quals; u16* ret_len; u64* ret_ridx; u32* ret_nrec;
-    ItemDev* items; u32* res; u64* dp_list;
+    ItemDev* items; u8* item_state; u32* res; u64* dp_list;
     u64 cap_ret, cap_items, cap_res, cap_dp;
 };
 
@@ -150,66 +155,73 @@ __device__ inline bool bucket_has(uint4 b, u32 fp, bool& full) {
     return (z & 0x80008000u) != 0;
 }
 
-#define SIEVE_MAXP 10        // pairs of words per row (RW / 2)
+// WPR = words per packed row (even).  A row of WPR words holds at most WPR-1 seeds (seed t = word t + low byte of
+// word t+1).  All WPR-1 bucket loads are issued before any is examined (branchless: seeds beyond the read's length
+// probe a harmless bucket and are masked), so a lane has WPR-1 independent 16-byte loads in flight.
+template <int WPR>
 __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
-                                                u32 wpr /* even */, const uint4* __restrict__ sieve, u32 smask,
+                                                const uint4* __restrict__ sieve, u32 smask,
                                                 u32* __restrict__ cand, Counters* __restrict__ ctr) {
-    extern __shared__ __attribute__((aligned(16))) u32 s_rows[];
+    __shared__ __attribute__((aligned(16))) u32 s_rows[256 * WPR];
+    constexpr int NT = WPR - 1;                 // seed slots
+    constexpr int NV = (64 * WPR + 255) / 256;  // 16-byte vectors staged per thread
     const int tid = threadIdx.x;
-    const u32 S2 = wpr >> 1;
     u64 n_blocks = (n_reads + 255) / 256;
     for (u64 blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         u64 r0 = blk * 256;
         u32 nr = (u32)((n_reads - r0) < 256 ? (n_reads - r0) : 256);
-        // stage rows: nr*wpr words, 16-byte vectors (r0*wpr*4 is 16-byte aligned because r0 % 256 == 0)
-        u32 nvec = (nr * wpr + 3) >> 2;
-        const uint4* g4 = reinterpret_cast<const uint4*>(packed + r0 * wpr);
-        uint4* s4 = reinterpret_cast<uint4*>(s_rows);
-        u32 full_vec = (nr * wpr) >> 2;
-        for (u32 v = tid; v < nvec; v += 256) {
-            if (v < full_vec) s4[v] = g4[v];
-            else { // ragged tail (only when nr*wpr % 4 != 0)
-                const u32* g = packed + r0 * wpr; u32 base = v * 4, lim = nr * wpr;
-                uint4 t; t.x = base < lim ? g[base] : 0; t.y = base + 1 < lim ? g[base + 1] : 0;
-                t.z = base + 2 < lim ? g[base + 2] : 0; t.w = 0; s4[v] = t;
-            }
+        // stage rows through LDS: a full tile is 64*WPR 16-byte vectors, loaded coalesced and non-temporal
+        // (r0*WPR*4 is 16-byte aligned because r0 % 256 == 0); the last, partial tile takes the scalar path
+        u32 n = (u32)tid < nr ? (u32)(lens[r0 + tid] & 0x7FFFu) : 0u;
+        if (nr == 256) {
+            const v4u* g4 = reinterpret_cast<const v4u*>(packed + r0 * WPR);
+            v4u* s4 = reinterpret_cast<v4u*>(s_rows);
+            v4u stg[NV];
+            #pragma unroll
+            for (int k = 0; k < NV; k++) { u32 v = tid + 256 * k; if (v < 64u * WPR) stg[k] = __builtin_nontemporal_load(g4 + v); }
+            #pragma unroll
+            for (int k = 0; k < NV; k++) { u32 v = tid + 256 * k; if (v < 64u * WPR) s4[v] = stg[k]; }
+        } else {
+            const u32* g = packed + r0 * WPR;
+            for (u32 i = tid; i < 256u * WPR; i += 256) s_rows[i] = i < nr * WPR ? g[i] : 0u;
         }
         __syncthreads();
         bool hit = false;
-        if ((u32)tid < nr) {
-            u32 n = lens[r0 + tid] & 0x7FFFu;
+        {
             int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-            const uint2* row = reinterpret_cast<const uint2*>(s_rows + (u32)tid * wpr);
-            u32 pending = 0;          // seeds whose first bucket was full without a match (rare)
-            u32 prev = 0;
+            const uint2* row = reinterpret_cast<const uint2*>(s_rows + (u32)tid * WPR);
+            u32 w[WPR];
             #pragma unroll
-            for (int t2 = 0; t2 < SIEVE_MAXP; t2++) {
-                if ((u32)t2 < S2) {
-                    uint2 w = row[t2];
-                    // seed t = 2*t2-1 : words (prev, w.x) ; seed t = 2*t2 : words (w.x, w.y)
-                    if (t2 > 0 && 2 * t2 - 1 < nseeds) {
-                        u32 lo = prev, hi = w.x & 0xFFu; bool full;
-                        uint4 b = sieve[sieve_bucket_hash(lo, hi) & smask];
-                        bool f = bucket_has(b, sieve_fp(lo, hi), full);
-                        hit |= f; if (!f && full) pending |= 1u << (2 * t2 - 1);
-                    }
-                    if (2 * t2 < nseeds) {
-                        u32 lo = w.x, hi = w.y & 0xFFu; bool full;
-                        uint4 b = sieve[sieve_bucket_hash(lo, hi) & smask];
-                        bool f = bucket_has(b, sieve_fp(lo, hi), full);
-                        hit |= f; if (!f && full) pending |= 1u << (2 * t2);
-                    }
-                    prev = w.y;
-                }
+            for (int t2 = 0; t2 < WPR / 2; t2++) { uint2 x = row[t2]; w[2 * t2] = x.x; w[2 * t2 + 1] = x.y; }
+            // Issue every probe before examining any.  hipcc sinks plain loads to their uses (one dependent
+            // round trip per seed), so the loads are inline asm and one explicit wait covers them all; the
+            // empty asm statements tie each result register to that wait.
+            v4u bv[NT];
+            #pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint4* ptr = sieve + (sieve_bucket_hash(w[t], w[t + 1] & 0xFFu) & smask);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[t]) : "v"(ptr) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint4 b[NT];
+            #pragma unroll
+            for (int t = 0; t < NT; t++) { asm volatile("" : "+v"(bv[t])); b[t] = make_uint4(bv[t].x, bv[t].y, bv[t].z, bv[t].w); }
+            u32 pending = 0;          // seeds whose first bucket was full without a match (rare)
+            #pragma unroll
+            for (int t = 0; t < NT; t++) {
+                bool full; bool f = bucket_has(b[t], sieve_fp(w[t], w[t + 1] & 0xFFu), full);
+                bool valid = t < nseeds;
+                hit |= valid && f;
+                pending |= (valid && !f && full) ? (1u << t) : 0u;
             }
             while (pending && !hit) {   // overflow chain: the key may sit in a following bucket
                 int t = __ffs(pending) - 1; pending &= pending - 1;
-                const u32* rw = s_rows + (u32)tid * wpr;
+                const u32* rw = s_rows + (u32)tid * WPR;
                 u32 lo = rw[t], hi = rw[t + 1] & 0xFFu; u32 fp = sieve_fp(lo, hi);
                 u32 bi = sieve_bucket_hash(lo, hi) & smask;
                 for (int step = 0; step < 64; step++) {
-                    bi = (bi + 1) & smask; bool full; uint4 b = sieve[bi];
-                    if (bucket_has(b, fp, full)) { hit = true; break; }
+                    bi = (bi + 1) & smask; bool full; uint4 bb = sieve[bi];
+                    if (bucket_has(bb, fp, full)) { hit = true; break; }
                     if (!full) break;
                 }
             }
@@ -217,14 +229,31 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
         u64 mask = __ballot(hit);
         if (mask) {
             int lane = tid & 63;
+            int leader = __ffsll((long long)mask) - 1;
             u64 base = 0;
-            if (lane == (__ffsll((long long)mask) - 1)) base = atomicAdd(&ctr->n_cand, (u64)__popcll(mask));
-            base = __shfl(base, __ffsll((long long)mask) - 1);
+            if (lane == leader) base = atomicAdd(&ctr->n_cand, (u64)__popcll(mask));
+            base = __shfl(base, leader);
             if (hit) cand[base + __popcll(mask & ((1ull << lane) - 1))] = (u32)(r0 + tid);
         }
         __syncthreads();
     }
 }
+
+// ------------------------------------------------------------------ wave helpers
+__device__ inline u32 wave_excl_scan_u32(u32 v, u32& total) {      // exclusive prefix sum over the 64 lanes
+    int lane = threadIdx.x & 63; u32 x = v;
+    #pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 y = __shfl_up(x, o); if (lane >= o) x += y; }
+    total = __shfl(x, 63);
+    return x - v;
+}
+__device__ inline u64 wave_sum_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ inline u64 wave_min_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) { u64 w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
+__device__ inline u32 wave_sum_u32(u32 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+// Loads the compiler cannot sink to their uses: issue a batch, wait once (cdna_hip_programming.md 5.7).
+__device__ inline u32 ld_async_u32(const u32* p) { u32 r; asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory"); return r; }
+__device__ inline void ld_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#define LD_TIE(x) asm volatile("" : "+v"(x))
 
 // ------------------------------------------------------------------ K2: exact seeds -> work items
 struct Bin { u32 locus; int diag; u16 strand, votes; };
@@ -246,56 +275,93 @@ __global__ __launch_bounds__(256) void k_seed(EngineDev E, const u32* __restrict
                                                const u32* __restrict__ cand) {
     __shared__ Bin s_bins[256][MLST_MAX_CAND];
     __shared__ Bin s_items[256][MLST_MAX_CAND];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     u64 n_cand = E.ctr->n_cand;
-    for (u64 c = (u64)blockIdx.x * 256 + tid; c < n_cand; c += (u64)gridDim.x * 256) {
-        u32 r = cand[c];
-        u32 lw = lens[r]; u32 n = lw & 0x7FFFu; bool has_n = (lw & 0x8000u) != 0;
-        const u32* row = packed + (u64)r * wpr;
-        const u8* qrow = qrows + (u64)r * qstride;
-        Bin* bins = s_bins[tid]; int nb = 0;
-        int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-        for (int t = 0; t < nseeds; t++) {
-            int o = t * MLST_SEED_STEP;
-            if (has_n) { bool bad = false; for (int k = 0; k < MLST_SEED_LEN; k++) bad |= (qrow[o + k] & 0x80) != 0; if (bad) continue; }
-            u32 lo = row[t], hi = row[t + 1] & 0xFFu, val;
-            if (!table_find(E, lo, hi, val)) continue;
-            u32 pstart, pcount; u32 single = 0;
-            if (val & 0x80000000u) { single = val & 0x7FFFFFFFu; pstart = 0; pcount = 1; }
-            else { pstart = val >> 5; pcount = val & 31u; }
-            for (u32 p = 0; p < pcount; p++) {
-                u32 post = (val & 0x80000000u) ? single : E.posts[pstart + p];
-                u32 locus = post >> 13, strand = (post >> 12) & 1; int pos = (int)(post & 0xFFFu);
-                int diag = strand ? pos + MLST_SEED_LEN + o - (int)n : pos - o;
-                int k; for (k = 0; k < nb; k++) if (bins[k].locus == locus && bins[k].strand == strand && bins[k].diag == diag) break;
-                if (k < nb) bins[k].votes++;
-                else if (nb < MLST_MAX_CAND) { bins[nb].locus = locus; bins[nb].strand = (u16)strand; bins[nb].diag = diag; bins[nb].votes = 1; nb++; }
+    for (u64 c0 = (u64)blockIdx.x * 256; c0 < n_cand; c0 += (u64)gridDim.x * 256) {
+        u64 c = c0 + tid;
+        u32 r = 0, lw = 0, n = 0; int no = 0;
+        Bin* items = s_items[tid];
+        if (c < n_cand) {
+            r = cand[c];
+            lw = lens[r]; n = lw & 0x7FFFu; bool has_n = (lw & 0x8000u) != 0;
+            const u32* row = packed + (u64)r * wpr;
+            const u8* qrow = qrows + (u64)r * qstride;
+            Bin* bins = s_bins[tid]; int nb = 0;
+            int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
+            for (int t = 0; t < nseeds; t++) {
+                int o = t * MLST_SEED_STEP;
+                if (has_n) { bool bad = false; for (int k = 0; k < MLST_SEED_LEN; k++) bad |= (qrow[o + k] & 0x80) != 0; if (bad) continue; }
+                u32 lo = row[t], hi = row[t + 1] & 0xFFu, val;
+                if (!table_find(E, lo, hi, val)) continue;
+                u32 pstart, pcount; u32 single = 0;
+                if (val & 0x80000000u) { single = val & 0x7FFFFFFFu; pstart = 0; pcount = 1; }
+                else { pstart = val >> 5; pcount = val & 31u; }
+                for (u32 p = 0; p < pcount; p++) {
+                    u32 post = (val & 0x80000000u) ? single : E.posts[pstart + p];
+                    u32 locus = post >> 13, strand = (post >> 12) & 1; int pos = (int)(post & 0xFFFu);
+                    int diag = strand ? pos + MLST_SEED_LEN + o - (int)n : pos - o;
+                    int k; for (k = 0; k < nb; k++) if (bins[k].locus == locus && bins[k].strand == strand && bins[k].diag == diag) break;
+                    if (k < nb) bins[k].votes++;
+                    else if (nb < MLST_MAX_CAND) { bins[nb].locus = locus; bins[nb].strand = (u16)strand; bins[nb].diag = diag; bins[nb].votes = 1; nb++; }
+                }
+            }
+            // one item per (locus, strand): most votes, then the smaller diagonal; first-seen order
+            int ni = 0;
+            for (int k = 0; k < nb; k++) {
+                int u; for (u = 0; u < ni; u++) if (items[u].locus == bins[k].locus && items[u].strand == bins[k].strand) break;
+                if (u == ni) items[ni++] = bins[k];
+                else if (bins[k].votes > items[u].votes || (bins[k].votes == items[u].votes && bins[k].diag < items[u].diag)) items[u] = bins[k];
+            }
+            for (int u = 0; u < ni; u++) if (items[u].votes >= MLST_MIN_VOTES) items[no++] = items[u];
+        }
+        // retain the read.  Counters are bumped once per wave (ballot / prefix sums), not once per lane:
+        // a contended word serves only ~88 returning atomics per microsecond.
+        u64 keep = __ballot(no > 0);
+        u64 slot = ~0ull;
+        if (keep) {
+            int leader = __ffsll((long long)keep) - 1;
+            u64 base = 0;
+            if (lane == leader) base = atomicAdd(&E.ctr->n_ret, (u64)__popcll(keep));
+            base = __shfl(base, leader);
+            if (no > 0) {
+                slot = base + __popcll(keep & ((1ull << lane) - 1));
+                if (slot >= E.cap_ret) { atomicOr(&E.ctr->err, 1ull); slot = ~0ull; no = 0; }
             }
         }
-        if (nb == 0) continue;
-        // one item per (locus, strand): most votes, then the smaller diagonal; first-seen order
-        Bin* items = s_items[tid]; int ni = 0;
-        for (int k = 0; k < nb; k++) {
-            int u; for (u = 0; u < ni; u++) if (items[u].locus == bins[k].locus && items[u].strand == bins[k].strand) break;
-            if (u == ni) items[ni++] = bins[k];
-            else if (bins[k].votes > items[u].votes || (bins[k].votes == items[u].votes && bins[k].diag < items[u].diag)) items[u] = bins[k];
+        u64 todo = __ballot(no > 0);
+        while (todo) {        // the 400-byte copy of each kept read is done by the whole wave
+            int src = __ffsll((long long)todo) - 1; todo &= todo - 1;
+            u32 rr = __shfl(r, src), nn = __shfl(n, src), lww = __shfl(lw, src);
+            u64 sl = __shfl(slot, src);
+            const u32* row = packed + (u64)rr * wpr;
+            const u32* qrow32 = reinterpret_cast<const u32*>(qrows + (u64)rr * qstride);
+            u32* dq = reinterpret_cast<u32*>(E.ret_quals + sl * RQ);
+            if (lane < RW) E.ret_bases[sl * RW + lane] = (u32)lane < wpr ? row[lane] : 0u;
+            u32 nq = (nn < qstride ? nn : qstride);        // bytes to keep; rows hold zeros beyond the read length
+            for (u32 w = lane; w < RQ / 4; w += 64) dq[w] = (w * 4 < nq) ? qrow32[w] : 0u;
+            if (lane == 0) { E.ret_len[sl] = (u16)lww; E.ret_ridx[sl] = read_base + rr; E.ret_nrec[sl] = 0; }
         }
-        int no = 0;
-        for (int u = 0; u < ni; u++) if (items[u].votes >= MLST_MIN_VOTES) items[no++] = items[u];
-        if (no == 0) continue;
-        u64 slot = atomicAdd(&E.ctr->n_ret, 1ull);
-        if (slot >= E.cap_ret) { atomicOr(&E.ctr->err, 1ull); continue; }
-        for (u32 w = 0; w < RW; w++) E.ret_bases[slot * RW + w] = w < wpr ? row[w] : 0u;
-        for (u32 i = 0; i < RQ; i++) E.ret_quals[slot * RQ + i] = (i < n && i < qstride) ? qrow[i] : (u8)0;
-        E.ret_len[slot] = (u16)lw; E.ret_ridx[slot] = read_base + r; E.ret_nrec[slot] = 0;
-        u64 ib = atomicAdd(&E.ctr->n_items, (u64)no);
+        // item slots and result rows: wave prefix sums, one atomic per counter per wave
+        u32 my_res = 0;
+        for (int u = 0; u < no; u++) my_res += E.loci[items[u].locus].n_pad;
+        u32 tot_items, tot_res;
+        u32 pre_items = wave_excl_scan_u32((u32)no, tot_items);
+        u32 pre_res = wave_excl_scan_u32(my_res, tot_res);
+        u64 ib0 = 0, ro0 = 0;
+        if (tot_items) {
+            if (lane == 0) { ib0 = atomicAdd(&E.ctr->n_items, (u64)tot_items); ro0 = atomicAdd(&E.ctr->n_res, (u64)tot_res); }
+            ib0 = __shfl(ib0, 0); ro0 = __shfl(ro0, 0);
+        }
+        u64 ib = ib0 + pre_items, ro = ro0 + pre_res;
         for (int u = 0; u < no; u++) {
+            u32 np = E.loci[items[u].locus].n_pad;
             if (ib + u >= E.cap_items) { atomicOr(&E.ctr->err, 2ull); break; }
-            u64 ro = atomicAdd(&E.ctr->n_res, (u64)E.loci[items[u].locus].n_pad);
-            if (ro + E.loci[items[u].locus].n_pad > E.cap_res) { atomicOr(&E.ctr->err, 4ull); }
-            ItemDev it; it.res_off = ro; it.ret = (u32)slot; it.locus = items[u].locus; it.diag = items[u].diag;
-            it.strand = items[u].strand; it.votes = items[u].votes;
-            E.items[ib + u] = it;
+            if (ro + np > E.cap_res) atomicOr(&E.ctr->err, 4ull);
+            ItemDev itd; itd.res_off = ro; itd.ret = (u32)slot; itd.locus = items[u].locus; itd.diag = items[u].diag;
+            itd.strand = items[u].strand; itd.votes = items[u].votes;
+            E.items[ib + u] = itd;
+            E.item_state[ib + u] = (u8)(no == 1 ? IS_SINGLE : 0);
+            ro += np;
         }
     }
 }
@@ -304,26 +370,26 @@ __global__ __launch_bounds__(256) void k_seed(EngineDev E, const u32* __restrict
 // Oriented read i (after reverse-complement when strand = 1) lives at source position s = strand ? n-1-i : i.
 __device__ inline u32 src_base(const u32* rb, int s) { return (rb[s >> 4] >> (2 * (s & 15))) & 3u; }
 
-// Build the oriented read of an item in LDS: 2-bit words, N bits (1 per base) and the per-position
-// mismatch penalty (bowtie2 --mp 6,2 quality-aware; --np 1 for N).
+// Build the oriented read of an item in LDS: 2-bit words, N bits (1 per base) and the per-position mismatch
+// penalty (bowtie2 --mp 6,2 quality-aware; --np 1 for N).  Cooperative: nthreads is a multiple of 64, every thread
+// owns read positions tid, tid+nthreads, ...; words are assembled with lane OR-reductions.
 __device__ inline void stage_read(const EngineDev& E, const KParams& P, const ItemDev& it, int n,
-                                  u32* s_rw, u32* s_rn, u8* s_pen, u8* s_q, int tid, int nthreads) {
+                                  u32* s_rw, u32* s_rn, u8* s_pen, u8* s_q, const u8* s_pentab, int tid, int nthreads) {
     const u32* rb = E.ret_bases + (u64)it.ret * RW;
     const u8* rq = E.ret_quals + (u64)it.ret * RQ;
-    for (int w = tid; w < RW; w += nthreads) {
-        u32 word = 0;
-        for (int k = 0; k < 16; k++) { int i = w * 16 + k; if (i < n) { int s = it.strand ? n - 1 - i : i; u32 b = src_base(rb, s); if (it.strand) b ^= 3u; word |= b << (2 * k); } }
-        s_rw[w] = word;
-    }
-    for (int w = tid; w < RW / 2; w += nthreads) {
-        u32 word = 0;
-        for (int k = 0; k < 32; k++) { int i = w * 32 + k; if (i < n) { int s = it.strand ? n - 1 - i : i; word |= (u32)(rq[s] >> 7) << k; } }
-        s_rn[w] = word;
-    }
-    for (int i = tid; i < n; i += nthreads) {
-        int s = it.strand ? n - 1 - i : i; u8 qb = rq[s];
-        s_pen[i] = (qb & 0x80) ? (u8)P.n_penalty : E.pen_tab[qb & 0x7F];
-        if (s_q) s_q[i] = qb;
+    for (int i0 = 0; i0 < RQ; i0 += nthreads) {
+        int i = i0 + tid; u32 v = 0, nb = 0;
+        if (i < n) {
+            int s = it.strand ? n - 1 - i : i; u8 qb = rq[s];
+            u32 b = src_base(rb, s); if (it.strand) b ^= 3u;
+            u32 isn = qb >> 7;
+            s_pen[i] = isn ? (u8)P.n_penalty : s_pentab[qb & 0x7F];
+            if (s_q) s_q[i] = qb;
+            v = b << (2 * (i & 15)); nb = isn << (i & 31);
+        }
+        v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 8);
+        nb |= __shfl_xor(nb, 1); nb |= __shfl_xor(nb, 2); nb |= __shfl_xor(nb, 4); nb |= __shfl_xor(nb, 8); nb |= __shfl_xor(nb, 16);
+        if (i < RQ) { if ((i & 15) == 0) s_rw[i >> 4] = v; if ((i & 31) == 0) s_rn[i >> 5] = nb; }
     }
 }
 
@@ -345,6 +411,8 @@ __device__ inline u32 spread16(u32 x) {
 // Ungapped local alignment of the staged read against allele a_local on diagonal d (Kadane over the mismatch
 // positions of the XOR of 2-bit words).  Returns the packed best value; mm_total = mismatching columns of the
 // whole overlap; [bs,be) = aligned read span.  Same recurrence as oracle align_ungapped.
+// The allele window (one dword per 16 bases, coalesced across lanes = alleles) is fetched as one batch of
+// independent loads before the serial Kadane pass.
 __device__ inline int ungapped(const EngineDev& E, const KParams& P, const LocusDev& L, u32 a_local, int m, int n, int d,
                                const u32* s_rw, const u32* s_rn, const u8* s_pen, bool read_has_n,
                                int& mm_total, int& bs, int& be) {
@@ -352,81 +420,147 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
     mm_total = 0; bs = be = i0;
     if (i1 <= i0) return P0;
     const int MA = P.match_bonus << MLST_P_SHIFT;
-    int cur = P0, best = P0, cs = i0, last = i0;
-    int t0 = i0 >> 4, t1 = (i1 + 15) >> 4;
-    // allele word holding allele base (16*t0 + d)
-    int g = 16 * t0 + d; int q = g >> 4; int r2 = (g & 15) * 2;   // g >> 4 floors for negatives (arithmetic shift)
-    u32 A0 = arena_word(E, L, q, a_local);
-    for (int t = t0; t < t1; t++, q++) {
-        u32 A1 = arena_word(E, L, q + 1, a_local);
-        u32 ash = r2 ? ((A0 >> r2) | (A1 << (32 - r2))) : A0;
-        A0 = A1;
-        u32 x = s_rw[t] ^ ash;
-        u32 mmw = (x | (x >> 1)) & 0x55555555u;
-        u32 anw = 0;
-        if (read_has_n) mmw |= spread16(s_rn[t >> 1] >> ((t & 1) * 16));
-        if (L.has_n) {   // allele N bits for allele bases g..g+15 (g = 16t + d)
-            int gg = 16 * t + d; int nq = gg >> 5, nr = gg & 31;
-            u32 n0 = nmask_word(E, L, nq, a_local), n1 = nmask_word(E, L, nq + 1, a_local);
-            u32 nb = nr ? ((n0 >> nr) | (n1 << (32 - nr))) : n0;
-            anw = spread16(nb); mmw |= anw;
+    const int nw = (n + 15) >> 4;                  // read words in use (block-uniform)
+    const int q0 = d >> 4, r2 = (d & 15) * 2;      // allele word of read position 0 (floor), bit shift
+    const u32* abase = E.arena + L.arena_off + a_local;
+    u32 Aw[RW + 1];
+    #pragma unroll
+    for (int t = 0; t <= RW; t++) {
+        Aw[t] = 0;
+        if (t <= nw) {                             // uniform guard
+            int q = q0 + t; int qc = q < 0 ? 0 : (q >= (int)L.words ? (int)L.words - 1 : q);
+            Aw[t] = ld_async_u32(abase + (u64)qc * L.n_pad);
         }
-        int lo = i0 - 16 * t; lo = lo < 0 ? 0 : lo;
-        int hi = i1 - 16 * t; hi = hi > 16 ? 16 : hi;
-        u32 vm = (hi >= 16 ? 0xFFFFFFFFu : ((1u << (2 * hi)) - 1u)) & ~((1u << (2 * lo)) - 1u);
-        mmw &= vm;
-        mm_total += __popc(mmw);
-        while (mmw) {
-            int bit = __ffs(mmw) - 1; mmw &= mmw - 1;
-            int i = 16 * t + (bit >> 1);
-            cur += (i - last) * MA;
-            if (cur > best) { best = cur; bs = cs; be = i; }
-            int pen = ((anw >> bit) & 1u) ? P.n_penalty : (int)s_pen[i];
-            cur -= (pen << MLST_P_SHIFT) + 1;
-            if (cur <= P0) { cur = P0; cs = i + 1; }
-            last = i + 1;
+    }
+    ld_wait_all();
+    #pragma unroll
+    for (int t = 0; t <= RW; t++) { LD_TIE(Aw[t]); int q = q0 + t; if (t > nw || q < 0 || q >= (int)L.words) Aw[t] = 0; }
+    int cur = P0, best = P0, cs = i0, last = i0;
+    #pragma unroll
+    for (int t = 0; t < RW; t++) {
+        if (t < nw) {
+            int lo = i0 - 16 * t; lo = lo < 0 ? 0 : lo;
+            int hi = i1 - 16 * t; hi = hi > 16 ? 16 : hi;
+            if (hi > lo) {
+                u32 ash = r2 ? ((Aw[t] >> r2) | (Aw[t + 1] << (32 - r2))) : Aw[t];
+                u32 x = s_rw[t] ^ ash;
+                u32 mmw = (x | (x >> 1)) & 0x55555555u;
+                u32 anw = 0;
+                if (read_has_n) mmw |= spread16(s_rn[t >> 1] >> ((t & 1) * 16));
+                if (L.has_n) {   // allele N bits for allele bases g..g+15 (g = 16t + d)
+                    int gg = 16 * t + d; int nq = gg >> 5, nr = gg & 31;
+                    u32 n0 = nmask_word(E, L, nq, a_local), n1 = nmask_word(E, L, nq + 1, a_local);
+                    u32 nb = nr ? ((n0 >> nr) | (n1 << (32 - nr))) : n0;
+                    anw = spread16(nb); mmw |= anw;
+                }
+                u32 vm = (hi >= 16 ? 0xFFFFFFFFu : ((1u << (2 * hi)) - 1u)) & ~((1u << (2 * lo)) - 1u);
+                mmw &= vm;
+                mm_total += __popc(mmw);
+                while (mmw) {
+                    int bit = __ffs(mmw) - 1; mmw &= mmw - 1;
+                    int i = 16 * t + (bit >> 1);
+                    cur += (i - last) * MA;
+                    if (cur > best) { best = cur; bs = cs; be = i; }
+                    int pen = ((anw >> bit) & 1u) ? P.n_penalty : (int)s_pen[i];
+                    cur -= (pen << MLST_P_SHIFT) + 1;
+                    if (cur <= P0) { cur = P0; cs = i + 1; }
+                    last = i + 1;
+                }
+            }
         }
     }
     cur += (i1 - last) * MA;
     if (cur > best) { best = cur; bs = cs; be = i1; }
     return best;
 }
+// the policy deciding whether the banded Smith-Waterman runs for a pair (same expression as oracle align_pair)
+__device__ inline bool gap_trigger(const KParams& P, int mm, int score, int floor_n, int m, int n, int d, int bs, int be) {
+    if (P.trig < 0) return true;
+    int i0 = d < 0 ? -d : 0, i1 = (m - d) < n ? (m - d) : n;
+    int overlap = i1 > i0 ? i1 - i0 : 0;
+    return mm > P.trig && score >= floor_n && overlap - (be - bs) >= P.clip;
+}
 
 // ------------------------------------------------------------------ K3: extension of every item against every allele of its locus
+// accept test of metamlst.py:115 on one result word; f15 = XM, or XO when the read has a single record (Q1)
+__device__ inline bool accept_rec(const KParams& P, u32 r, int n, bool use_xo) {
+    int score = (int)(r & 0x3FF), xm = (int)((r >> 10) & 0xFF), xo = (int)((r >> 18) & 0x7F);
+    return score >= P.minscore && n >= P.min_read_len && (use_xo ? xo : xm) <= P.max_xm;
+}
+
 __global__ __launch_bounds__(256) void k_extend(EngineDev E, KParams P) {
-    __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u32 s_cnt[4];
+    __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
+    __shared__ u32 s_cnt[4][3];
     const int tid = threadIdx.x;
+    if (tid < 128) s_pentab[tid] = E.pen_tab[tid];
+    u64 c_tot = 0, c_ign = 0;                     // block-level counters, flushed once at the end (thread 0)
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
     for (u64 ii = begin + blockIdx.x; ii < end; ii += gridDim.x) {
         ItemDev it = E.items[ii];
         const LocusDev L = E.loci[it.locus];
         u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu); bool read_has_n = (lw & 0x8000u) != 0;
+        u8 state = E.item_state[ii];
         __syncthreads();
-        stage_read(E, P, it, n, s_rw, s_rn, s_pen, nullptr, tid, 256);
+        stage_read(E, P, it, n, s_rw, s_rn, s_pen, nullptr, s_pentab, tid, 256);
         if (tid == 0) { s_rw[RW] = s_rw[RW + 1] = 0; }
         __syncthreads();
         if (it.res_off + L.n_pad > E.cap_res) continue;      // flagged by k_seed
         const int floor_n = E.floor_tab[n];
-        u32 nrec = 0;
+        u32 nrec = 0, ndp = 0;
         for (u32 a = tid; a < L.n_alleles; a += 256) {
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
             int best = ungapped(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_pen, read_has_n, mm, bs, be);
             int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
-            bool need_dp = P.trig < 0 ? true : (mm > P.trig && score >= floor_n);
+            bool need_dp = gap_trigger(P, mm, score, floor_n, m, n, it.diag, bs, be);
             u32 r = pack_result(score, xm, xo);
-            if (need_dp) {
-                r |= R_NEEDDP;
-                u64 slot = atomicAdd(&E.ctr->n_dp, 1ull);
-                if (slot < E.cap_dp) E.dp_list[slot] = (ii << 20) | (u64)a; else atomicOr(&E.ctr->err, 8ull);
-            } else if (score >= floor_n && score > 0) { r |= R_REC; nrec++; }
+            if (need_dp) { r |= R_NEEDDP; ndp++; }
+            else if (score >= floor_n && score > 0) { r |= R_REC; nrec++; }
+            // banded-SW worklist: one returning atomic per wave, not per pair
+            u64 wm = __ballot(need_dp);
+            if (wm) {
+                int lane = tid & 63, leader = __ffsll((long long)wm) - 1; u64 base = 0;
+                if (lane == leader) base = atomicAdd(&E.ctr->n_dp, (u64)__popcll(wm));
+                base = __shfl(base, leader);
+                if (need_dp) { u64 slot = base + __popcll(wm & ((1ull << lane) - 1));
+                               if (slot < E.cap_dp) E.dp_list[slot] = (ii << 20) | (u64)a; else atomicOr(&E.ctr->err, 8ull); }
+            }
             E.res[it.res_off + a] = r;
         }
-        // records of this item -> per-read record count (decides XM vs XO column, Q1)
-        for (int o = 32; o > 0; o >>= 1) nrec += __shfl_down(nrec, o);
-        if ((tid & 63) == 0) s_cnt[tid >> 6] = nrec;
+        nrec = wave_sum_u32(nrec); ndp = wave_sum_u32(ndp);
+        if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = nrec; s_cnt[tid >> 6][1] = ndp; }
         __syncthreads();
-        if (tid == 0) { u32 tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; if (tot) atomicAdd(&E.ret_nrec[it.ret], tot); }
+        u32 tot_rec = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+        u32 tot_dp = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+        if (tid == 0 && tot_rec) atomicAdd(&E.ret_nrec[it.ret], tot_rec);   // per-read record count (Q1)
+        // Fused accumulation (metamlst.py:101-130) when everything about this read is known here:
+        // it has a single work item and no pair is waiting for the banded SW.
+        if ((state & IS_SINGLE) && tot_dp == 0) {
+            bool use_xo = P.quirk && tot_rec == 1;
+            u32 acc = 0, ign = 0;
+            for (u32 a = tid; a < L.n_alleles; a += 256) {
+                u32 r = E.res[it.res_off + a];
+                if (!(r & R_REC)) continue;
+                if (accept_rec(P, r, n, use_xo)) {
+                    atomicAdd((u64*)&E.sum_score[L.a_begin + a], (u64)(r & 0x3FF));
+                    atomicAdd(&E.n_hits[L.a_begin + a], 1u);
+                    acc++;
+                } else ign++;
+            }
+            acc = wave_sum_u32(acc); ign = wave_sum_u32(ign);
+            __syncthreads();
+            if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = acc; s_cnt[tid >> 6][1] = ign; }
+            __syncthreads();
+            if (tid == 0) {
+                u32 A = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0], I = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+                c_tot += tot_rec; c_ign += I;
+                E.item_state[ii] = (u8)(state | IS_DONE | (A ? IS_ACC : 0));
+            }
+        }
+    }
+    if (tid == 0) {
+        if (c_tot) atomicAdd(&E.ctr->cnt[MLST_CNT_TOTAL_RECORDS], c_tot);
+        if (c_ign) atomicAdd(&E.ctr->cnt[MLST_CNT_IGNORED], c_ign);
     }
 }
 
@@ -435,7 +569,7 @@ __global__ __launch_bounds__(256) void k_extend(EngineDev E, KParams P) {
 // rules as oracle align_banded.  TB != nullptr additionally stores the traceback byte of every cell.
 template <bool TRACE>
 __device__ inline int banded(const EngineDev& E, const KParams& P, const ItemDev& it, const LocusDev& L, u32 a_local,
-                             int n, u8* TB, int& bi, int& bb) {
+                             int n, const u8* s_pentab, u8* TB, int& bi, int& bb) {
     const int W = P.band_w, BW = 2 * W + 1, G = P.gbar, d = it.diag;
     const int m = (int)E.allele_len[L.a_begin + a_local];
     const int OPEN = P.open_p, EXT = P.ext_p, MA = P.match_bonus << MLST_P_SHIFT;
@@ -445,22 +579,33 @@ __device__ inline int banded(const EngineDev& E, const KParams& P, const ItemDev
     #pragma unroll
     for (int b = 0; b < 2 * MAX_W + 2; b++) { Hp[b] = P0; Fp[b] = NEGP; }
     int best = P0; bi = -1; bb = -1;
-    for (int i = 0; i < n; i++) {
+    // allele bases of the band live in a sliding window: three arena words = allele bases [16q, 16q+48)
+    int jb = d - W;                               // allele position of band cell 0 in row 0
+    int q = jb >> 4;                              // floor(jb / 16)
+    u32 w0 = arena_word(E, L, q, a_local), w1 = arena_word(E, L, q + 1, a_local), w2 = arena_word(E, L, q + 2, a_local);
+    u8 qb_next = rq[it.strand ? n - 1 : 0];
+    u32 rword = 0; int rword_idx = -1;
+    for (int i = 0; i < n; i++, jb++) {
         int s = it.strand ? n - 1 - i : i;
-        u8 qb = rq[s]; bool rn = (qb & 0x80) != 0;
-        u32 rbase = src_base(rb, s); if (it.strand) rbase ^= 3u;
-        int pen = rn ? P.n_penalty : (int)E.pen_tab[qb & 0x7F];
+        u8 qb = qb_next;
+        if (i + 1 < n) qb_next = rq[it.strand ? n - 2 - i : i + 1];      // prefetch the next row's quality byte
+        if ((s >> 4) != rword_idx) { rword_idx = s >> 4; rword = rb[rword_idx]; }
+        bool rn = (qb & 0x80) != 0;
+        u32 rbase = (rword >> (2 * (s & 15))) & 3u; if (it.strand) rbase ^= 3u;
+        int pen = rn ? P.n_penalty : (int)s_pentab[qb & 0x7F];
         bool gap_ok = (i >= G && i < n - G);
+        if ((jb >> 4) != q) { q++; w0 = w1; w1 = w2; w2 = arena_word(E, L, q + 2, a_local); }
+        int sh = 2 * (jb - 16 * q);               // 0..30
+        u64 lo64 = (u64)w0 | ((u64)w1 << 32);
+        u64 rowbits = sh ? ((lo64 >> sh) | ((u64)w2 << (64 - sh))) : lo64;   // bases jb .. jb+31, 2 bits each
         int Hleft = P0, Eleft = NEGP;
-        int jb = i + d - W;
         #pragma unroll
         for (int b = 0; b < 2 * MAX_W + 1; b++) {
             if (b < BW) {
                 int j = jb + b;
                 bool exists = (j >= 0 && j < m);
-                int jj = exists ? j : 0;
-                u32 ab = (arena_word(E, L, jj >> 4, a_local) >> (2 * (jj & 15))) & 3u;
-                bool an = exists && allele_is_n(E, L, jj, a_local);
+                u32 ab = (u32)(rowbits >> (2 * b)) & 3u;
+                bool an = L.has_n && exists && allele_is_n(E, L, j, a_local);
                 int delta = (!rn && !an && rbase == ab) ? MA : -(((rn || an) ? P.n_penalty : pen) << MLST_P_SHIFT) - 1;
                 int diag = Hp[b] + delta;
                 int e = NEGP, f = NEGP; u8 tb = 0;
@@ -480,28 +625,97 @@ __device__ inline int banded(const EngineDev& E, const KParams& P, const ItemDev
     return best;
 }
 
-__global__ __launch_bounds__(64) void k_banded(EngineDev E, KParams P) {
+// Score-only banded SW, row-parallel: 32 lanes per (item, allele) pair, lane b owns band cell b of the current row.
+//   diagonal predecessor (i-1, j-1) = the lane's own previous H      (band coordinates shift by one per row)
+//   F predecessor        (i-1, j)   = lane b+1's previous H / F      (one shuffle)
+//   E within the row: E_b = max_{b'<b} (H'_{b'} - OPEN - EXT*(b-1-b')) with H' = max(fresh, diag, F): an exclusive
+//   prefix-max scan over the lanes (a gap is never opened from a cell that was itself reached through E, because
+//   OPEN > EXT), so every H equals the sequential recurrence of banded<>() / oracle align_banded.
+// Two pairs per wave; XM / XO come out of the packed maximum, no traceback.
+__global__ __launch_bounds__(256) void k_banded(EngineDev E, KParams P) {
+    __shared__ u8 s_pentab[128];
+    if (threadIdx.x < 128) s_pentab[threadIdx.x] = E.pen_tab[threadIdx.x];
+    __syncthreads();
+    const int b = threadIdx.x & 31;
+    const u64 grp = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 5, ngrp = ((u64)gridDim.x * blockDim.x) >> 5;
     const u64 begin = E.ctr->dp_done, end = E.ctr->n_dp < E.cap_dp ? E.ctr->n_dp : E.cap_dp;
-    for (u64 k = begin + (u64)blockIdx.x * 64 + threadIdx.x; k < end; k += (u64)gridDim.x * 64) {
-        u64 e = E.dp_list[k]; u64 ii = e >> 20; u32 a = (u32)(e & 0xFFFFFu);
-        ItemDev it = E.items[ii];
+    const int W = P.band_w, BW = 2 * W + 1, G = P.gbar;
+    const int OPEN = P.open_p, EXT = P.ext_p, MA = P.match_bonus << MLST_P_SHIFT;
+    const u64 n_iter = (end - begin + ngrp - 1) / ngrp;
+    for (u64 itx = 0; itx < n_iter; itx++) {
+        u64 k = begin + itx * ngrp + grp;
+        bool live = k < end;
+        u64 e = live ? E.dp_list[k] : 0; u64 ii = e >> 20; u32 a_local = (u32)(e & 0xFFFFFu);
+        ItemDev it; it.res_off = 0; it.ret = 0; it.locus = 0; it.diag = 0; it.strand = 0; it.votes = 0;
+        if (live) it = E.items[ii];
         const LocusDev L = E.loci[it.locus];
-        int n = (int)(E.ret_len[it.ret] & 0x7FFFu);
-        int bi, bb;
-        int best = banded<false>(E, P, it, L, a, n, nullptr, bi, bb);
-        int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
-        u32 r = pack_result(score, xm, xo) | R_USEDDP;
-        if (score >= E.floor_tab[n] && score > 0) { r |= R_REC; atomicAdd(&E.ret_nrec[it.ret], 1u); }
-        E.res[it.res_off + a] = r;
+        int n = live ? (int)(E.ret_len[it.ret] & 0x7FFFu) : 0;
+        int nmax = n; { int o = __shfl_xor(nmax, 32); nmax = o > nmax ? o : nmax; }    // both halves run the same trip count
+        const int d = it.diag;
+        const int m = live ? (int)E.allele_len[L.a_begin + a_local] : 0;
+        const u32* rb = E.ret_bases + (u64)it.ret * RW;
+        const u8* rq = E.ret_quals + (u64)it.ret * RQ;
+        int Hp = P0, Fp = NEGP, best = P0;
+        int jb = d - W, q = jb >> 4;
+        u32 w0 = arena_word(E, L, q, a_local), w1 = arena_word(E, L, q + 1, a_local), w2 = arena_word(E, L, q + 2, a_local);
+        u8 qb_next = n > 0 ? rq[it.strand ? n - 1 : 0] : (u8)0;
+        u32 rword = 0; int rword_idx = -1;
+        for (int i = 0; i < nmax; i++, jb++) {
+            bool row = i < n;
+            int s = it.strand ? n - 1 - i : i; if (!row) s = 0;
+            u8 qb = qb_next;
+            if (i + 1 < n) qb_next = rq[it.strand ? n - 2 - i : i + 1];
+            if (row && (s >> 4) != rword_idx) { rword_idx = s >> 4; rword = rb[rword_idx]; }
+            bool rn = (qb & 0x80) != 0;
+            u32 rbase = (rword >> (2 * (s & 15))) & 3u; if (it.strand) rbase ^= 3u;
+            int pen = rn ? P.n_penalty : (int)s_pentab[qb & 0x7F];
+            bool gap_ok = row && (i >= G && i < n - G);
+            if (row && (jb >> 4) != q) { q++; w0 = w1; w1 = w2; w2 = arena_word(E, L, q + 2, a_local); }
+            int sh = 2 * (jb - 16 * q);
+            u64 lo64 = (u64)w0 | ((u64)w1 << 32);
+            u64 rowbits = sh ? ((lo64 >> sh) | ((u64)w2 << (64 - sh))) : lo64;
+            int j = jb + b;
+            bool exists = row && b < BW && j >= 0 && j < m;
+            u32 ab = (u32)(rowbits >> (2 * b)) & 3u;
+            bool an = L.has_n && exists && allele_is_n(E, L, j, a_local);
+            int delta = (!rn && !an && rbase == ab) ? MA : -(((rn || an) ? P.n_penalty : pen) << MLST_P_SHIFT) - 1;
+            int diag = Hp + delta;
+            int Hup = __shfl_down(Hp, 1, 32), Fup = __shfl_down(Fp, 1, 32);
+            int f = NEGP;
+            if (gap_ok && b < BW - 1) { int f1 = Hup - OPEN, f2 = Fup - EXT; f = f2 > f1 ? f2 : f1; }
+            int h1 = P0; if (diag > h1) h1 = diag; if (f > h1) h1 = f;
+            if (!exists) { h1 = P0; f = NEGP; }
+            // exclusive prefix max of g = H' + EXT*b over the 32 lanes of the pair
+            int g = h1 + EXT * b;
+            int x = __shfl_up(g, 1, 32); if (b < 1) x = NEGP;
+            #pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { int y = __shfl_up(x, o, 32); if (b >= o + 1 && y > x) x = y; }
+            int ee = (gap_ok && b > 0) ? x - OPEN - EXT * (b - 1) : NEGP;
+            int h = h1; if (ee > h) h = ee;
+            if (!exists) h = P0;
+            if (row) { if (h > best) best = h; Hp = h; Fp = f; }
+        }
+        #pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { int y = __shfl_xor(best, o, 32); best = y > best ? y : best; }
+        if (live && b == 0) {
+            int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
+            u32 r = pack_result(score, xm, xo) | R_USEDDP;
+            if (score >= E.floor_tab[n] && score > 0) { r |= R_REC; atomicAdd(&E.ret_nrec[it.ret], 1u); }
+            E.res[it.res_off + a_local] = r;
+        }
     }
 }
 
 // ------------------------------------------------------------------ K5: accumulate (metamlst.py:101-130)
 __global__ __launch_bounds__(256) void k_accumulate(EngineDev E, KParams P) {
+    // items k_extend could not finish: reads with several work items, or pairs that went through the banded SW
     __shared__ u32 s_red[4][4];
     const int tid = threadIdx.x;
+    u64 c_tot = 0, c_ign = 0, c_dp = 0;
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
     for (u64 ii = begin + blockIdx.x; ii < end; ii += gridDim.x) {
+        u8 state = E.item_state[ii];
+        if (state & IS_DONE) continue;
         ItemDev it = E.items[ii];
         const LocusDev L = E.loci[it.locus];
         if (it.res_off + L.n_pad > E.cap_res) continue;
@@ -513,29 +727,51 @@ __global__ __launch_bounds__(256) void k_accumulate(EngineDev E, KParams P) {
             u32 r = E.res[it.res_off + a];
             if (r & R_USEDDP) dp++;
             if (!(r & R_REC)) continue;
-            int score = (int)(r & 0x3FF), xm = (int)((r >> 10) & 0xFF), xo = (int)((r >> 18) & 0x7F);
-            int f15 = use_xo ? xo : xm;
             tot++;
-            if (score >= P.minscore && n >= P.min_read_len && f15 <= P.max_xm) {
-                atomicAdd((u64*)&E.sum_score[L.a_begin + a], (u64)score);
+            if (accept_rec(P, r, n, use_xo)) {
+                atomicAdd((u64*)&E.sum_score[L.a_begin + a], (u64)(r & 0x3FF));
                 atomicAdd(&E.n_hits[L.a_begin + a], 1u);
                 acc++;
             } else ign++;
         }
-        for (int o = 32; o > 0; o >>= 1) { tot += __shfl_down(tot, o); ign += __shfl_down(ign, o); acc += __shfl_down(acc, o); dp += __shfl_down(dp, o); }
+        tot = wave_sum_u32(tot); ign = wave_sum_u32(ign); acc = wave_sum_u32(acc); dp = wave_sum_u32(dp);
         __syncthreads();
         if ((tid & 63) == 0) { s_red[tid >> 6][0] = tot; s_red[tid >> 6][1] = ign; s_red[tid >> 6][2] = acc; s_red[tid >> 6][3] = dp; }
         __syncthreads();
         if (tid == 0) {
             u32 T = 0, I = 0, A = 0, D = 0;
             for (int w = 0; w < 4; w++) { T += s_red[w][0]; I += s_red[w][1]; A += s_red[w][2]; D += s_red[w][3]; }
-            if (T) atomicAdd(&E.ctr->cnt[MLST_CNT_TOTAL_RECORDS], (u64)T);
-            if (I) atomicAdd(&E.ctr->cnt[MLST_CNT_IGNORED], (u64)I);
-            if (D) atomicAdd(&E.ctr->cnt[MLST_CNT_DP_PAIRS], (u64)D);
-            if (A) {   // sequenceBank[locus][QNAME] = len(SEQ), first-seen order (Q6)
-                atomicAdd(&E.locus_len[it.locus], (u64)n);
-                atomicMin(&E.locus_first[it.locus], E.ret_ridx[it.ret]);
-            }
+            c_tot += T; c_ign += I; c_dp += D;
+            E.item_state[ii] = (u8)(state | IS_DONE | (A ? IS_ACC : 0));
+        }
+    }
+    if (tid == 0) {
+        if (c_tot) atomicAdd(&E.ctr->cnt[MLST_CNT_TOTAL_RECORDS], c_tot);
+        if (c_ign) atomicAdd(&E.ctr->cnt[MLST_CNT_IGNORED], c_ign);
+        if (c_dp) atomicAdd(&E.ctr->cnt[MLST_CNT_DP_PAIRS], c_dp);
+    }
+}
+
+// sequenceBank[locus][QNAME] = len(SEQ) (metamlst.py:127) and first-seen order (Q6): one lane per item, items of the
+// same locus inside a wave are combined before touching the per-locus words.
+__global__ __launch_bounds__(256) void k_locus(EngineDev E) {
+    const int lane = threadIdx.x & 63;
+    const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
+    for (u64 i0 = begin + (u64)blockIdx.x * 256; i0 < end; i0 += (u64)gridDim.x * 256) {
+        u64 ii = i0 + threadIdx.x;
+        bool acc = false; u32 locus = 0; u64 n = 0, ridx = ~0ull;
+        if (ii < end && (E.item_state[ii] & IS_ACC)) {
+            ItemDev it = E.items[ii];
+            acc = true; locus = it.locus; n = (u64)(E.ret_len[it.ret] & 0x7FFFu); ridx = E.ret_ridx[it.ret];
+        }
+        u64 todo = __ballot(acc);
+        while (todo) {
+            int src = __ffsll((long long)todo) - 1;
+            u32 L0 = __shfl(locus, src);
+            bool in = acc && locus == L0;
+            u64 grp = __ballot(in); todo &= ~grp;
+            u64 sum = wave_sum_u64(in ? n : 0ull), mn = wave_min_u64(in ? ridx : ~0ull);
+            if (lane == src) { atomicAdd(&E.locus_len[L0], sum); atomicMin(&E.locus_first[L0], mn); }
         }
     }
 }
@@ -561,34 +797,47 @@ __device__ inline void pile_base(const EngineDev& E, const KParams& P, const Ite
 __global__ __launch_bounds__(64) void k_pileup(EngineDev E, KParams P, const int* __restrict__ locus_chosen,
                                                const u64* __restrict__ locus_colbase, u32* __restrict__ counts,
                                                u64* __restrict__ pl_list) {
-    // per-lane staging area in LDS: oriented read words, N bits, penalties
-    __shared__ u32 s_rw[64][RW + 2]; __shared__ u32 s_rn[64][RW / 2 + 1]; __shared__ u8 s_pen[64][RQ];
-    const int tid = threadIdx.x;
+    // one wave per item: the 64 lanes stage the oriented read together, every lane evaluates the (single)
+    // ungapped alignment redundantly, then the aligned columns are piled up 64 at a time
+    __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_q[RQ]; __shared__ u8 s_pentab[128];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 128; i += 64) s_pentab[i] = E.pen_tab[i];
     const u64 end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
-    for (u64 ii = (u64)blockIdx.x * 64 + tid; ii < end; ii += (u64)gridDim.x * 64) {
+    for (u64 ii = blockIdx.x; ii < end; ii += gridDim.x) {
         ItemDev it = E.items[ii];
         int ca = locus_chosen[it.locus];
-        if (ca < 0) continue;
+        if (ca < 0) continue;                                   // block-uniform
         const LocusDev L = E.loci[it.locus];
         u32 a = (u32)ca - L.a_begin;
         u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu);
-        stage_read(E, P, it, n, s_rw[tid], s_rn[tid], s_pen[tid], nullptr, 0, 1);
-        s_rw[tid][RW] = s_rw[tid][RW + 1] = 0;
+        __syncthreads();
+        stage_read(E, P, it, n, s_rw, s_rn, s_pen, s_q, s_pentab, lane, 64);
+        if (lane == 0) { s_rw[RW] = s_rw[RW + 1] = 0; }
+        __syncthreads();
         int m = (int)E.allele_len[ca];
         int mm, bs, be;
-        int best = ungapped(E, P, L, a, m, n, it.diag, s_rw[tid], s_rn[tid], s_pen[tid], (lw & 0x8000u) != 0, mm, bs, be);
+        int best = ungapped(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_pen, (lw & 0x8000u) != 0, mm, bs, be);
         int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF);
         int floor_n = E.floor_tab[n];
-        bool need_dp = P.trig < 0 ? true : (mm > P.trig && score >= floor_n);
-        if (need_dp) { u64 slot = atomicAdd(&E.ctr->n_pl_dp, 1ull); pl_list[slot] = ii; continue; }
+        bool need_dp = gap_trigger(P, mm, score, floor_n, m, n, it.diag, bs, be);
+        if (need_dp) { if (lane == 0) { u64 slot = atomicAdd(&E.ctr->n_pl_dp, 1ull); pl_list[slot] = ii; } continue; }
         if (score < floor_n || score <= 0 || score < P.minscore || xm > P.max_xm) continue;   // BAM_tagFilter AS, XM
-        for (int i = bs; i < be; i++) pile_base(E, P, it, n, i, i + it.diag, counts, locus_colbase[it.locus]);
+        u64 colbase = locus_colbase[it.locus];
+        for (int i = bs + lane; i < be; i += 64) {
+            u8 qb = s_q[i];
+            if ((qb & 0x80) || (int)(qb & 0x7F) < P.minqual) continue;
+            u32 b = (s_rw[i >> 4] >> (2 * (i & 15))) & 3u;
+            atomicAdd(&counts[(colbase + (u64)(i + it.diag)) * 4 + b], 1u);
+        }
     }
 }
 
 __global__ __launch_bounds__(64) void k_pileup_dp(EngineDev E, KParams P, const int* __restrict__ locus_chosen,
                                                   const u64* __restrict__ locus_colbase, u32* __restrict__ counts,
                                                   const u64* __restrict__ pl_list, u8* __restrict__ tb_scratch) {
+    __shared__ u8 s_pentab[128];
+    for (int i = threadIdx.x; i < 128; i += 64) s_pentab[i] = E.pen_tab[i];
+    __syncthreads();
     const u64 end = E.ctr->n_pl_dp;
     const int BWMAX = 2 * MAX_W + 1;
     u8* TB = tb_scratch + ((u64)blockIdx.x * 64 + threadIdx.x) * (u64)(MLST_MAX_READ_LEN * BWMAX);
@@ -599,7 +848,7 @@ __global__ __launch_bounds__(64) void k_pileup_dp(EngineDev E, KParams P, const 
         u32 a = (u32)ca - L.a_begin;
         int n = (int)(E.ret_len[it.ret] & 0x7FFFu);
         int bi, bb;
-        int best = banded<true>(E, P, it, L, a, n, TB, bi, bb);
+        int best = banded<true>(E, P, it, L, a, n, s_pentab, TB, bi, bb);
         int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF);
         if (score < E.floor_tab[n] || score <= 0 || score < P.minscore || xm > P.max_xm) continue;
         const int W = P.band_w, BW = 2 * W + 1;
@@ -689,9 +938,14 @@ struct mlst_handle {
     int* d_locus_chosen = nullptr; u64* d_locus_colbase = nullptr; u64* d_pl_list = nullptr; u8* d_tb = nullptr;
     u32* d_counts = nullptr; u64 cap_counts = 0;
     u32* d_dist = nullptr; u8* d_query = nullptr; u64 cap_dist = 0, cap_query = 0;
+    // one contiguous device block [sum_score | locus_len | Counters | n_hits | pad][locus_first] with a pinned mirror
+    u8* d_stats = nullptr; u8* h_stats = nullptr; u64 stats_bytes = 0, stats_zero_bytes = 0;
+    u64 off_sum = 0, off_len = 0, off_ctr = 0, off_hits = 0, off_first = 0;
+    u8* h_pin = nullptr; u64 cap_pin = 0;          // pinned staging for pileup tables / counts
     // profiling
     bool profiling = false;
     std::vector<EvPair> events;
+    std::vector<hipEvent_t> ev_pool;
     double k_ms[8] = {0}; u64 k_n[8] = {0};
 };
 
@@ -706,17 +960,21 @@ static int fail(mlst_handle* h, int code, const char* fmt, ...) {
 
 template <typename T> static hipError_t dmalloc(T** p, u64 n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
 
+static hipEvent_t ev_get(mlst_handle* h) {
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
 struct Prof {
     mlst_handle* h; int which; hipEvent_t a = nullptr, b = nullptr;
     Prof(mlst_handle* h_, int w) : h(h_), which(w) {
-        if (h->profiling) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, h->stream); }
+        if (h->profiling) { a = ev_get(h); b = ev_get(h); hipEventRecord(a, h->stream); }
     }
     ~Prof() { if (h->profiling) { hipEventRecord(b, h->stream); h->events.push_back({a, b, which}); } }
 };
 static void drain_events(mlst_handle* h) {
     if (h->events.empty()) return;
     hipStreamSynchronize(h->stream);
-    for (auto& e : h->events) { float ms = 0; hipEventElapsedTime(&ms, e.a, e.b); h->k_ms[e.which] += ms; h->k_n[e.which]++; hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& e : h->events) { float ms = 0; hipEventElapsedTime(&ms, e.a, e.b); h->k_ms[e.which] += ms; h->k_n[e.which]++; h->ev_pool.push_back(e.a); h->ev_pool.push_back(e.b); }
     h->events.clear();
 }
 
@@ -726,7 +984,7 @@ extern "C" void mlst_default_params(mlst_params* p) {
     p->minqual = MLST_DEF_MINQUAL; p->mincov = MLST_DEF_MINCOV; p->match_bonus = MLST_DEF_MATCH_BONUS;
     p->mm_max = MLST_DEF_MM_MAX; p->mm_min = MLST_DEF_MM_MIN; p->n_penalty = MLST_DEF_N_PENALTY;
     p->gap_open = MLST_DEF_GAP_OPEN; p->gap_ext = MLST_DEF_GAP_EXT; p->gbar = MLST_DEF_GBAR; p->band_w = MLST_DEF_BAND_W;
-    p->gap_trigger_mm = MLST_DEF_GAP_TRIGGER_MM; p->xm_field_quirk = MLST_DEF_XM_FIELD_QUIRK;
+    p->gap_trigger_mm = MLST_DEF_GAP_TRIGGER_MM; p->xm_field_quirk = MLST_DEF_XM_FIELD_QUIRK; p->gap_trigger_clip = MLST_DEF_GAP_TRIGGER_CLIP;
     p->minscore_const = MLST_DEF_MINSCORE_CONST; p->minscore_coef = MLST_DEF_MINSCORE_COEF;
 }
 
@@ -752,7 +1010,7 @@ extern "C" int mlst_create(int device, const mlst_params* p, mlst_handle** out) 
     k.minscore = prm.minscore; k.max_xm = prm.max_xm; k.min_read_len = prm.min_read_len; k.minqual = prm.minqual;
     k.match_bonus = prm.match_bonus; k.n_penalty = prm.n_penalty;
     k.open_p = ((prm.gap_open + prm.gap_ext) << MLST_P_SHIFT) + (1 << 8); k.ext_p = prm.gap_ext << MLST_P_SHIFT;
-    k.gbar = prm.gbar; k.band_w = prm.band_w; k.trig = prm.gap_trigger_mm; k.quirk = prm.xm_field_quirk;
+    k.gbar = prm.gbar; k.band_w = prm.band_w; k.trig = prm.gap_trigger_mm; k.quirk = prm.xm_field_quirk; k.clip = prm.gap_trigger_clip;
     memset(&h->E, 0, sizeof h->E);
     *out = h;
     return MLST_OK;
@@ -768,12 +1026,12 @@ static void free_ref(mlst_handle* h) {
 }
 static void free_state(mlst_handle* h) {
     EngineDev& E = h->E;
-    hipFree(E.sum_score); hipFree(E.n_hits); hipFree(E.locus_len); hipFree(E.locus_first); hipFree(E.ctr);
+    hipFree(h->d_stats); h->d_stats = nullptr; if (h->h_stats) { hipHostFree(h->h_stats); h->h_stats = nullptr; }
     hipFree(E.ret_bases); hipFree(E.ret_quals); hipFree(E.ret_len); hipFree(E.ret_ridx); hipFree(E.ret_nrec);
-    hipFree(E.items); hipFree(E.res); hipFree(E.dp_list);
+    hipFree(E.items); hipFree(E.item_state); hipFree(E.res); hipFree(E.dp_list);
     hipFree(h->d_locus_chosen); hipFree(h->d_locus_colbase); hipFree(h->d_pl_list); hipFree(h->d_tb);
     E.sum_score = nullptr; E.n_hits = nullptr; E.locus_len = E.locus_first = nullptr; E.ctr = nullptr; E.ret_bases = nullptr; E.ret_quals = nullptr;
-    E.ret_len = nullptr; E.ret_ridx = nullptr; E.ret_nrec = nullptr; E.items = nullptr; E.res = nullptr; E.dp_list = nullptr;
+    E.ret_len = nullptr; E.ret_ridx = nullptr; E.ret_nrec = nullptr; E.items = nullptr; E.item_state = nullptr; E.res = nullptr; E.dp_list = nullptr;
     h->d_locus_chosen = nullptr; h->d_locus_colbase = nullptr; h->d_pl_list = nullptr; h->d_tb = nullptr;
     h->have_state = false;
 }
@@ -783,7 +1041,9 @@ extern "C" void mlst_destroy(mlst_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& e : h->ev_pool) hipEventDestroy(e);
     free_ref(h); free_state(h);
+    if (h->h_pin) hipHostFree(h->h_pin);
     hipFree(h->d_cand); hipFree(h->d_in_bases); hipFree(h->d_in_quals); hipFree(h->d_in_off);
     hipFree(h->d_packed); hipFree(h->d_qrows); hipFree(h->d_lens); hipFree(h->d_counts); hipFree(h->d_dist); hipFree(h->d_query);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -795,12 +1055,8 @@ static inline int base_code(u8 c) {
 }
 
 static int reset_sample_state(mlst_handle* h) {
-    EngineDev& E = h->E;
-    HIPCHK(h, hipMemsetAsync(E.sum_score, 0, sizeof(long long) * (h->n_alleles ? h->n_alleles : 1), h->stream));
-    HIPCHK(h, hipMemsetAsync(E.n_hits, 0, sizeof(u32) * (h->n_alleles ? h->n_alleles : 1), h->stream));
-    HIPCHK(h, hipMemsetAsync(E.locus_len, 0, sizeof(u64) * (h->n_loci ? h->n_loci : 1), h->stream));
-    HIPCHK(h, hipMemsetAsync(E.locus_first, 0xFF, sizeof(u64) * (h->n_loci ? h->n_loci : 1), h->stream));
-    HIPCHK(h, hipMemsetAsync(E.ctr, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, h->stats_zero_bytes, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats + h->off_first, 0xFF, h->stats_bytes - h->off_first, h->stream));
     h->reads_seen = 0;
     return MLST_OK;
 }
@@ -946,12 +1202,25 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     E.sieve = h->d_sieve; E.sieve_mask = smask; E.keys = h->d_keys; E.vals = h->d_vals; E.posts = h->d_posts; E.table_mask = tmask;
     E.floor_tab = h->d_floor; E.pen_tab = h->d_pen; E.n_alleles = n_alleles; E.n_loci = n_loci;
     E.cap_ret = h->prm.max_retained_reads; E.cap_items = h->prm.max_items; E.cap_res = h->prm.max_pair_results; E.cap_dp = h->prm.max_items * 4;
-    HIPCHK(h, dmalloc(&E.sum_score, (u64)n_alleles)); HIPCHK(h, dmalloc(&E.n_hits, (u64)n_alleles));
-    HIPCHK(h, dmalloc(&E.locus_len, (u64)n_loci)); HIPCHK(h, dmalloc(&E.locus_first, (u64)n_loci)); HIPCHK(h, dmalloc(&E.ctr, (u64)1));
+    {   // statistics live in ONE device block so that a sample needs one memset pair and one D2H copy
+        u64 o = 0;
+        h->off_sum = o; o += (u64)n_alleles * 8;
+        h->off_len = o; o += (u64)n_loci * 8;
+        h->off_ctr = o; o += (sizeof(Counters) + 7) & ~7ull;
+        h->off_hits = o; o += ((u64)n_alleles * 4 + 7) & ~7ull;
+        h->stats_zero_bytes = o;
+        h->off_first = o; o += (u64)n_loci * 8;
+        h->stats_bytes = o ? o : 8;
+        HIPCHK(h, dmalloc(&h->d_stats, h->stats_bytes));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_stats, h->stats_bytes, hipHostMallocDefault));
+        E.sum_score = (long long*)(h->d_stats + h->off_sum); E.locus_len = (u64*)(h->d_stats + h->off_len);
+        E.ctr = (Counters*)(h->d_stats + h->off_ctr); E.n_hits = (u32*)(h->d_stats + h->off_hits);
+        E.locus_first = (u64*)(h->d_stats + h->off_first);
+    }
     HIPCHK(h, dmalloc(&E.ret_bases, E.cap_ret * RW)); HIPCHK(h, dmalloc(&E.ret_quals, E.cap_ret * RQ));
     HIPCHK(h, dmalloc(&E.ret_len, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_ridx, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_nrec, E.cap_ret));
-    HIPCHK(h, dmalloc(&E.items, E.cap_items)); HIPCHK(h, dmalloc(&E.res, E.cap_res)); HIPCHK(h, dmalloc(&E.dp_list, E.cap_dp));
-    HIPCHK(h, dmalloc(&h->d_locus_chosen, (u64)n_loci)); HIPCHK(h, dmalloc(&h->d_locus_colbase, (u64)n_loci));
+    HIPCHK(h, dmalloc(&E.items, E.cap_items)); HIPCHK(h, dmalloc(&E.item_state, E.cap_items)); HIPCHK(h, dmalloc(&E.res, E.cap_res)); HIPCHK(h, dmalloc(&E.dp_list, E.cap_dp));
+    HIPCHK(h, dmalloc(&h->d_locus_colbase, (u64)n_loci * 2 + 2));   // [colbase u64 x L][chosen int x L]
     HIPCHK(h, dmalloc(&h->d_pl_list, E.cap_items));
     HIPCHK(h, dmalloc(&h->d_tb, (u64)64 * 64 * MLST_MAX_READ_LEN * (2 * MAX_W + 1)));
     h->have_ref = h->have_state = true;
@@ -992,7 +1261,8 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);
     if (wpr == 0 || wpr > RW || (wpr & 1)) return fail(h, MLST_E_INVALID, "words_per_read must be even and in 2..%d", RW);
-    if (qstride < 1 || qstride > RQ) return fail(h, MLST_E_INVALID, "qual_stride must be in 1..%d", RQ);
+    if (qstride < 4 || qstride > RQ || (qstride & 3)) return fail(h, MLST_E_INVALID, "qual_stride must be a multiple of 4 in 4..%d", RQ);
+    if (((uintptr_t)d_qrows & 3) != 0) return fail(h, MLST_E_INVALID, "quality rows must be 4-byte aligned");
     if (n_reads >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "a batch holds at most 2^32-1 reads");
     if (((uintptr_t)d_packed & 15) != 0) return fail(h, MLST_E_INVALID, "packed rows must be 16-byte aligned");
     if (n_reads == 0) return MLST_OK;
@@ -1001,13 +1271,18 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     EngineDev& E = h->E;
     { Prof pf(h, 0);
       u64 nblk = (n_reads + 255) / 256;
-      hipLaunchKernelGGL(k_sieve, dim3(grid_for(nblk, 1, 256 * 8)), dim3(256), 256 * wpr * 4, h->stream, d_packed, d_lens, n_reads, wpr,
-                         E.sieve, E.sieve_mask, h->d_cand, E.ctr); }
+      dim3 grid(grid_for(nblk, 1, 256 * 8)), block(256);
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_sieve<W>, grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, h->d_cand, E.ctr); break;
+      switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
+                     SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
+#undef SIEVE_CASE
+    }
     { Prof pf(h, 1);
       hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand); }
-    { Prof pf(h, 2); hipLaunchKernelGGL(k_extend, dim3(2048), dim3(256), 0, h->stream, E, h->kp); }
-    { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(64), 0, h->stream, E, h->kp); }
-    { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(2048), dim3(256), 0, h->stream, E, h->kp); }
+    { Prof pf(h, 2); hipLaunchKernelGGL(k_extend, dim3(1024), dim3(256), 0, h->stream, E, h->kp); }
+    { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, E, h->kp); }
+    { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, E, h->kp);
+      hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, E); }
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, h->stream, E.ctr, n_reads);
     HIPCHK(h, hipGetLastError());
     h->reads_seen += n_reads;
@@ -1059,27 +1334,30 @@ extern "C" int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uin
     return mlst_submit_reads_device(h, h->d_in_bases, h->d_in_quals, (const uint64_t*)h->d_in_off, n_reads, max_len, paired);
 }
 
-static int check_overflow(mlst_handle* h) {
-    Counters c; HIPCHK(h, hipMemcpyAsync(&c, h->E.ctr, sizeof c, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (c.err) return fail(h, MLST_E_CAPACITY, "capacity exceeded (flags 0x%llx: 1=retained reads %llu/%llu, 2=items %llu/%llu, 4=pair results %llu/%llu, 8=banded-SW list); raise mlst_params.max_*",
-                           (unsigned long long)c.err, (unsigned long long)c.n_ret, (unsigned long long)h->E.cap_ret, (unsigned long long)c.n_items, (unsigned long long)h->E.cap_items,
-                           (unsigned long long)c.n_res, (unsigned long long)h->E.cap_res);
+// one D2H copy of the whole statistics block into pinned memory, one synchronisation
+static int fetch_stats(mlst_handle* h, Counters** c_out) {
+    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, h->stats_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    Counters* c = (Counters*)(h->h_stats + h->off_ctr);
+    if (c_out) *c_out = c;
+    if (c->err) return fail(h, MLST_E_CAPACITY, "capacity exceeded (flags 0x%llx: 1=retained reads %llu/%llu, 2=items %llu/%llu, 4=pair results %llu/%llu, 8=banded-SW list); raise mlst_params.max_*",
+                            (unsigned long long)c->err, (unsigned long long)c->n_ret, (unsigned long long)h->E.cap_ret, (unsigned long long)c->n_items, (unsigned long long)h->E.cap_items,
+                            (unsigned long long)c->n_res, (unsigned long long)h->E.cap_res);
     return MLST_OK;
 }
+static int check_overflow(mlst_handle* h) { return fetch_stats(h, nullptr); }
 
 extern "C" int mlst_get_allele_stats(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_len,
                                      uint64_t* locus_first, uint64_t* counters) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);
-    int rc = check_overflow(h); if (rc) return rc;
-    EngineDev& E = h->E;
-    if (sum_score) HIPCHK(h, hipMemcpyAsync(sum_score, E.sum_score, (u64)h->n_alleles * 8, hipMemcpyDeviceToHost, h->stream));
-    if (n_hits) HIPCHK(h, hipMemcpyAsync(n_hits, E.n_hits, (u64)h->n_alleles * 4, hipMemcpyDeviceToHost, h->stream));
-    if (locus_len) HIPCHK(h, hipMemcpyAsync(locus_len, E.locus_len, (u64)h->n_loci * 8, hipMemcpyDeviceToHost, h->stream));
-    if (locus_first) HIPCHK(h, hipMemcpyAsync(locus_first, E.locus_first, (u64)h->n_loci * 8, hipMemcpyDeviceToHost, h->stream));
-    Counters c; HIPCHK(h, hipMemcpyAsync(&c, E.ctr, sizeof c, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (counters) { for (int i = 0; i < MLST_CNT_N; i++) counters[i] = c.cnt[i]; counters[MLST_CNT_RETAINED] = c.n_ret; counters[MLST_CNT_ITEMS] = c.n_items; }
+    Counters* c = nullptr;
+    int rc = fetch_stats(h, &c); if (rc) return rc;
+    if (sum_score) memcpy(sum_score, h->h_stats + h->off_sum, (u64)h->n_alleles * 8);
+    if (n_hits) memcpy(n_hits, h->h_stats + h->off_hits, (u64)h->n_alleles * 4);
+    if (locus_len) memcpy(locus_len, h->h_stats + h->off_len, (u64)h->n_loci * 8);
+    if (locus_first) memcpy(locus_first, h->h_stats + h->off_first, (u64)h->n_loci * 8);
+    if (counters) { for (int i = 0; i < MLST_CNT_N; i++) counters[i] = c->cnt[i]; counters[MLST_CNT_RETAINED] = c->n_ret; counters[MLST_CNT_ITEMS] = c->n_items; }
     return MLST_OK;
 }
 
@@ -1105,25 +1383,45 @@ extern "C" int mlst_import_stats_device(mlst_handle* h, const int64_t* d_sum, co
     return MLST_OK;
 }
 
-extern "C" int mlst_pileup_device(mlst_handle* h, const uint32_t* chosen, uint32_t n, uint32_t* d_counts, uint64_t* n_cols_out) {
-    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
-    hipSetDevice(h->device);
-    std::vector<int> lc(h->n_loci, -1); std::vector<u64> cb(h->n_loci, 0); u64 ncols = 0;
+static int ensure_pin(mlst_handle* h, u64 bytes) {
+    if (h->cap_pin >= bytes) return MLST_OK;
+    hipStreamSynchronize(h->stream);
+    if (h->h_pin) hipHostFree(h->h_pin);
+    h->h_pin = nullptr; h->cap_pin = 0;
+    HIPCHK(h, hipHostMalloc((void**)&h->h_pin, bytes, hipHostMallocDefault));
+    h->cap_pin = bytes;
+    return MLST_OK;
+}
+
+// launches pass 2; tables go through pinned memory (laid out [colbase u64 x L][chosen int x L]); no sync here
+static int pileup_launch(mlst_handle* h, const uint32_t* chosen, uint32_t n, uint32_t* d_counts, u64 counts_tail_bytes, uint64_t* n_cols_out) {
+    const u64 nl = h->n_loci, tab_bytes = nl * 12;
+    int rc = ensure_pin(h, tab_bytes + counts_tail_bytes + 128); if (rc) return rc;
+    u64* cb = (u64*)h->h_pin; int* lc = (int*)(h->h_pin + nl * 8);
+    for (u64 l = 0; l < nl; l++) { lc[l] = -1; cb[l] = 0; }
+    u64 ncols = 0;
     for (u32 k = 0; k < n; k++) {
         u32 a = chosen[k]; if (a >= h->n_alleles) return fail(h, MLST_E_INVALID, "chosen allele %u out of range", a);
         u32 L = h->allele_locus[a]; if (lc[L] >= 0) return fail(h, MLST_E_INVALID, "two chosen alleles for locus %u", L);
         lc[L] = (int)a; cb[L] = ncols; ncols += h->aoff[a + 1] - h->aoff[a];
     }
     if (n_cols_out) *n_cols_out = ncols;
-    HIPCHK(h, hipMemcpyAsync(h->d_locus_chosen, lc.data(), (u64)h->n_loci * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_locus_colbase, cb.data(), (u64)h->n_loci * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_locus_colbase, h->h_pin, tab_bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(d_counts, 0, (ncols ? ncols : 1) * 16, h->stream));
     HIPCHK(h, hipMemsetAsync(&h->E.ctr->n_pl_dp, 0, 8, h->stream));
+    const int* d_lc = (const int*)((u8*)h->d_locus_colbase + nl * 8);
     { Prof pf(h, 5);
-      hipLaunchKernelGGL(k_pileup, dim3(1024), dim3(64), 0, h->stream, h->E, h->kp, h->d_locus_chosen, h->d_locus_colbase, d_counts, h->d_pl_list);
-      hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->E, h->kp, h->d_locus_chosen, h->d_locus_colbase, d_counts, h->d_pl_list, h->d_tb); }
+      hipLaunchKernelGGL(k_pileup, dim3(4096), dim3(64), 0, h->stream, h->E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list);
+      hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list, h->d_tb); }
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // lc / cb are stack-owned host buffers
+    return MLST_OK;
+}
+
+extern "C" int mlst_pileup_device(mlst_handle* h, const uint32_t* chosen, uint32_t n, uint32_t* d_counts, uint64_t* n_cols_out) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    hipSetDevice(h->device);
+    int rc = pileup_launch(h, chosen, n, d_counts, 0, n_cols_out); if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return MLST_OK;
 }
 
@@ -1133,8 +1431,11 @@ extern "C" int mlst_pileup(mlst_handle* h, const uint32_t* chosen, uint32_t n, u
     u64 ncols = 0;
     for (u32 k = 0; k < n; k++) { if (chosen[k] >= h->n_alleles) return fail(h, MLST_E_INVALID, "chosen allele out of range"); ncols += h->aoff[chosen[k] + 1] - h->aoff[chosen[k]]; }
     if (h->cap_counts < ncols * 4 + 4) { hipStreamSynchronize(h->stream); hipFree(h->d_counts); h->d_counts = nullptr; HIPCHK(h, dmalloc(&h->d_counts, ncols * 4 + 4)); h->cap_counts = ncols * 4 + 4; }
-    uint64_t nc2 = 0; int rc = mlst_pileup_device(h, chosen, n, h->d_counts, &nc2); if (rc) return rc;
-    if (ncols) HIPCHK(h, hipMemcpy(counts, h->d_counts, ncols * 16, hipMemcpyDeviceToHost));
+    uint64_t nc2 = 0; int rc = pileup_launch(h, chosen, n, h->d_counts, ncols * 16, &nc2); if (rc) return rc;
+    u8* stage = h->h_pin + (u64)h->n_loci * 12 + 16; stage = (u8*)(((uintptr_t)stage + 15) & ~(uintptr_t)15);
+    if (ncols) HIPCHK(h, hipMemcpyAsync(stage, h->d_counts, ncols * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ncols) memcpy(counts, stage, ncols * 16);
     return MLST_OK;
 }
 

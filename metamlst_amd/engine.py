@@ -29,7 +29,7 @@ class MlstParams(C.Structure):
                 ("mm_max", C.c_int32), ("mm_min", C.c_int32), ("n_penalty", C.c_int32),
                 ("gap_open", C.c_int32), ("gap_ext", C.c_int32), ("gbar", C.c_int32),
                 ("band_w", C.c_int32), ("gap_trigger_mm", C.c_int32), ("xm_field_quirk", C.c_int32),
-                ("reserved0", C.c_int32), ("minscore_const", C.c_double), ("minscore_coef", C.c_double),
+                ("gap_trigger_clip", C.c_int32), ("minscore_const", C.c_double), ("minscore_coef", C.c_double),
                 ("max_retained_reads", C.c_uint64), ("max_items", C.c_uint64), ("max_pair_results", C.c_uint64)]
 
 
@@ -45,7 +45,7 @@ def default_params() -> MlstParams:
     p.minscore, p.max_xm, p.min_read_len, p.minqual, p.mincov = 80, 5, 50, 20, 1
     p.match_bonus, p.mm_max, p.mm_min, p.n_penalty = 2, 6, 2, 1
     p.gap_open, p.gap_ext, p.gbar, p.band_w = 5, 3, 4, 8
-    p.gap_trigger_mm, p.xm_field_quirk = 12, 1
+    p.gap_trigger_mm, p.xm_field_quirk, p.gap_trigger_clip = 12, 1, 8
     p.minscore_const, p.minscore_coef = 20.0, 8.0
     p.max_retained_reads = p.max_items = p.max_pair_results = 0
     return p

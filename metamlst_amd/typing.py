@@ -98,30 +98,29 @@ def pick_alleles_fast(index: AlleleIndex, st: SampleStats, penalty: int) -> dict
     """Same decision as compile_cel + pick_alleles for every locus at once: {locus: allele idx}.
     Exactness: Python's round(x, 1) is correctly rounded and monotone, so the winning rounded
     average is round(max x); only alleles with x within 0.11 of the maximum can tie with it, and
-    those few are rounded with Python's own round()."""
-    chosen = {}
-    nh_all = st.n_hits.astype(np.int64)
-    for l in range(index.n_loci):
-        if st.locus_first[l] == NO_READ:
-            continue
-        b, c = int(index.locus_begin[l]), int(index.locus_count[l])
-        nh = nh_all[b:b + c]
-        hit = np.nonzero(nh)[0]
-        if hit.size == 0:
-            continue
-        nhh = nh[hit]
-        local = st.sum_score[b:b + c][hit] - (nhh.max() - nhh) * penalty
-        x = local.astype(np.float64) / nhh.astype(np.float64)
-        near = np.nonzero(x >= x.max() - 0.11)[0]
-        best, best_no, best_a = None, None, None
-        for t in near:
-            r = round(float(int(local[t])) / float(int(nhh[t])), 1)
-            a = b + int(hit[t])
-            no = int(index.allele_no[a])
-            if best is None or r > best or (r == best and no < best_no):
-                best, best_no, best_a = r, no, a
-        chosen[l] = best_a
-    return chosen
+    those few are rounded with Python's own round().  Array operations run over all loci together
+    (alleles of a locus are contiguous in the index)."""
+    nh = st.n_hits.astype(np.int64)
+    if nh.size == 0:
+        return {}
+    begins = index.locus_begin
+    lid = index.locus_id
+    maxlen = np.maximum.reduceat(nh, begins)                       # per locus: max hits over its alleles
+    local = st.sum_score - (maxlen[lid] - nh) * penalty            # metamlst.py:146-147
+    hit = nh > 0
+    x = np.full(nh.shape, -np.inf)
+    np.divide(local, nh, out=x, where=hit)
+    xmax = np.maximum.reduceat(x, begins)
+    near = np.nonzero(hit & (x >= xmax[lid] - 0.11) & (st.locus_first[lid] != NO_READ))[0]
+    best: dict = {}
+    for a in near.tolist():
+        r = round(float(int(local[a])) / float(int(nh[a])), 1)
+        l = int(lid[a])
+        no = int(index.allele_no[a])
+        cur = best.get(l)
+        if cur is None or r > cur[0] or (r == cur[0] and no < cur[1]):
+            best[l] = (r, no, a)
+    return {l: v[2] for l, v in best.items()}
 
 
 def _consensus_bytes(counts: np.ndarray, mincov: int = 1, none_char: str = "N") -> np.ndarray:
@@ -142,21 +141,25 @@ def build_consensus(chromosomeList: dict, counts_by_label: dict, mincov: int = 1
     """buildConsensus (metaMLST_functions.py:249-281) with the cmseq call replaced by the
     engine's pileup counts.  Gap-fill (:265-273): 'N' -> lower-cased database base (CI += 1); a
     consensus base differing from the database base counts as a SNP (Q11).  The per-position loop
-    of the reference is done with array operations; build_consensus_loop below is the literal
-    restatement the tests compare it with."""
-    seqRec = []
-    for chromo, nucleots in chromosomeList.items():
-        cons = _consensus_bytes(counts_by_label[chromo], mincov)
-        dbarr = np.frombuffer(chromosomeList[chromo].encode("latin-1"), dtype=np.uint8)
-        if len(dbarr) != len(cons):
-            return build_consensus_loop(chromosomeList, counts_by_label, mincov)
-        isN = cons == ord("N")
-        upper = (dbarr >= 65) & (dbarr <= 90)
-        out = np.where(isN, np.where(upper, dbarr + 32, dbarr), cons).astype(np.uint8)
-        cIndex = int(isN.sum())
-        SNPs = int(((cons != dbarr) & ~isN).sum())
-        seqRec.append(SeqRecordLite(out.tobytes().decode("latin-1"), chromo, "CI::" + str(cIndex) + "_SP::" + str(SNPs)))
-    return seqRec
+    of the reference is done with array operations over all contigs at once;
+    build_consensus_loop below is the literal restatement the tests compare it with."""
+    labels = list(chromosomeList)
+    if not labels:
+        return []
+    lens = [len(chromosomeList[l]) for l in labels]
+    if any(counts_by_label[l].shape[0] != n for l, n in zip(labels, lens)) or min(lens) == 0:
+        return build_consensus_loop(chromosomeList, counts_by_label, mincov)
+    counts = counts_by_label[labels[0]] if len(labels) == 1 else np.concatenate([counts_by_label[l] for l in labels])
+    dbarr = np.frombuffer("".join(chromosomeList[l] for l in labels).encode("latin-1"), dtype=np.uint8)
+    cons = _consensus_bytes(counts, mincov)
+    isN = cons == ord("N")
+    upper = (dbarr >= 65) & (dbarr <= 90)
+    out = np.where(isN, np.where(upper, dbarr + 32, dbarr), cons).astype(np.uint8).tobytes().decode("latin-1")
+    offs = np.concatenate(([0], np.cumsum(lens)))
+    cI = np.add.reduceat(isN.astype(np.int64), offs[:-1])
+    sn = np.add.reduceat(((cons != dbarr) & ~isN).astype(np.int64), offs[:-1])
+    return [SeqRecordLite(out[int(offs[k]):int(offs[k + 1])], l, "CI::" + str(int(cI[k])) + "_SP::" + str(int(sn[k])))
+            for k, l in enumerate(labels)]
 
 
 def build_consensus_loop(chromosomeList: dict, counts_by_label: dict, mincov: int = 1) -> list[SeqRecordLite]:
@@ -208,8 +211,8 @@ def sample_name(path: str) -> str:
 def _detected_loci(index: AlleleIndex, st: SampleStats) -> dict:
     """{species: {gene: None}} in the same first-appearance order as compile_cel, without the
     per-allele tuples (fast path)."""
-    loci_hit = [l for l in range(index.n_loci) if st.locus_first[l] != NO_READ]
-    loci_hit.sort(key=lambda l: (int(st.locus_first[l]), l))
+    hit = np.nonzero(st.locus_first != NO_READ)[0]
+    loci_hit = hit[np.lexsort((hit, st.locus_first[hit]))].tolist()
     out: dict = {}
     for l in loci_hit:
         sp, gene = index.loci[l]

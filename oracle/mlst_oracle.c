@@ -274,7 +274,10 @@ static void align_pair(const orc_ref* r, const uint8_t* rb, const uint8_t* pen, 
     const uint8_t* ab = r->code[allele]; int m = (int)r->len[allele];
     align_ungapped(r, rb, pen, n, ab, m, d, o);
     int trig = r->prm.gap_trigger_mm;
-    int run_dp = trig < 0 ? 1 : (o->mm_total > trig && o->score >= r->floor_tab[n]);
+    int i0 = d < 0 ? -d : 0, i1 = (m - d) < n ? (m - d) : n;
+    int overlap = i1 > i0 ? i1 - i0 : 0;
+    int run_dp = trig < 0 ? 1 : (o->mm_total > trig && o->score >= r->floor_tab[n] &&
+                                 overlap - o->n_cols >= r->prm.gap_trigger_clip);
     if (run_dp) { int mm = o->mm_total; align_banded(r, rb, pen, n, ab, m, d, o); o->mm_total = mm; }
 }
 
