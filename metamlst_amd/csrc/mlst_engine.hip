@@ -106,6 +106,20 @@ struct EngineDev {
     u64 cap_ret, cap_items, cap_res, cap_dp;
 };
 
+// Batched loads.  hipcc sinks a plain load to its first use, which turns N independent probes into N dependent
+// round trips.  An empty asm statement that takes the loaded values as in/out operands is a use the optimiser
+// cannot move or split: every load of the batch has to be issued before it, and the compiler itself places the
+// (correct, spill-safe) s_waitcnt.  Inline-asm *loads* are not used: their results may be spilled before they land.
+#define TIE1(a)             asm volatile("" : "+v"(a))
+#define TIE4(a, b, c, d)    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define TIE7(a, b, c, d, e, f, g) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g))
+template <int N, typename T> __device__ inline void tie_all(T (&v)[N]) {
+    #pragma unroll
+    for (int i = 0; i + 4 <= N; i += 4) TIE4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    #pragma unroll
+    for (int i = N - (N % 4); i < N; i++) TIE1(v[i]);
+}
+
 // ------------------------------------------------------------------ K0: pack
 // One thread packs 16 bases (one 32-bit word) and their 16 Phred bytes.  lens[r] bit 15 = read has a non-ACGT base.
 __global__ __launch_bounds__(256) void k_pack(const u8* __restrict__ bases, const u8* __restrict__ quals,
@@ -193,19 +207,15 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             u32 w[WPR];
             #pragma unroll
             for (int t2 = 0; t2 < WPR / 2; t2++) { uint2 x = row[t2]; w[2 * t2] = x.x; w[2 * t2 + 1] = x.y; }
-            // Issue every probe before examining any.  hipcc sinks plain loads to their uses (one dependent
-            // round trip per seed), so the loads are inline asm and one explicit wait covers them all; the
-            // empty asm statements tie each result register to that wait.
+            // issue every probe before examining any (see tie_all)
             v4u bv[NT];
             #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const uint4* ptr = sieve + (sieve_bucket_hash(w[t], w[t + 1] & 0xFFu) & smask);
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[t]) : "v"(ptr) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int t = 0; t < NT; t++)
+                bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(w[t], w[t + 1] & 0xFFu) & smask];
+            tie_all<NT>(bv);
             uint4 b[NT];
             #pragma unroll
-            for (int t = 0; t < NT; t++) { asm volatile("" : "+v"(bv[t])); b[t] = make_uint4(bv[t].x, bv[t].y, bv[t].z, bv[t].w); }
+            for (int t = 0; t < NT; t++) b[t] = make_uint4(bv[t].x, bv[t].y, bv[t].z, bv[t].w);
             u32 pending = 0;          // seeds whose first bucket was full without a match (rare)
             #pragma unroll
             for (int t = 0; t < NT; t++) {
@@ -250,11 +260,6 @@ __device__ inline u32 wave_excl_scan_u32(u32 v, u32& total) {      // exclusive 
 __device__ inline u64 wave_sum_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 __device__ inline u64 wave_min_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) { u64 w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
 __device__ inline u32 wave_sum_u32(u32 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-// Loads the compiler cannot sink to their uses: issue a batch, wait once (cdna_hip_programming.md 5.7).
-__device__ inline u32 ld_async_u32(const u32* p) { u32 r; asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory"); return r; }
-__device__ inline void ld_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#define LD_TIE(x) asm volatile("" : "+v"(x))
-
 // ------------------------------------------------------------------ K2: exact seeds -> work items
 struct Bin { u32 locus; int diag; u16 strand, votes; };
 
@@ -270,9 +275,10 @@ __device__ inline bool table_find(const EngineDev& E, u32 lo, u32 hi, u32& val) 
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_seed(EngineDev E, const u32* __restrict__ packed, const u8* __restrict__ qrows,
+__global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, const u32* __restrict__ packed, const u8* __restrict__ qrows,
                                                const u16* __restrict__ lens, u32 wpr, u32 qstride, u64 read_base,
                                                const u32* __restrict__ cand) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     __shared__ Bin s_bins[256][MLST_MAX_CAND];
     __shared__ Bin s_items[256][MLST_MAX_CAND];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -374,22 +380,25 @@ __device__ inline u32 src_base(const u32* rb, int s) { return (rb[s >> 4] >> (2 
 // penalty (bowtie2 --mp 6,2 quality-aware; --np 1 for N).  Cooperative: nthreads is a multiple of 64, every thread
 // owns read positions tid, tid+nthreads, ...; words are assembled with lane OR-reductions.
 __device__ inline void stage_read(const EngineDev& E, const KParams& P, const ItemDev& it, int n,
-                                  u32* s_rw, u32* s_rn, u8* s_pen, u8* s_q, const u8* s_pentab, int tid, int nthreads) {
+                                  u32* s_rw, u32* s_rn, u32* s_odd, u8* s_pen, u8* s_q, const u8* s_pentab, int tid, int nthreads) {
+    const u8 pen_def = s_pentab[40];     // s_odd marks the positions whose penalty is not the Phred-40 one
     const u32* rb = E.ret_bases + (u64)it.ret * RW;
     const u8* rq = E.ret_quals + (u64)it.ret * RQ;
     for (int i0 = 0; i0 < RQ; i0 += nthreads) {
-        int i = i0 + tid; u32 v = 0, nb = 0;
+        int i = i0 + tid; u32 v = 0, nb = 0, ob = 0;
         if (i < n) {
             int s = it.strand ? n - 1 - i : i; u8 qb = rq[s];
             u32 b = src_base(rb, s); if (it.strand) b ^= 3u;
             u32 isn = qb >> 7;
-            s_pen[i] = isn ? (u8)P.n_penalty : s_pentab[qb & 0x7F];
+            u8 pen = isn ? (u8)P.n_penalty : s_pentab[qb & 0x7F];
+            s_pen[i] = pen;
             if (s_q) s_q[i] = qb;
-            v = b << (2 * (i & 15)); nb = isn << (i & 31);
+            v = b << (2 * (i & 15)); nb = isn << (i & 31); ob = (u32)(pen != pen_def) << (i & 31);
         }
         v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 8);
         nb |= __shfl_xor(nb, 1); nb |= __shfl_xor(nb, 2); nb |= __shfl_xor(nb, 4); nb |= __shfl_xor(nb, 8); nb |= __shfl_xor(nb, 16);
-        if (i < RQ) { if ((i & 15) == 0) s_rw[i >> 4] = v; if ((i & 31) == 0) s_rn[i >> 5] = nb; }
+        ob |= __shfl_xor(ob, 1); ob |= __shfl_xor(ob, 2); ob |= __shfl_xor(ob, 4); ob |= __shfl_xor(ob, 8); ob |= __shfl_xor(ob, 16);
+        if (i < RQ) { if ((i & 15) == 0) s_rw[i >> 4] = v; if ((i & 31) == 0) { s_rn[i >> 5] = nb; s_odd[i >> 5] = ob; } }
     }
 }
 
@@ -401,6 +410,11 @@ __device__ inline u32 nmask_word(const EngineDev& E, const LocusDev& L, int q, u
 }
 __device__ inline bool allele_is_n(const EngineDev& E, const LocusDev& L, int j, u32 a_local) {
     return L.has_n && ((nmask_word(E, L, j >> 5, a_local) >> (j & 31)) & 1u);
+}
+// gather the even bits of x into the low 16 bits
+__device__ inline u32 compress16(u32 x) {
+    x &= 0x55555555u; x = (x | (x >> 1)) & 0x33333333u; x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu; x = (x | (x >> 8)) & 0xFFFFu; return x;
 }
 // spread the low 16 bits of x to the even bit positions
 __device__ inline u32 spread16(u32 x) {
@@ -414,7 +428,7 @@ __device__ inline u32 spread16(u32 x) {
 // The allele window (one dword per 16 bases, coalesced across lanes = alleles) is fetched as one batch of
 // independent loads before the serial Kadane pass.
 __device__ inline int ungapped(const EngineDev& E, const KParams& P, const LocusDev& L, u32 a_local, int m, int n, int d,
-                               const u32* s_rw, const u32* s_rn, const u8* s_pen, bool read_has_n,
+                               const u32* s_rw, const u32* s_rn, const u32* s_odd, const u8* s_pen, int pen_def, bool read_has_n,
                                int& mm_total, int& bs, int& be) {
     int i0 = d < 0 ? -d : 0, i1 = (m - d) < n ? (m - d) : n;
     mm_total = 0; bs = be = i0;
@@ -422,55 +436,71 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
     const int MA = P.match_bonus << MLST_P_SHIFT;
     const int nw = (n + 15) >> 4;                  // read words in use (block-uniform)
     const int q0 = d >> 4, r2 = (d & 15) * 2;      // allele word of read position 0 (floor), bit shift
-    const u32* abase = E.arena + L.arena_off + a_local;
+    const u32* abase = E.arena + L.arena_off;      // uniform base of the locus; lanes differ only in a_local
     u32 Aw[RW + 1];
     #pragma unroll
     for (int t = 0; t <= RW; t++) {
         Aw[t] = 0;
         if (t <= nw) {                             // uniform guard
             int q = q0 + t; int qc = q < 0 ? 0 : (q >= (int)L.words ? (int)L.words - 1 : q);
-            Aw[t] = ld_async_u32(abase + (u64)qc * L.n_pad);
+            Aw[t] = abase[(u32)qc * L.n_pad + a_local];
         }
     }
-    ld_wait_all();
+    // Words outside the allele only ever meet read positions outside [i0, i1), which the valid mask removes,
+    // so clamped (out-of-range) words need no zeroing.  Issue the whole window before using any of it:
+    TIE7(Aw[0], Aw[1], Aw[2], Aw[3], Aw[4], Aw[5], Aw[6]);
+    TIE7(Aw[7], Aw[8], Aw[9], Aw[10], Aw[11], Aw[12], Aw[13]);
+    TIE7(Aw[14], Aw[15], Aw[16], Aw[17], Aw[18], Aw[19], Aw[20]);
+    // mismatch bits, one per read base, 32 bases per mask
+    u32 M[RW / 2], AN[RW / 2];
     #pragma unroll
-    for (int t = 0; t <= RW; t++) { LD_TIE(Aw[t]); int q = q0 + t; if (t > nw || q < 0 || q >= (int)L.words) Aw[t] = 0; }
-    int cur = P0, best = P0, cs = i0, last = i0;
+    for (int w = 0; w < RW / 2; w++) {
+        M[w] = 0; AN[w] = 0;
+        if (w * 2 < nw) {                          // uniform guard
+            u32 x0 = s_rw[2 * w] ^ __builtin_amdgcn_alignbit(Aw[2 * w + 1], Aw[2 * w], r2);        // allele bases aligned to the read word
+            u32 x1 = s_rw[2 * w + 1] ^ __builtin_amdgcn_alignbit(Aw[2 * w + 2], Aw[2 * w + 1], r2);
+            M[w] = compress16(x0 | (x0 >> 1)) | (compress16(x1 | (x1 >> 1)) << 16);
+            if (read_has_n) M[w] |= s_rn[w];
+            if (L.has_n) {                         // allele N bits for allele bases 32w+d .. 32w+d+31
+                int gg = 32 * w + d; int nq = gg >> 5, nr = gg & 31;
+                AN[w] = __builtin_amdgcn_alignbit(nmask_word(E, L, nq + 1, a_local), nmask_word(E, L, nq, a_local), nr);
+                M[w] |= AN[w];
+            }
+            int lo_i = i0 - 32 * w; lo_i = lo_i < 0 ? 0 : (lo_i > 32 ? 32 : lo_i);
+            int hi_i = i1 - 32 * w; hi_i = hi_i < 0 ? 0 : (hi_i > 32 ? 32 : hi_i);
+            u32 vm = (hi_i >= 32 ? 0xFFFFFFFFu : ((1u << hi_i) - 1u)) & ~(lo_i >= 32 ? 0xFFFFFFFFu : ((1u << lo_i) - 1u));
+            M[w] &= vm;
+            mm_total += __popc(M[w]);
+        }
+    }
+    // Kadane over the mismatch positions.  The penalty is the read's default (Phred 40) except where s_odd / the
+    // allele N mask says otherwise, so the LDS lookup stays out of the dependent chain.
+    int cur = P0, best = P0, cs = i0, last = i0, blen = 0, bend = i0;
+    const int PD = (pen_def << MLST_P_SHIFT) + 1;
     #pragma unroll
-    for (int t = 0; t < RW; t++) {
-        if (t < nw) {
-            int lo = i0 - 16 * t; lo = lo < 0 ? 0 : lo;
-            int hi = i1 - 16 * t; hi = hi > 16 ? 16 : hi;
-            if (hi > lo) {
-                u32 ash = r2 ? ((Aw[t] >> r2) | (Aw[t + 1] << (32 - r2))) : Aw[t];
-                u32 x = s_rw[t] ^ ash;
-                u32 mmw = (x | (x >> 1)) & 0x55555555u;
-                u32 anw = 0;
-                if (read_has_n) mmw |= spread16(s_rn[t >> 1] >> ((t & 1) * 16));
-                if (L.has_n) {   // allele N bits for allele bases g..g+15 (g = 16t + d)
-                    int gg = 16 * t + d; int nq = gg >> 5, nr = gg & 31;
-                    u32 n0 = nmask_word(E, L, nq, a_local), n1 = nmask_word(E, L, nq + 1, a_local);
-                    u32 nb = nr ? ((n0 >> nr) | (n1 << (32 - nr))) : n0;
-                    anw = spread16(nb); mmw |= anw;
-                }
-                u32 vm = (hi >= 16 ? 0xFFFFFFFFu : ((1u << (2 * hi)) - 1u)) & ~((1u << (2 * lo)) - 1u);
-                mmw &= vm;
-                mm_total += __popc(mmw);
-                while (mmw) {
-                    int bit = __ffs(mmw) - 1; mmw &= mmw - 1;
-                    int i = 16 * t + (bit >> 1);
-                    cur += (i - last) * MA;
-                    if (cur > best) { best = cur; bs = cs; be = i; }
-                    int pen = ((anw >> bit) & 1u) ? P.n_penalty : (int)s_pen[i];
-                    cur -= (pen << MLST_P_SHIFT) + 1;
-                    if (cur <= P0) { cur = P0; cs = i + 1; }
-                    last = i + 1;
-                }
+    for (int w = 0; w < RW / 2; w++) {
+        if (w * 2 < nw) {
+            u32 Mw = M[w];
+#ifdef EXP_NO_KADANE
+            Mw = 0;
+#endif
+            const u32 special = s_odd[w] | AN[w];
+            while (Mw) {
+                int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
+                int i = 32 * w + bit;
+                cur += (i - last) * MA;
+                if (cur > best) { best = cur; blen = i - cs; bend = i; }
+                int dec = PD;
+                if ((special >> bit) & 1u) dec = ((((AN[w] >> bit) & 1u) ? P.n_penalty : (int)s_pen[i]) << MLST_P_SHIFT) + 1;
+                cur -= dec;
+                if (cur <= P0) { cur = P0; cs = i + 1; }
+                last = i + 1;
             }
         }
     }
     cur += (i1 - last) * MA;
-    if (cur > best) { best = cur; bs = cs; be = i1; }
+    if (cur > best) { best = cur; blen = i1 - cs; bend = i1; }
+    be = bend; bs = bend - blen;
     return best;
 }
 // the policy deciding whether the banded Smith-Waterman runs for a pair (same expression as oracle align_pair)
@@ -488,8 +518,12 @@ __device__ inline bool accept_rec(const KParams& P, u32 r, int n, bool use_xo) {
     return score >= P.minscore && n >= P.min_read_len && (use_xo ? xo : xm) <= P.max_xm;
 }
 
-__global__ __launch_bounds__(256) void k_extend(EngineDev E, KParams P) {
-    __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
+#ifndef EXT_WAVES
+#define EXT_WAVES 4          // waves per SIMD the register allocator must leave room for (swept on MI355X)
+#endif
+__global__ __launch_bounds__(256, EXT_WAVES) void k_extend(const EngineDev* __restrict__ Ep, KParams P) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
+    __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u32 s_odd[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
     __shared__ u32 s_cnt[4][3];
     const int tid = threadIdx.x;
     if (tid < 128) s_pentab[tid] = E.pen_tab[tid];
@@ -501,7 +535,7 @@ __global__ __launch_bounds__(256) void k_extend(EngineDev E, KParams P) {
         u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu); bool read_has_n = (lw & 0x8000u) != 0;
         u8 state = E.item_state[ii];
         __syncthreads();
-        stage_read(E, P, it, n, s_rw, s_rn, s_pen, nullptr, s_pentab, tid, 256);
+        stage_read(E, P, it, n, s_rw, s_rn, s_odd, s_pen, nullptr, s_pentab, tid, 256);
         if (tid == 0) { s_rw[RW] = s_rw[RW + 1] = 0; }
         __syncthreads();
         if (it.res_off + L.n_pad > E.cap_res) continue;      // flagged by k_seed
@@ -510,7 +544,7 @@ __global__ __launch_bounds__(256) void k_extend(EngineDev E, KParams P) {
         for (u32 a = tid; a < L.n_alleles; a += 256) {
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
-            int best = ungapped(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_pen, read_has_n, mm, bs, be);
+            int best = ungapped(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_odd, s_pen, (int)s_pentab[40], read_has_n, mm, bs, be);
             int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
             bool need_dp = gap_trigger(P, mm, score, floor_n, m, n, it.diag, bs, be);
             u32 r = pack_result(score, xm, xo);
@@ -535,6 +569,7 @@ __global__ __launch_bounds__(256) void k_extend(EngineDev E, KParams P) {
         if (tid == 0 && tot_rec) atomicAdd(&E.ret_nrec[it.ret], tot_rec);   // per-read record count (Q1)
         // Fused accumulation (metamlst.py:101-130) when everything about this read is known here:
         // it has a single work item and no pair is waiting for the banded SW.
+#ifndef EXP_NO_ACC
         if ((state & IS_SINGLE) && tot_dp == 0) {
             bool use_xo = P.quirk && tot_rec == 1;
             u32 acc = 0, ign = 0;
@@ -557,6 +592,7 @@ __global__ __launch_bounds__(256) void k_extend(EngineDev E, KParams P) {
                 E.item_state[ii] = (u8)(state | IS_DONE | (A ? IS_ACC : 0));
             }
         }
+#endif
     }
     if (tid == 0) {
         if (c_tot) atomicAdd(&E.ctr->cnt[MLST_CNT_TOTAL_RECORDS], c_tot);
@@ -632,7 +668,8 @@ __device__ inline int banded(const EngineDev& E, const KParams& P, const ItemDev
 //   prefix-max scan over the lanes (a gap is never opened from a cell that was itself reached through E, because
 //   OPEN > EXT), so every H equals the sequential recurrence of banded<>() / oracle align_banded.
 // Two pairs per wave; XM / XO come out of the packed maximum, no traceback.
-__global__ __launch_bounds__(256) void k_banded(EngineDev E, KParams P) {
+__global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep, KParams P) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     __shared__ u8 s_pentab[128];
     if (threadIdx.x < 128) s_pentab[threadIdx.x] = E.pen_tab[threadIdx.x];
     __syncthreads();
@@ -707,7 +744,8 @@ __global__ __launch_bounds__(256) void k_banded(EngineDev E, KParams P) {
 }
 
 // ------------------------------------------------------------------ K5: accumulate (metamlst.py:101-130)
-__global__ __launch_bounds__(256) void k_accumulate(EngineDev E, KParams P) {
+__global__ __launch_bounds__(256) void k_accumulate(const EngineDev* __restrict__ Ep, KParams P) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     // items k_extend could not finish: reads with several work items, or pairs that went through the banded SW
     __shared__ u32 s_red[4][4];
     const int tid = threadIdx.x;
@@ -754,7 +792,8 @@ __global__ __launch_bounds__(256) void k_accumulate(EngineDev E, KParams P) {
 
 // sequenceBank[locus][QNAME] = len(SEQ) (metamlst.py:127) and first-seen order (Q6): one lane per item, items of the
 // same locus inside a wave are combined before touching the per-locus words.
-__global__ __launch_bounds__(256) void k_locus(EngineDev E) {
+__global__ __launch_bounds__(256) void k_locus(const EngineDev* __restrict__ Ep) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     const int lane = threadIdx.x & 63;
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
     for (u64 i0 = begin + (u64)blockIdx.x * 256; i0 < end; i0 += (u64)gridDim.x * 256) {
@@ -794,12 +833,13 @@ __device__ inline void pile_base(const EngineDev& E, const KParams& P, const Ite
     atomicAdd(&counts[(colbase + (u64)j) * 4 + b], 1u);
 }
 
-__global__ __launch_bounds__(64) void k_pileup(EngineDev E, KParams P, const int* __restrict__ locus_chosen,
+__global__ __launch_bounds__(64) void k_pileup(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen,
                                                const u64* __restrict__ locus_colbase, u32* __restrict__ counts,
                                                u64* __restrict__ pl_list) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     // one wave per item: the 64 lanes stage the oriented read together, every lane evaluates the (single)
     // ungapped alignment redundantly, then the aligned columns are piled up 64 at a time
-    __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_q[RQ]; __shared__ u8 s_pentab[128];
+    __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u32 s_odd[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_q[RQ]; __shared__ u8 s_pentab[128];
     const int lane = threadIdx.x;
     for (int i = lane; i < 128; i += 64) s_pentab[i] = E.pen_tab[i];
     const u64 end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
@@ -811,12 +851,12 @@ __global__ __launch_bounds__(64) void k_pileup(EngineDev E, KParams P, const int
         u32 a = (u32)ca - L.a_begin;
         u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu);
         __syncthreads();
-        stage_read(E, P, it, n, s_rw, s_rn, s_pen, s_q, s_pentab, lane, 64);
+        stage_read(E, P, it, n, s_rw, s_rn, s_odd, s_pen, s_q, s_pentab, lane, 64);
         if (lane == 0) { s_rw[RW] = s_rw[RW + 1] = 0; }
         __syncthreads();
         int m = (int)E.allele_len[ca];
         int mm, bs, be;
-        int best = ungapped(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_pen, (lw & 0x8000u) != 0, mm, bs, be);
+        int best = ungapped(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_odd, s_pen, (int)s_pentab[40], (lw & 0x8000u) != 0, mm, bs, be);
         int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF);
         int floor_n = E.floor_tab[n];
         bool need_dp = gap_trigger(P, mm, score, floor_n, m, n, it.diag, bs, be);
@@ -832,9 +872,10 @@ __global__ __launch_bounds__(64) void k_pileup(EngineDev E, KParams P, const int
     }
 }
 
-__global__ __launch_bounds__(64) void k_pileup_dp(EngineDev E, KParams P, const int* __restrict__ locus_chosen,
+__global__ __launch_bounds__(64) void k_pileup_dp(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen,
                                                   const u64* __restrict__ locus_colbase, u32* __restrict__ counts,
                                                   const u64* __restrict__ pl_list, u8* __restrict__ tb_scratch) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     __shared__ u8 s_pentab[128];
     for (int i = threadIdx.x; i < 128; i += 64) s_pentab[i] = E.pen_tab[i];
     __syncthreads();
@@ -882,7 +923,8 @@ __global__ __launch_bounds__(256) void k_hamming(const u8* __restrict__ ascii, c
 }
 
 // ------------------------------------------------------------------ stats export / import (multi-GPU all-reduce)
-__global__ void k_export(EngineDev E, long long* d_sum, long long* d_min) {
+__global__ void k_export(const EngineDev* __restrict__ Ep, long long* d_sum, long long* d_min) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     u64 nA = E.n_alleles, nL = E.n_loci;
     u64 total = 2 * nA + nL + MLST_CNT_N;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total + nL; i += (u64)gridDim.x * blockDim.x) {
@@ -893,7 +935,8 @@ __global__ void k_export(EngineDev E, long long* d_sum, long long* d_min) {
         else { u64 l = i - total; u64 f = E.locus_first[l]; d_min[l] = f > 0x7FFFFFFFFFFFFFFFull ? 0x7FFFFFFFFFFFFFFFll : (long long)f; }
     }
 }
-__global__ void k_import(EngineDev E, const long long* d_sum, const long long* d_min) {
+__global__ void k_import(const EngineDev* __restrict__ Ep, const long long* d_sum, const long long* d_min) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     u64 nA = E.n_alleles, nL = E.n_loci;
     u64 total = 2 * nA + nL + MLST_CNT_N;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total + nL; i += (u64)gridDim.x * blockDim.x) {
@@ -927,7 +970,7 @@ struct mlst_handle {
     LocusDev* d_loci = nullptr; uint4* d_sieve = nullptr; u64* d_keys = nullptr; u32* d_vals = nullptr; u32* d_posts = nullptr;
     int* d_floor = nullptr; u8* d_pen = nullptr; u8* d_ascii = nullptr; u64* d_aoff = nullptr;
     u64 bytes_arena = 0, bytes_sieve = 0, bytes_table = 0;
-    EngineDev E;
+    EngineDev E; EngineDev* d_E = nullptr;      // host copy and its device-resident twin
     bool have_ref = false, have_state = false;
     // batch scratch
     u32* d_cand = nullptr; u64 cap_cand = 0;
@@ -1026,6 +1069,7 @@ static void free_ref(mlst_handle* h) {
 }
 static void free_state(mlst_handle* h) {
     EngineDev& E = h->E;
+    hipFree(h->d_E); h->d_E = nullptr;
     hipFree(h->d_stats); h->d_stats = nullptr; if (h->h_stats) { hipHostFree(h->h_stats); h->h_stats = nullptr; }
     hipFree(E.ret_bases); hipFree(E.ret_quals); hipFree(E.ret_len); hipFree(E.ret_ridx); hipFree(E.ret_nrec);
     hipFree(E.items); hipFree(E.item_state); hipFree(E.res); hipFree(E.dp_list);
@@ -1094,6 +1138,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     for (auto& L : loci) {
         if (L.n_alleles >= (1u << 20)) return fail(h, MLST_E_LIMIT, "locus with %u alleles exceeds 2^20", L.n_alleles);
         L.n_pad = (L.n_alleles + 63) & ~63u; L.words = (L.max_len + 15) / 16 + 2; L.nwords = (L.max_len + 31) / 32 + 1;
+        if ((u64)L.words * L.n_pad * 4 >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "a locus arena exceeds 4 GB");
         L.arena_off = arena_words; arena_words += (u64)L.words * L.n_pad;
         if (L.has_n) { L.nmask_off = nmask_words; nmask_words += (u64)L.nwords * L.n_pad; }
     }
@@ -1223,6 +1268,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_locus_colbase, (u64)n_loci * 2 + 2));   // [colbase u64 x L][chosen int x L]
     HIPCHK(h, dmalloc(&h->d_pl_list, E.cap_items));
     HIPCHK(h, dmalloc(&h->d_tb, (u64)64 * 64 * MLST_MAX_READ_LEN * (2 * MAX_W + 1)));
+    HIPCHK(h, dmalloc(&h->d_E, (u64)1)); HIPCHK(h, hipMemcpy(h->d_E, &h->E, sizeof(EngineDev), hipMemcpyHostToDevice));
     h->have_ref = h->have_state = true;
     int rc = reset_sample_state(h); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1278,11 +1324,11 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
 #undef SIEVE_CASE
     }
     { Prof pf(h, 1);
-      hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand); }
-    { Prof pf(h, 2); hipLaunchKernelGGL(k_extend, dim3(1024), dim3(256), 0, h->stream, E, h->kp); }
-    { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, E, h->kp); }
-    { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, E, h->kp);
-      hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, E); }
+      hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand); }
+    { Prof pf(h, 2); hipLaunchKernelGGL(k_extend, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
+    { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
+    { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
+      hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, h->d_E); }
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, h->stream, E.ctr, n_reads);
     HIPCHK(h, hipGetLastError());
     h->reads_seen += n_reads;
@@ -1371,14 +1417,14 @@ extern "C" int mlst_export_stats_device(mlst_handle* h, int64_t* d_sum, int64_t*
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);
     int rc = check_overflow(h); if (rc) return rc;
-    hipLaunchKernelGGL(k_export, dim3(256), dim3(256), 0, h->stream, h->E, (long long*)d_sum, (long long*)d_min);
+    hipLaunchKernelGGL(k_export, dim3(256), dim3(256), 0, h->stream, h->d_E, (long long*)d_sum, (long long*)d_min);
     HIPCHK(h, hipGetLastError()); HIPCHK(h, hipStreamSynchronize(h->stream));
     return MLST_OK;
 }
 extern "C" int mlst_import_stats_device(mlst_handle* h, const int64_t* d_sum, const int64_t* d_min) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);
-    hipLaunchKernelGGL(k_import, dim3(256), dim3(256), 0, h->stream, h->E, (const long long*)d_sum, (const long long*)d_min);
+    hipLaunchKernelGGL(k_import, dim3(256), dim3(256), 0, h->stream, h->d_E, (const long long*)d_sum, (const long long*)d_min);
     HIPCHK(h, hipGetLastError()); HIPCHK(h, hipStreamSynchronize(h->stream));
     return MLST_OK;
 }
@@ -1411,8 +1457,8 @@ static int pileup_launch(mlst_handle* h, const uint32_t* chosen, uint32_t n, uin
     HIPCHK(h, hipMemsetAsync(&h->E.ctr->n_pl_dp, 0, 8, h->stream));
     const int* d_lc = (const int*)((u8*)h->d_locus_colbase + nl * 8);
     { Prof pf(h, 5);
-      hipLaunchKernelGGL(k_pileup, dim3(4096), dim3(64), 0, h->stream, h->E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list);
-      hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list, h->d_tb); }
+      hipLaunchKernelGGL(k_pileup, dim3(4096), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list);
+      hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list, h->d_tb); }
     HIPCHK(h, hipGetLastError());
     return MLST_OK;
 }

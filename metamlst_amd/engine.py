@@ -15,7 +15,7 @@ from .index import AlleleIndex
 from .typing import SampleStats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmlst_hip.so")
+LIB_PATH = os.environ.get("MLST_LIB", os.path.join(_HERE, "libmlst_hip.so"))   # MLST_LIB: profiling builds only
 
 MLST_CNT_N = 8
 CNT_TOTAL_RECORDS, CNT_IGNORED, CNT_READS_SEEN, CNT_CANDIDATES, CNT_RETAINED, CNT_ITEMS, CNT_DP_PAIRS = range(7)
