@@ -102,11 +102,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # MLST_BENCH_BACKEND=gloo + MLST_BENCH_ONE_GPU=1 let the whole N>1 path be exercised on a 1-GPU box
+    # (every rank on device 0, collectives through gloo); the real runs use RCCL, one GPU per rank.
+    backend = os.environ.get("MLST_BENCH_BACKEND", "nccl")
+    if os.environ.get("MLST_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -152,6 +160,7 @@ def main():
     def step():
         t_a = time.perf_counter()
         eng.reset_sample()
+        eng.set_read_index_base(rank * args.reads)
         eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), args.reads, wpr, qstride)
         if world > 1:
             allreduce_stats(port, device)
@@ -223,7 +232,8 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "sieve_pmc.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path))      # measured on 10 M reads per launch; scales with the reads streamed
+            traffic = int(pmc["hbm_bytes_per_launch"] * args.reads / 10_000_000)
         except Exception:
             traffic = None
     achieved = args.reads * ALG_BYTES_BASES / (sieve_ms * 1e-3) / 1e9 if sieve_ms > 0 else 0.0

@@ -150,6 +150,10 @@ int mlst_hamming_le(mlst_handle* h, uint32_t locus, const uint8_t* query, uint32
 int mlst_hamming_all(mlst_handle* h, uint32_t locus, const uint8_t* query, uint32_t len,
                      uint32_t* dist);
 
+/* Multi-GPU: index of this rank's first read in the whole sample, so that locus_first_read (the
+ * first-seen order of metamlst.py's dicts, Q6) is global.  Call after mlst_reset_sample / before submitting. */
+int mlst_set_read_index_base(mlst_handle* h, uint64_t base);
+
 /* Forget reads and statistics, keep the reference (next sample). */
 int mlst_reset_sample(mlst_handle* h);
 

@@ -1,0 +1,120 @@
+"""Command-line entry points with the reference's flags.
+
+    python -m metamlst_amd.cli type  SAMPLE.fastq[.gz] [-2 MATES.fastq] -d DB [-o out] [--penalty ...]   (metamlst.py:34-49)
+    python -m metamlst_amd.cli merge FOLDER -d DB [-z 5] [--filter ...] [--meta ...] [--idField ...]       (metamlst-merge.py:35-49)
+
+`type` takes reads instead of a bowtie2 BAM: the alignment happens on the GPU.  Everything it
+writes (<out>/<sample>.nfo, optional --log file) has the reference's format; `merge` writes
+merged/<species>_ST.txt and _report.txt.  --presorted / --debug / --version of the reference have
+no meaning here and are accepted and ignored; --outseqformat and -j/--jgroup are out of scope."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+from . import db as mdb
+from .engine import Engine, default_params
+from .fastq import interleave, read_batches
+from .index import load_index
+from .merge import EngineMatcher, merge_folder
+from .typing import TypingArgs, log_table, sample_name, type_sample
+
+
+def _type_parser(sub):
+    p = sub.add_parser("type", help="reconstruct the MLST loci of one sample from its reads (counterpart of metamlst.py)")
+    p.add_argument("READS", help="FASTQ file (plain or .gz)")
+    p.add_argument("-2", dest="mates", help="second FASTQ of a paired-end sample")
+    p.add_argument("-o", metavar="OUTPUT FOLDER", default="./out")
+    p.add_argument("-d", "--database", metavar="DB PATH", required=True)
+    p.add_argument("--filter", metavar="species1,species2...")
+    p.add_argument("--penalty", default=100, type=int)
+    p.add_argument("--minscore", default=80, type=int)
+    p.add_argument("--max_xM", default=5, type=int)
+    p.add_argument("--min_read_len", default=50, type=int)
+    p.add_argument("--min_accuracy", default=0.90, type=float)
+    p.add_argument("--nloci", default=100, type=int)
+    p.add_argument("--log", action="store_true")
+    p.add_argument("-a", action="store_true", help="Write known sequences")
+    p.add_argument("--quiet", action="store_true")
+    p.add_argument("--debug", action="store_true")
+    p.add_argument("--presorted", action="store_true")
+    p.add_argument("--device", default=0, type=int)
+    return p
+
+
+def _merge_parser(sub):
+    p = sub.add_parser("merge", help="detect the ST of every sample in a folder of .nfo files (counterpart of metamlst-merge.py)")
+    p.add_argument("folder")
+    p.add_argument("-d", "--database", metavar="DB PATH", required=True)
+    p.add_argument("--filter", metavar="species1,species2...")
+    p.add_argument("-z", metavar="ED", default=5, type=int)
+    p.add_argument("--meta", metavar="METADATA_PATH")
+    p.add_argument("--idField", default=0, type=int)
+    p.add_argument("--device", default=0, type=int)
+    return p
+
+
+def run_type(a) -> int:
+    try:
+        database = mdb.metaMLST_db(a.database)
+        idx = load_index(a.database, a.filter.split(",") if a.filter else None)
+    except Exception as e:   # metamlst.py:73-75
+        print("Failed to connect to the database: please check your database file! (%s)" % e)
+        return 1
+    prm = default_params()
+    prm.minscore, prm.max_xm, prm.min_read_len = a.minscore, a.max_xM, a.min_read_len
+    eng = Engine(a.device, prm)
+    eng.load_reference(idx)
+    batches = interleave(a.READS, a.mates) if a.mates else read_batches(a.READS)
+    for bases, quals, off, _ in batches:
+        eng.submit_reads(bases, quals, off, paired=bool(a.mates))
+    st = eng.stats()
+    targs = TypingArgs(penalty=a.penalty, minscore=a.minscore, max_xM=a.max_xM, min_read_len=a.min_read_len,
+                       min_accuracy=a.min_accuracy, nloci=a.nloci, a=a.a, quiet=a.quiet, filter=a.filter, log=a.log)
+    fileName = sample_name(a.READS)
+    if not os.path.isdir(a.o):
+        os.mkdir(a.o)
+    if a.log:   # metamlst.py:159-172
+        with open(a.o + "/" + fileName + "_" + str(int(time.time())) + ".out", "w", newline="") as f:
+            f.write(log_table(idx, st, targs, a.READS))
+    results = type_sample(idx, st, eng.pileup, database, fileName, targs, out_dir=a.o)
+    if not a.quiet:
+        for r in results:
+            print(" %-18s Detected Loci: %s" % (r.species, ", ".join(r.detected)))
+            if r.missing:
+                print(" " * 20 + "Missing Loci : " + ", ".join(r.missing))
+            for g, (avg, hits, alleles, cov) in sorted(r.closest.items()):
+                print("  %-7s%15s%7s%6s  %s" % (g, cov, avg, hits, ",".join(alleles[:5]) + ("... (%d more)" % len(alleles) if len(alleles) > 5 else "")))
+            for l in r.loci_report:
+                print("  %-7s%-7s%7s%7s%7s%15s%10s" % (l["locus"], l["ref"], l["length"], l["ns"], l["snps"], l["confidence"], l["notes"]))
+            print("  -> " + ("Reconstruction Successful [WRITE]" if r.written else
+                             ("Accuracy lower than %s%% [SKIP]" % round(a.min_accuracy * 100, 2) if r.passed_nloci else "not enough loci [SKIP]")))
+    database.closeConnection()
+    return 0
+
+
+def run_merge(a) -> int:
+    database = mdb.metaMLST_db(a.database)
+    idx = load_index(a.database)
+    eng = Engine(a.device)
+    eng.load_reference(idx)
+    tables = merge_folder(a.folder, database, EngineMatcher(eng, idx), z=a.z, filter=a.filter, meta=a.meta, idField=a.idField,
+                          cache=mdb.DbCache(database.conn))
+    for sp, t in tables.items():
+        print("%s: %d sample(s) typed, %d new profile(s)" % (sp, len(t["isolates"]), sum(1 for v in t["encounteredProfiles"].values() if v[2] in (1, 2))))
+    return 0
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="metamlst_amd", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    _type_parser(sub)
+    _merge_parser(sub)
+    a = ap.parse_args(argv)
+    return run_type(a) if a.cmd == "type" else run_merge(a)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

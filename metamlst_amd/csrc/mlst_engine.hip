@@ -1275,6 +1275,12 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     return MLST_OK;
 }
 
+extern "C" int mlst_set_read_index_base(mlst_handle* h, uint64_t base) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    h->reads_seen = base;
+    return MLST_OK;
+}
+
 extern "C" int mlst_reset_sample(mlst_handle* h) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);

@@ -89,6 +89,7 @@ def load_library(path: str | None = None):
         "mlst_hamming_le": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
         "mlst_hamming_all": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, u32p]),
         "mlst_reset_sample": (C.c_int, [H]),
+        "mlst_set_read_index_base": (C.c_int, [H, C.c_uint64]),
         "mlst_get_items": (C.c_int, [H, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
         "mlst_set_profiling": (C.c_int, [H, C.c_int]),
         "mlst_get_kernel_time": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -225,6 +226,9 @@ class Engine:
     # ---- misc ----
     def reset_sample(self):
         self._check(self.lib.mlst_reset_sample(self._h), "mlst_reset_sample")
+
+    def set_read_index_base(self, base: int):
+        self._check(self.lib.mlst_set_read_index_base(self._h, int(base)), "mlst_set_read_index_base")
 
     def items(self, cap: int = 1 << 20) -> np.ndarray:
         buf = (MlstItem * cap)()

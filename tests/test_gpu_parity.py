@@ -161,3 +161,54 @@ def test_hamming_matches_stringdiff():
             assert np.array_equal(eng.hamming_all(locus, q), orc.hamming_all(locus, q))
             assert eng.hamming_le(locus, q, 5) == orc.hamming_le(locus, q, 5)
     assert eng.hamming_le(0, b"", 0)[1] == int(idx.locus_count[0])     # zip with '' -> 0 mismatches
+
+
+def test_sharded_engines_reduce_to_the_single_engine_result():
+    """Multi-GPU data path on one GPU: two engines each see half of the reads (as two ranks would), their
+    statistics are summed / min-reduced through mlst_export_stats_device + mlst_import_stats_device and the
+    pileups through mlst_pileup_device; the result must equal one engine that saw every read."""
+    import torch
+    from metamlst_amd.dist import DeviceStatsPort, shard_range, split_counts
+    db, idx = fx.ecoli_small(80)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 4, n_reads=14001)
+    dev = torch.device("cuda", 0)
+    whole = Engine(0)
+    whole.load_reference(idx)
+    whole.submit_reads(fb, fq, off)
+    s_all = whole.stats()
+    n = len(off) - 1
+    shards, ports = [], []
+    for r in range(2):
+        lo, hi = shard_range(n, r, 2)
+        e = Engine(0)
+        e.load_reference(idx)
+        o = off[lo:hi + 1]
+        e.set_read_index_base(lo)     # first-seen order (Q6) must be global across shards
+        e.submit_reads(fb[int(o[0]):int(o[-1])], fq[int(o[0]):int(o[-1])], o - o[0])
+        shards.append(e)
+        ports.append(DeviceStatsPort(e, dev))
+    n_sum, n_min = ports[0].flat_sizes()
+    sums = [torch.empty(n_sum, dtype=torch.int64, device=dev) for _ in range(2)]
+    mins = [torch.empty(max(1, n_min), dtype=torch.int64, device=dev) for _ in range(2)]
+    for p, ts, tm in zip(ports, sums, mins):
+        p.export_stats(ts, tm)
+    tot, mn = sums[0] + sums[1], torch.minimum(mins[0], mins[1])
+    for p in ports:
+        p.import_stats(tot, mn)
+    for e in shards:
+        s = e.stats()
+        assert np.array_equal(s.sum_score, s_all.sum_score) and np.array_equal(s.n_hits, s_all.n_hits)
+        assert np.array_equal(s.locus_len_sum, s_all.locus_len_sum) and np.array_equal(s.locus_first, s_all.locus_first)
+        assert all(int(s.counters[k]) == int(s_all.counters[k]) for k in (0, 1, 2, 6))
+    chosen = sorted(pick_alleles_fast(idx, shards[0].stats(), 100).values())
+    assert chosen == sorted(pick_alleles_fast(idx, s_all, 100).values())
+    n_cols = sum(int(idx.off[a + 1] - idx.off[a]) for a in chosen)
+    parts = []
+    for p in ports:
+        t = torch.zeros(n_cols * 4, dtype=torch.int32, device=dev)
+        assert p.pileup_into(chosen, t) == n_cols
+        parts.append(t)
+    merged = split_counts(idx, chosen, (parts[0] + parts[1]).cpu().numpy().view(np.uint32).reshape(-1, 4))
+    ref = whole.pileup(chosen)
+    for a in chosen:
+        assert np.array_equal(merged[a], ref[a])
