@@ -63,6 +63,32 @@ __host__ __device__ inline u32 table_hash(u32 lo, u32 hi) {
     return h;
 }
 
+// Canonical seed: the smaller of a 20-mer and its reverse complement (40-bit keys, base t at bits 2t).  One table
+// entry serves both strands, which halves the sieve and the seed table.  flag = 1 when the reverse complement is the
+// canonical form.  A posting stores the flag of the ALLELE k-mer; strand = posting flag XOR read-seed flag.
+__host__ __device__ inline u64 brev64_(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    return (x >> 32) | (x << 32);
+#endif
+}
+__host__ __device__ inline u64 revcomp40(u64 s) {
+    u64 y = brev64_(s);                                                                  // group t -> pair 31-t, bits swapped
+    y = ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);      // restore bit order inside each base
+    return (~(y >> 24)) & 0xFFFFFFFFFFull;                                               // pair 31-t -> 19-t, complement
+}
+__host__ __device__ inline u64 canon40(u64 s, u32& flag) {
+    u64 r = revcomp40(s); flag = r < s ? 1u : 0u; return flag ? r : s;
+}
+#define BITMAP_BITS 20                  // LDS first-level filter: 2^20 bits = 128 KiB
+__host__ __device__ inline u32 bitmap_hash(u32 lo, u32 hi) { return table_hash(lo, hi) >> (32 - BITMAP_BITS); }
+
 // ------------------------------------------------------------------ device-side views
 struct LocusDev {
     u64 arena_off;      // word offset of this locus in the transposed 2-bit arena
@@ -95,6 +121,7 @@ struct EngineDev {
     // reference
     const u32* arena; const u32* nmask; const u16* allele_len; const u32* allele_locus; const LocusDev* loci;
     const uint4* sieve; u32 sieve_mask;
+    const u32* bitmap;        // first-level 2^20-bit filter (nullptr when the database is too large for it to be selective)
     const u64* keys; const u32* vals; const u32* posts; u32 table_mask;
     const int* floor_tab; const u8* pen_tab;
     u32 n_alleles, n_loci;
@@ -207,11 +234,14 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             u32 w[WPR];
             #pragma unroll
             for (int t2 = 0; t2 < WPR / 2; t2++) { uint2 x = row[t2]; w[2 * t2] = x.x; w[2 * t2 + 1] = x.y; }
-            // issue every probe before examining any (see tie_all)
+            // canonical seed keys, then every probe issued before examining any (see tie_all)
+            u32 klo[NT], khi[NT];
+            #pragma unroll
+            for (int t = 0; t < NT; t++) { u32 fl; u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl); klo[t] = (u32)c; khi[t] = (u32)(c >> 32); }
             v4u bv[NT];
             #pragma unroll
             for (int t = 0; t < NT; t++)
-                bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(w[t], w[t + 1] & 0xFFu) & smask];
+                bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) & smask];
             tie_all<NT>(bv);
             uint4 b[NT];
             #pragma unroll
@@ -219,7 +249,7 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             u32 pending = 0;          // seeds whose first bucket was full without a match (rare)
             #pragma unroll
             for (int t = 0; t < NT; t++) {
-                bool full; bool f = bucket_has(b[t], sieve_fp(w[t], w[t + 1] & 0xFFu), full);
+                bool full; bool f = bucket_has(b[t], sieve_fp(klo[t], khi[t]), full);
                 bool valid = t < nseeds;
                 hit |= valid && f;
                 pending |= (valid && !f && full) ? (1u << t) : 0u;
@@ -227,7 +257,8 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             while (pending && !hit) {   // overflow chain: the key may sit in a following bucket
                 int t = __ffs(pending) - 1; pending &= pending - 1;
                 const u32* rw = s_rows + (u32)tid * WPR;
-                u32 lo = rw[t], hi = rw[t + 1] & 0xFFu; u32 fp = sieve_fp(lo, hi);
+                u32 fl; u64 c = canon40((u64)rw[t] | ((u64)(rw[t + 1] & 0xFFu) << 32), fl);
+                u32 lo = (u32)c, hi = (u32)(c >> 32); u32 fp = sieve_fp(lo, hi);
                 u32 bi = sieve_bucket_hash(lo, hi) & smask;
                 for (int step = 0; step < 64; step++) {
                     bi = (bi + 1) & smask; bool full; uint4 bb = sieve[bi];
@@ -246,6 +277,89 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             if (hit) cand[base + __popcll(mask & ((1ull << lane) - 1))] = (u32)(r0 + tid);
         }
         __syncthreads();
+    }
+}
+
+// Sieve with an LDS-resident first level.  One 1024-thread workgroup per CU keeps a 2^20-bit membership bitmap of
+// the canonical seeds in LDS (128 KiB); a seed costs an L2 request only when its bit is set.  Rows are read straight
+// from global memory (lane = read, 8-byte non-temporal loads; the wave's rows are contiguous).  Used when the
+// database is small enough for the bitmap to be selective.
+template <int WPR>
+__global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
+                                                     const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ bitmap,
+                                                     u32* __restrict__ cand, Counters* __restrict__ ctr) {
+    __shared__ __attribute__((aligned(16))) u32 s_bm[(1u << BITMAP_BITS) / 32];
+    constexpr int NT = WPR - 1;
+    const int tid = threadIdx.x;
+    {   // 32768 words, 16-byte vectors
+        const v4u* g4 = reinterpret_cast<const v4u*>(bitmap); v4u* s4 = reinterpret_cast<v4u*>(s_bm);
+        #pragma unroll
+        for (int k = 0; k < 8; k++) s4[tid + 1024 * k] = g4[tid + 1024 * k];
+    }
+    __syncthreads();
+    const u64 n_tiles = (n_reads + 1023) / 1024;
+    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        u64 r = tile * 1024 + tid;
+        bool live = r < n_reads;
+        u32 n = live ? (u32)(lens[r] & 0x7FFFu) : 0u;
+        int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
+        u32 w[WPR];
+        {
+            typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+            const v2u* row = reinterpret_cast<const v2u*>(packed + (live ? r : 0) * WPR);
+            v2u x[WPR / 2];
+            #pragma unroll
+            for (int t2 = 0; t2 < WPR / 2; t2++) x[t2] = __builtin_nontemporal_load(row + t2);
+            #pragma unroll
+            for (int t2 = 0; t2 < WPR / 2; t2++) { w[2 * t2] = x[t2].x; w[2 * t2 + 1] = x[t2].y; }
+        }
+        u32 klo[NT], khi[NT]; u32 pass = 0;
+        #pragma unroll
+        for (int t = 0; t < NT; t++) {
+            u32 fl; u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl); klo[t] = (u32)c; khi[t] = (u32)(c >> 32);
+            u32 bi = bitmap_hash(klo[t], khi[t]);
+            u32 bit = (s_bm[bi >> 5] >> (bi & 31)) & 1u;
+            pass |= (t < nseeds ? bit : 0u) << t;
+        }
+        bool hit = false;
+        if (pass) {      // second level: the fingerprint sieve, only for seeds whose bit is set
+            v4u bv[NT];
+            #pragma unroll
+            for (int t = 0; t < NT; t++) {
+                bv[t] = v4u{0u, 0u, 0u, 0u};
+                if ((pass >> t) & 1u) bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) & smask];
+            }
+            tie_all<NT>(bv);
+            u32 pending = 0;
+            #pragma unroll
+            for (int t = 0; t < NT; t++) {
+                bool full; bool f = bucket_has(make_uint4(bv[t].x, bv[t].y, bv[t].z, bv[t].w), sieve_fp(klo[t], khi[t]), full);
+                bool valid = (pass >> t) & 1u;
+                hit |= valid && f;
+                pending |= (valid && !f && full) ? (1u << t) : 0u;
+            }
+            while (pending && !hit) {   // overflow chain: the key may sit in a following bucket
+                int t = __ffs(pending) - 1; pending &= pending - 1;
+                u32 lo = 0, hi = 0;
+                #pragma unroll
+                for (int u = 0; u < NT; u++) if (u == t) { lo = klo[u]; hi = khi[u]; }
+                u32 fp = sieve_fp(lo, hi); u32 bi = sieve_bucket_hash(lo, hi) & smask;
+                for (int step = 0; step < 64; step++) {
+                    bi = (bi + 1) & smask; bool full; uint4 bb = sieve[bi];
+                    if (bucket_has(bb, fp, full)) { hit = true; break; }
+                    if (!full) break;
+                }
+            }
+        }
+        u64 mask = __ballot(hit);
+        if (mask) {
+            int lane = tid & 63;
+            int leader = __ffsll((long long)mask) - 1;
+            u64 base = 0;
+            if (lane == leader) base = atomicAdd(&ctr->n_cand, (u64)__popcll(mask));
+            base = __shfl(base, leader);
+            if (hit) cand[base + __popcll(mask & ((1ull << lane) - 1))] = (u32)r;
+        }
     }
 }
 
@@ -297,17 +411,28 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             for (int t = 0; t < nseeds; t++) {
                 int o = t * MLST_SEED_STEP;
                 if (has_n) { bool bad = false; for (int k = 0; k < MLST_SEED_LEN; k++) bad |= (qrow[o + k] & 0x80) != 0; if (bad) continue; }
-                u32 lo = row[t], hi = row[t + 1] & 0xFFu, val;
+                u32 sflag; u64 ck = canon40((u64)row[t] | ((u64)(row[t + 1] & 0xFFu) << 32), sflag);
+                u32 lo = (u32)ck, hi = (u32)(ck >> 32), val;
                 if (!table_find(E, lo, hi, val)) continue;
                 u32 pstart, pcount; u32 single = 0;
                 if (val & 0x80000000u) { single = val & 0x7FFFFFFFu; pstart = 0; pcount = 1; }
                 else { pstart = val >> 5; pcount = val & 31u; }
-                for (u32 p = 0; p < pcount; p++) {
-                    u32 post = (val & 0x80000000u) ? single : E.posts[pstart + p];
+                // postings are stored sorted by (locus, flag, pos); visit them in (locus, strand, pos) order with
+                // strand = flag XOR sflag -- the order the non-canonical index of the oracle has
+                u32 last_key = 0; bool first = true;
+                for (u32 k = 0; k < pcount; k++) {
+                    u32 post;
+                    if (val & 0x80000000u) post = single ^ (sflag << 12);
+                    else if (!sflag) post = E.posts[pstart + k];
+                    else {      // k-th smallest of the flag-flipped postings (pcount <= 16)
+                        u32 bestp = 0xFFFFFFFFu;
+                        for (u32 pp = 0; pp < pcount; pp++) { u32 x = E.posts[pstart + pp] ^ (1u << 12); if ((first || x > last_key) && x < bestp) bestp = x; }
+                        post = bestp; last_key = bestp; first = false;
+                    }
                     u32 locus = post >> 13, strand = (post >> 12) & 1; int pos = (int)(post & 0xFFFu);
                     int diag = strand ? pos + MLST_SEED_LEN + o - (int)n : pos - o;
-                    int k; for (k = 0; k < nb; k++) if (bins[k].locus == locus && bins[k].strand == strand && bins[k].diag == diag) break;
-                    if (k < nb) bins[k].votes++;
+                    int kk; for (kk = 0; kk < nb; kk++) if (bins[kk].locus == locus && bins[kk].strand == strand && bins[kk].diag == diag) break;
+                    if (kk < nb) bins[kk].votes++;
                     else if (nb < MLST_MAX_CAND) { bins[nb].locus = locus; bins[nb].strand = (u16)strand; bins[nb].diag = diag; bins[nb].votes = 1; nb++; }
                 }
             }
@@ -967,7 +1092,7 @@ struct mlst_handle {
     std::vector<u32> allele_locus;
     // device memory
     u32* d_arena = nullptr; u32* d_nmask = nullptr; u16* d_allele_len = nullptr; u32* d_allele_locus = nullptr;
-    LocusDev* d_loci = nullptr; uint4* d_sieve = nullptr; u64* d_keys = nullptr; u32* d_vals = nullptr; u32* d_posts = nullptr;
+    LocusDev* d_loci = nullptr; uint4* d_sieve = nullptr; u32* d_bitmap = nullptr; u64* d_keys = nullptr; u32* d_vals = nullptr; u32* d_posts = nullptr;
     int* d_floor = nullptr; u8* d_pen = nullptr; u8* d_ascii = nullptr; u64* d_aoff = nullptr;
     u64 bytes_arena = 0, bytes_sieve = 0, bytes_table = 0;
     EngineDev E; EngineDev* d_E = nullptr;      // host copy and its device-resident twin
@@ -1061,7 +1186,7 @@ extern "C" int mlst_create(int device, const mlst_params* p, mlst_handle** out) 
 
 static void free_ref(mlst_handle* h) {
     hipFree(h->d_arena); hipFree(h->d_nmask); hipFree(h->d_allele_len); hipFree(h->d_allele_locus); hipFree(h->d_loci);
-    hipFree(h->d_sieve); hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
+    hipFree(h->d_sieve); hipFree(h->d_bitmap); h->d_bitmap = nullptr; hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
     hipFree(h->d_ascii); hipFree(h->d_aoff);
     h->d_arena = h->d_nmask = nullptr; h->d_allele_len = nullptr; h->d_allele_locus = nullptr; h->d_loci = nullptr; h->d_sieve = nullptr;
     h->d_keys = nullptr; h->d_vals = h->d_posts = nullptr; h->d_floor = nullptr; h->d_pen = nullptr; h->d_ascii = nullptr; h->d_aoff = nullptr;
@@ -1166,8 +1291,10 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
             rk = ((rk << 2) | (u64)(3 - c)) & mask40;        // rc base t = 3 - code[p+19-t]
             if (i + 1 >= MLST_SEED_LEN && !bad) {
                 u32 p = i + 1 - MLST_SEED_LEN;
-                kp.push_back({fk, (locus_id[a] << 13) | p});
-                kp.push_back({rk, (locus_id[a] << 13) | (1u << 12) | p});
+                // canonical entry: flag = 1 when the reverse complement is the smaller (canonical) form
+                u64 ck = fk < rk ? fk : rk; u32 fl = rk < fk ? 1u : 0u;
+                kp.push_back({ck, (locus_id[a] << 13) | (fl << 12) | p});
+                if (fk == rk) kp.push_back({ck, (locus_id[a] << 13) | (1u << 12) | p});   // palindrome: both strands
             }
         }
     }
@@ -1216,6 +1343,16 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
             b = (b + 1) & smask;
         }
     }
+    // ---- first-level bitmap (LDS resident in k_sieve_lds): only when it is selective
+    std::vector<u32> bitmap;
+    {
+        const u64 nbits = 1ull << BITMAP_BITS;
+        const char* off_sw = getenv("MLST_NO_LDS_SIEVE");   // test / tuning switch: force the plain sieve kernel
+        if (nk * 2 <= nbits && !(off_sw && off_sw[0] == '1')) {       // expected fill <= 1 - exp(-0.5) = 39 %
+            bitmap.assign(nbits / 32, 0);
+            for (u64 i = 0; i < nk; i++) { u32 bi = bitmap_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32)); bitmap[bi >> 5] |= 1u << (bi & 31); }
+        }
+    }
     // ---- tables derived from the parameters
     std::vector<int> floor_tab(MLST_MAX_READ_LEN + 1);
     for (int n = 0; n <= MLST_MAX_READ_LEN; n++) {
@@ -1231,6 +1368,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_allele_locus, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_locus, locus_id, (u64)n_alleles * 4, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_loci, (u64)n_loci)); HIPCHK(h, hipMemcpy(h->d_loci, loci.data(), (u64)n_loci * sizeof(LocusDev), hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_sieve, nb)); HIPCHK(h, hipMemcpy(h->d_sieve, sv.data(), nb * 16, hipMemcpyHostToDevice));
+    if (!bitmap.empty()) { HIPCHK(h, dmalloc(&h->d_bitmap, (u64)bitmap.size())); HIPCHK(h, hipMemcpy(h->d_bitmap, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice)); }
     HIPCHK(h, dmalloc(&h->d_keys, tcap)); HIPCHK(h, hipMemcpy(h->d_keys, tkeys.data(), tcap * 8, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_vals, tcap)); HIPCHK(h, hipMemcpy(h->d_vals, tvals.data(), tcap * 4, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_posts, (u64)posts.size())); if (!posts.empty()) HIPCHK(h, hipMemcpy(h->d_posts, posts.data(), posts.size() * 4, hipMemcpyHostToDevice));
@@ -1239,12 +1377,12 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     u64 abytes = off[n_alleles];
     HIPCHK(h, dmalloc(&h->d_ascii, abytes)); if (abytes) HIPCHK(h, hipMemcpy(h->d_ascii, ascii, abytes, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_aoff, (u64)n_alleles + 1)); HIPCHK(h, hipMemcpy(h->d_aoff, off, ((u64)n_alleles + 1) * 8, hipMemcpyHostToDevice));
-    h->bytes_arena = arena.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16; h->bytes_table = tcap * 12 + posts.size() * 4;
+    h->bytes_arena = arena.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
     h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
     // ---- sample state
     EngineDev& E = h->E;
     E.arena = h->d_arena; E.nmask = h->d_nmask; E.allele_len = h->d_allele_len; E.allele_locus = h->d_allele_locus; E.loci = h->d_loci;
-    E.sieve = h->d_sieve; E.sieve_mask = smask; E.keys = h->d_keys; E.vals = h->d_vals; E.posts = h->d_posts; E.table_mask = tmask;
+    E.sieve = h->d_sieve; E.sieve_mask = smask; E.bitmap = h->d_bitmap; E.keys = h->d_keys; E.vals = h->d_vals; E.posts = h->d_posts; E.table_mask = tmask;
     E.floor_tab = h->d_floor; E.pen_tab = h->d_pen; E.n_alleles = n_alleles; E.n_loci = n_loci;
     E.cap_ret = h->prm.max_retained_reads; E.cap_items = h->prm.max_items; E.cap_res = h->prm.max_pair_results; E.cap_dp = h->prm.max_items * 4;
     {   // statistics live in ONE device block so that a sample needs one memset pair and one D2H copy
@@ -1322,12 +1460,20 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     if (h->cap_cand < n_reads) { hipStreamSynchronize(h->stream); hipFree(h->d_cand); h->d_cand = nullptr; HIPCHK(h, dmalloc(&h->d_cand, n_reads)); h->cap_cand = n_reads; }
     EngineDev& E = h->E;
     { Prof pf(h, 0);
-      u64 nblk = (n_reads + 255) / 256;
-      dim3 grid(grid_for(nblk, 1, 256 * 8)), block(256);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_sieve<W>, grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, h->d_cand, E.ctr); break;
-      switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
-                     SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
+      if (E.bitmap) {      // LDS first level: one 1024-thread workgroup per CU
+        dim3 grid(grid_for((n_reads + 1023) / 1024, 1, 256)), block(1024);
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_sieve_lds<W>, grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.bitmap, h->d_cand, E.ctr); break;
+        switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
+                       SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
+      } else {
+        u64 nblk = (n_reads + 255) / 256;
+        dim3 grid(grid_for(nblk, 1, 256 * 8)), block(256);
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_sieve<W>, grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, h->d_cand, E.ctr); break;
+        switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
+                       SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
+#undef SIEVE_CASE
+      }
     }
     { Prof pf(h, 1);
       hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand); }

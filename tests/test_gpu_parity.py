@@ -212,3 +212,13 @@ def test_sharded_engines_reduce_to_the_single_engine_result():
     ref = whole.pileup(chosen)
     for a in chosen:
         assert np.array_equal(merged[a], ref[a])
+
+
+def test_plain_sieve_kernel_without_lds_bitmap(monkeypatch):
+    """Large databases skip the LDS first-level bitmap; force that path on a small one."""
+    monkeypatch.setenv("MLST_NO_LDS_SIEVE", "1")
+    db, idx = fx.ecoli_small(80)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 8, n_reads=9000)
+    eng, orc = both(idx)
+    s, _ = run_both(eng, orc, fb, fq, off)
+    check_pileup(eng, orc, idx, s)
