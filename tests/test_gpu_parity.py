@@ -222,3 +222,68 @@ def test_plain_sieve_kernel_without_lds_bitmap(monkeypatch):
     eng, orc = both(idx)
     s, _ = run_both(eng, orc, fb, fq, off)
     check_pileup(eng, orc, idx, s)
+
+
+def test_alleles_with_ambiguity_codes_use_the_n_mask_paths():
+    """Database alleles containing N / IUPAC codes: --np 1 penalty, counts in XM, never a seed."""
+    import sqlite3
+    import tempfile
+    from metamlst_amd.index import load_index
+    d = tempfile.mkdtemp()
+    db = synth.make_ecoli_db(d + "/n.db", alleles_per_locus=30, n_profiles=10, seed=77, indel_every=6)
+    conn = sqlite3.connect(db.path)
+    rng = np.random.default_rng(2)
+    rows = conn.execute("SELECT recID, sequence FROM alleles").fetchall()
+    for rid, seq in rows:
+        if rid % 3 == 0:
+            s = list(seq)
+            for p in rng.integers(0, len(s), size=int(rng.integers(1, 4))):
+                s[p] = "NRYK"[int(rng.integers(4))]
+            conn.execute("UPDATE alleles SET sequence=? WHERE recID=?", ("".join(s), rid))
+    conn.commit()
+    conn.close()
+    idx = load_index(db.path)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 3, n_reads=12000, genome=120_000)
+    for trig in (12, -1):
+        p = default_params()
+        p.gap_trigger_mm = trig
+        eng, orc = both(idx, p)
+        n = 12000 if trig > 0 else 1500
+        o = off[:n + 1]
+        s, _ = run_both(eng, orc, fb[:int(o[-1])], fq[:int(o[-1])], o)
+        check_pileup(eng, orc, idx, s)
+
+
+def test_paired_end_five_fold_coverage_cfg5():
+    """cfg5 of SURVEY.md 8(d): 2 x 150 bp pairs, insert N(300, 30), loci at ~5x.  The documented pipeline
+    aligns mates as unpaired reads (bowtie2 -U), so pairing only affects the displayed coverage figure."""
+    db, idx = fx.ecoli_small(80)
+    g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][2], size=100_000)
+    b, q = synth.sample_pairs(g, n_pairs=int(100_000 * 5 / 300))
+    fb, fq, off = synth.flatten_reads(b, q)
+    eng, orc = both(idx)
+    eng.reset_sample()
+    eng.submit_reads(fb, fq, off, paired=True)
+    orc.submit_reads(fb, fq, off)
+    s = eng.stats()
+    so, items_o = orc.stats(want_items=1 << 16)
+    fx.assert_stats_equal(s, so)
+    chosen, pc = check_pileup(eng, orc, idx, s)
+    holes = sum(int((pc[a].sum(axis=1) == 0).sum()) for a in chosen)
+    assert holes > 0, "5x coverage should leave some columns for the gap-fill path"
+
+
+def test_larger_multi_species_database():
+    db, idx = fx.multi_species(20, 60)
+    parts = []
+    for k, sp in enumerate(db.species[:6]):
+        g, _ = synth.make_genome(db, sp, db.profiles[sp][k % 5], size=60_000, seed=300 + k)
+        parts.append(synth.sample_reads(g, 3000 + 500 * k, seed=400 + k))
+    b = np.concatenate([p[0] for p in parts])
+    q = np.concatenate([p[1] for p in parts])
+    perm = np.random.default_rng(9).permutation(len(b))
+    fb, fq, off = synth.flatten_reads(b[perm], q[perm])
+    eng, orc = both(idx)
+    s, _ = run_both(eng, orc, fb, fq, off)
+    chosen, _ = check_pileup(eng, orc, idx, s)
+    assert len({int(idx.species_id[a]) for a in chosen}) == 6
