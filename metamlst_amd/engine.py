@@ -194,6 +194,8 @@ class Engine:
     def pileup(self, chosen: list[int]) -> dict[int, np.ndarray]:
         """{allele idx: uint32[len, 4]} for the chosen alleles (A,C,G,T columns)."""
         ch = np.ascontiguousarray(chosen, dtype=np.uint32)
+        if any(int(a) >= self.index.n_alleles for a in chosen):
+            raise MlstError("mlst_pileup: chosen allele out of range")
         lens = [int(self.index.off[a + 1] - self.index.off[a]) for a in chosen]
         counts = np.zeros((sum(lens), 4), np.uint32)
         self._check(self.lib.mlst_pileup(self._h, _ptr(ch), len(chosen), _ptr(counts)), "mlst_pileup")
@@ -219,6 +221,8 @@ class Engine:
 
     def hamming_all(self, locus: int, query: bytes) -> np.ndarray:
         q = np.frombuffer(query, dtype=np.uint8)
+        if not 0 <= locus < self.index.n_loci:
+            raise MlstError("mlst_hamming_all: locus %d out of range" % locus)
         d = np.zeros(int(self.index.locus_count[locus]), np.uint32)
         self._check(self.lib.mlst_hamming_all(self._h, locus, _ptr(q) if len(q) else None, len(q), _ptr(d)), "mlst_hamming_all")
         return d

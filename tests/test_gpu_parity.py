@@ -287,3 +287,43 @@ def test_larger_multi_species_database():
     s, _ = run_both(eng, orc, fb, fq, off)
     chosen, _ = check_pileup(eng, orc, idx, s)
     assert len({int(idx.species_id[a]) for a in chosen}) == 6
+
+
+def test_error_codes_capacity_and_limits():
+    from metamlst_amd.engine import MlstError
+    db, idx = fx.ecoli_small(40)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 1, n_reads=8000, genome=80_000)
+    # retained-read capacity too small -> MLST_E_CAPACITY reported when statistics are read
+    p = default_params()
+    p.max_retained_reads = 16
+    eng = Engine(0, p)
+    eng.load_reference(idx)
+    eng.submit_reads(fb, fq, off)
+    with pytest.raises(MlstError, match="capacity exceeded"):
+        eng.stats()
+    # pair-result arena too small
+    p = default_params()
+    p.max_pair_results = 4096
+    eng = Engine(0, p)
+    eng.load_reference(idx)
+    eng.submit_reads(fb, fq, off)
+    with pytest.raises(MlstError, match="capacity exceeded"):
+        eng.stats()
+    # a read longer than the packed format allows -> MLST_E_LIMIT, nothing submitted
+    eng = Engine(0)
+    eng.load_reference(idx)
+    long_read = np.full(400, ord("A"), np.uint8)
+    with pytest.raises(MlstError, match="longer than 320"):
+        eng.submit_reads(long_read, np.full(400, 73, np.uint8), np.array([0, 400], np.uint64))
+    assert eng.stats().counters[2] == 0
+    # bad arguments
+    with pytest.raises(MlstError):
+        eng.pileup([idx.n_alleles + 5])
+    with pytest.raises(MlstError):
+        eng.pileup([0, 1])            # two alleles of one locus
+    with pytest.raises(MlstError):
+        eng.hamming_all(idx.n_loci + 1, b"ACGT")
+    p = default_params()
+    p.band_w = 40
+    with pytest.raises(MlstError, match="band_w"):
+        Engine(0, p)
