@@ -41,7 +41,9 @@
                                        reaches the bowtie2 floor, and ... (next constant);
                                        a negative value means "always run banded SW" */
 #define MLST_DEF_GAP_TRIGGER_CLIP 8 /* ... the ungapped local alignment leaves at least this many overlap
-                                       columns unaligned (an indel clips the alignment; scattered SNPs do not) */
+                                       columns unaligned (an indel clips the alignment; scattered SNPs do not),
+                                       and at least half of those unaligned columns are mismatches (past an indel
+                                       the diagonal looks random, ~75 % mismatches; a clipped SNP cluster does not) */
 #define MLST_DEF_XM_FIELD_QUIRK 1   /* metamlst.py:110 reads SAM column 15 by position: it is XM only
                                        when XS:i is present (read has >= 2 records), else XO (Q1) */
 

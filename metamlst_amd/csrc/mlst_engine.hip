@@ -46,15 +46,15 @@ __host__ __device__ inline u32 pack_result(int score, int xm, int xo) {
 }
 
 // ------------------------------------------------------------------ hashing (host + device)
-__host__ __device__ inline u32 sieve_bucket_hash(u32 lo, u32 hi) {
-    u32 h = (lo ^ (hi * 0x9E3779B1u)) * 0x85EBCA6Bu;
-    h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return h;
-}
+// The sieve's three indices (bitmap bit, bucket, fingerprint) are multiplicative hashes of one pre-mixed word:
+// four integer multiplies per seed (32-bit multiplies are quarter rate).  Top bits of a product are the well
+// mixed ones.  The pre-mix folds 40 key bits into 32, so a key has 255 aliases (one per other value of its top
+// byte) with the same bucket; the fingerprint therefore mixes the top byte in a second, different way.
+__host__ __device__ inline u32 seed_premix(u32 lo, u32 hi) { return lo ^ (hi * 0x01010101u); }
+__host__ __device__ inline u32 sieve_bucket_hash(u32 lo, u32 hi) { return seed_premix(lo, hi) * 0x9E3779B1u; }   // callers keep the TOP log2(buckets) bits: h >> sshift
 __host__ __device__ inline u32 sieve_fp(u32 lo, u32 hi) {
-    u32 h = (lo * 0x27D4EB2Fu) ^ (hi * 0x165667B1u);
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-    u32 fp = h & 0xFFFFu;
+    u32 t = seed_premix(lo, hi) ^ (hi << 11); t ^= t >> 15;   // differs between bucket aliases; the xor-shift breaks the linear relation to the bucket hash
+    u32 fp = (t * 0x85EBCA6Bu) >> 16;
     return fp ? fp : 1u;
 }
 __host__ __device__ inline u32 table_hash(u32 lo, u32 hi) {
@@ -87,7 +87,7 @@ __host__ __device__ inline u64 canon40(u64 s, u32& flag) {
     u64 r = revcomp40(s); flag = r < s ? 1u : 0u; return flag ? r : s;
 }
 #define BITMAP_BITS 20                  // LDS first-level filter: 2^20 bits = 128 KiB
-__host__ __device__ inline u32 bitmap_hash(u32 lo, u32 hi) { return table_hash(lo, hi) >> (32 - BITMAP_BITS); }
+__host__ __device__ inline u32 bitmap_hash(u32 lo, u32 hi) { u32 t = seed_premix(lo, hi); t ^= t >> 13; return (t * 0xC2B2AE35u) >> (32 - BITMAP_BITS); }
 
 // ------------------------------------------------------------------ device-side views
 struct LocusDev {
@@ -191,8 +191,7 @@ __device__ inline bool bucket_has(uint4 b, u32 fp, bool& full) {
     u32 x0 = b.x ^ pat, x1 = b.y ^ pat, x2 = b.z ^ pat, x3 = b.w ^ pat;
     // zero-halfword test
     u32 z = ((x0 - 0x00010001u) & ~x0) | ((x1 - 0x00010001u) & ~x1) | ((x2 - 0x00010001u) & ~x2) | ((x3 - 0x00010001u) & ~x3);
-    u32 e = ((b.x - 0x00010001u) & ~b.x) | ((b.y - 0x00010001u) & ~b.y) | ((b.z - 0x00010001u) & ~b.z) | ((b.w - 0x00010001u) & ~b.w);
-    full = (e & 0x80008000u) == 0;
+    full = (b.w >> 16) != 0;        // slots are filled in order: the bucket is full iff its last slot is occupied
     return (z & 0x80008000u) != 0;
 }
 
@@ -204,6 +203,7 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
                                                 const uint4* __restrict__ sieve, u32 smask,
                                                 u32* __restrict__ cand, Counters* __restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) u32 s_rows[256 * WPR];
+    const u32 sshift = (u32)__clz((int)smask);       // buckets = smask + 1 = 2^(32 - sshift)
     constexpr int NT = WPR - 1;                 // seed slots
     constexpr int NV = (64 * WPR + 255) / 256;  // 16-byte vectors staged per thread
     const int tid = threadIdx.x;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             v4u bv[NT];
             #pragma unroll
             for (int t = 0; t < NT; t++)
-                bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) & smask];
+                bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) >> sshift];
             tie_all<NT>(bv);
             uint4 b[NT];
             #pragma unroll
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
                 const u32* rw = s_rows + (u32)tid * WPR;
                 u32 fl; u64 c = canon40((u64)rw[t] | ((u64)(rw[t + 1] & 0xFFu) << 32), fl);
                 u32 lo = (u32)c, hi = (u32)(c >> 32); u32 fp = sieve_fp(lo, hi);
-                u32 bi = sieve_bucket_hash(lo, hi) & smask;
+                u32 bi = sieve_bucket_hash(lo, hi) >> sshift;
                 for (int step = 0; step < 64; step++) {
                     bi = (bi + 1) & smask; bool full; uint4 bb = sieve[bi];
                     if (bucket_has(bb, fp, full)) { hit = true; break; }
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
                                                      const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ bitmap,
                                                      u32* __restrict__ cand, Counters* __restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) u32 s_bm[(1u << BITMAP_BITS) / 32];
+    const u32 sshift = (u32)__clz((int)smask);       // buckets = smask + 1 = 2^(32 - sshift)
     constexpr int NT = WPR - 1;
     const int tid = threadIdx.x;
     {   // 32768 words, 16-byte vectors
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
             #pragma unroll
             for (int t = 0; t < NT; t++) {
                 bv[t] = v4u{0u, 0u, 0u, 0u};
-                if ((pass >> t) & 1u) bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) & smask];
+                if ((pass >> t) & 1u) bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) >> sshift];
             }
             tie_all<NT>(bv);
             u32 pending = 0;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
                 u32 lo = 0, hi = 0;
                 #pragma unroll
                 for (int u = 0; u < NT; u++) if (u == t) { lo = klo[u]; hi = khi[u]; }
-                u32 fp = sieve_fp(lo, hi); u32 bi = sieve_bucket_hash(lo, hi) & smask;
+                u32 fp = sieve_fp(lo, hi); u32 bi = sieve_bucket_hash(lo, hi) >> sshift;
                 for (int step = 0; step < 64; step++) {
                     bi = (bi + 1) & smask; bool full; uint4 bb = sieve[bi];
                     if (bucket_has(bb, fp, full)) { hit = true; break; }
@@ -552,6 +553,8 @@ __device__ inline u32 spread16(u32 x) {
 // whole overlap; [bs,be) = aligned read span.  Same recurrence as oracle align_ungapped.
 // The allele window (one dword per 16 bases, coalesced across lanes = alleles) is fetched as one batch of
 // independent loads before the serial Kadane pass.
+// NW = number of 16-base read words the instantiation supports (register arrays are sized by it)
+template <int NW>
 __device__ inline int ungapped(const EngineDev& E, const KParams& P, const LocusDev& L, u32 a_local, int m, int n, int d,
                                const u32* s_rw, const u32* s_rn, const u32* s_odd, const u8* s_pen, int pen_def, bool read_has_n,
                                int& mm_total, int& bs, int& be) {
@@ -562,9 +565,9 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
     const int nw = (n + 15) >> 4;                  // read words in use (block-uniform)
     const int q0 = d >> 4, r2 = (d & 15) * 2;      // allele word of read position 0 (floor), bit shift
     const u32* abase = E.arena + L.arena_off;      // uniform base of the locus; lanes differ only in a_local
-    u32 Aw[RW + 1];
+    u32 Aw[NW + 1];
     #pragma unroll
-    for (int t = 0; t <= RW; t++) {
+    for (int t = 0; t <= NW; t++) {
         Aw[t] = 0;
         if (t <= nw) {                             // uniform guard
             int q = q0 + t; int qc = q < 0 ? 0 : (q >= (int)L.words ? (int)L.words - 1 : q);
@@ -573,13 +576,11 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
     }
     // Words outside the allele only ever meet read positions outside [i0, i1), which the valid mask removes,
     // so clamped (out-of-range) words need no zeroing.  Issue the whole window before using any of it:
-    TIE7(Aw[0], Aw[1], Aw[2], Aw[3], Aw[4], Aw[5], Aw[6]);
-    TIE7(Aw[7], Aw[8], Aw[9], Aw[10], Aw[11], Aw[12], Aw[13]);
-    TIE7(Aw[14], Aw[15], Aw[16], Aw[17], Aw[18], Aw[19], Aw[20]);
+    tie_all<NW + 1>(Aw);
     // mismatch bits, one per read base, 32 bases per mask
-    u32 M[RW / 2], AN[RW / 2];
+    u32 M[NW / 2], AN[NW / 2];
     #pragma unroll
-    for (int w = 0; w < RW / 2; w++) {
+    for (int w = 0; w < NW / 2; w++) {
         M[w] = 0; AN[w] = 0;
         if (w * 2 < nw) {                          // uniform guard
             u32 x0 = s_rw[2 * w] ^ __builtin_amdgcn_alignbit(Aw[2 * w + 1], Aw[2 * w], r2);        // allele bases aligned to the read word
@@ -603,7 +604,7 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
     int cur = P0, best = P0, cs = i0, last = i0, blen = 0, bend = i0;
     const int PD = (pen_def << MLST_P_SHIFT) + 1;
     #pragma unroll
-    for (int w = 0; w < RW / 2; w++) {
+    for (int w = 0; w < NW / 2; w++) {
         if (w * 2 < nw) {
             u32 Mw = M[w];
 #ifdef EXP_NO_KADANE
@@ -629,11 +630,12 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
     return best;
 }
 // the policy deciding whether the banded Smith-Waterman runs for a pair (same expression as oracle align_pair)
-__device__ inline bool gap_trigger(const KParams& P, int mm, int score, int floor_n, int m, int n, int d, int bs, int be) {
+__device__ inline bool gap_trigger(const KParams& P, int mm, int xm, int score, int floor_n, int m, int n, int d, int bs, int be) {
     if (P.trig < 0) return true;
     int i0 = d < 0 ? -d : 0, i1 = (m - d) < n ? (m - d) : n;
     int overlap = i1 > i0 ? i1 - i0 : 0;
-    return mm > P.trig && score >= floor_n && overlap - (be - bs) >= P.clip;
+    int clipped = overlap - (be - bs);          // overlap columns the ungapped alignment left out
+    return mm > P.trig && score >= floor_n && clipped >= P.clip && 2 * (mm - xm) >= clipped;
 }
 
 // ------------------------------------------------------------------ K3: extension of every item against every allele of its locus
@@ -646,6 +648,7 @@ __device__ inline bool accept_rec(const KParams& P, u32 r, int n, bool use_xo) {
 #ifndef EXT_WAVES
 #define EXT_WAVES 4          // waves per SIMD the register allocator must leave room for (swept on MI355X)
 #endif
+template <int NW>
 __global__ __launch_bounds__(256, EXT_WAVES) void k_extend(const EngineDev* __restrict__ Ep, KParams P) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u32 s_odd[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
@@ -669,9 +672,9 @@ __global__ __launch_bounds__(256, EXT_WAVES) void k_extend(const EngineDev* __re
         for (u32 a = tid; a < L.n_alleles; a += 256) {
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
-            int best = ungapped(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_odd, s_pen, (int)s_pentab[40], read_has_n, mm, bs, be);
+            int best = ungapped<NW>(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_odd, s_pen, (int)s_pentab[40], read_has_n, mm, bs, be);
             int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
-            bool need_dp = gap_trigger(P, mm, score, floor_n, m, n, it.diag, bs, be);
+            bool need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
             u32 r = pack_result(score, xm, xo);
             if (need_dp) { r |= R_NEEDDP; ndp++; }
             else if (score >= floor_n && score > 0) { r |= R_REC; nrec++; }
@@ -796,9 +799,11 @@ __device__ inline int banded(const EngineDev& E, const KParams& P, const ItemDev
 __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep, KParams P) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     __shared__ u8 s_pentab[128];
+    __shared__ u32 s_qrow[8][RQ / 4];       // per pair (8 pairs per block): the read's quality row ...
+    __shared__ u32 s_brow[8][RW];           // ... and its packed bases, so a DP row costs no global-memory round trip
     if (threadIdx.x < 128) s_pentab[threadIdx.x] = E.pen_tab[threadIdx.x];
     __syncthreads();
-    const int b = threadIdx.x & 31;
+    const int b = threadIdx.x & 31, gl = threadIdx.x >> 5;
     const u64 grp = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 5, ngrp = ((u64)gridDim.x * blockDim.x) >> 5;
     const u64 begin = E.ctr->dp_done, end = E.ctr->n_dp < E.cap_dp ? E.ctr->n_dp : E.cap_dp;
     const int W = P.band_w, BW = 2 * W + 1, G = P.gbar;
@@ -815,8 +820,16 @@ __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep
         int nmax = n; { int o = __shfl_xor(nmax, 32); nmax = o > nmax ? o : nmax; }    // both halves run the same trip count
         const int d = it.diag;
         const int m = live ? (int)E.allele_len[L.a_begin + a_local] : 0;
-        const u32* rb = E.ret_bases + (u64)it.ret * RW;
-        const u8* rq = E.ret_quals + (u64)it.ret * RQ;
+        __syncthreads();                      // previous pair's rows are no longer read (trip count is block-uniform)
+        {
+            const u32* gq = reinterpret_cast<const u32*>(E.ret_quals + (u64)it.ret * RQ);
+            const u32* gb = E.ret_bases + (u64)it.ret * RW;
+            for (int w = b; w < RQ / 4; w += 32) s_qrow[gl][w] = live ? gq[w] : 0u;
+            if (b < RW) s_brow[gl][b] = live ? gb[b] : 0u;
+        }
+        __syncthreads();
+        const u32* rb = s_brow[gl];
+        const u8* rq = reinterpret_cast<const u8*>(s_qrow[gl]);
         int Hp = P0, Fp = NEGP, best = P0;
         int jb = d - W, q = jb >> 4;
         u32 w0 = arena_word(E, L, q, a_local), w1 = arena_word(E, L, q + 1, a_local), w2 = arena_word(E, L, q + 2, a_local);
@@ -981,10 +994,10 @@ __global__ __launch_bounds__(64) void k_pileup(const EngineDev* __restrict__ Ep,
         __syncthreads();
         int m = (int)E.allele_len[ca];
         int mm, bs, be;
-        int best = ungapped(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_odd, s_pen, (int)s_pentab[40], (lw & 0x8000u) != 0, mm, bs, be);
+        int best = ungapped<RW>(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_odd, s_pen, (int)s_pentab[40], (lw & 0x8000u) != 0, mm, bs, be);
         int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF);
         int floor_n = E.floor_tab[n];
-        bool need_dp = gap_trigger(P, mm, score, floor_n, m, n, it.diag, bs, be);
+        bool need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
         if (need_dp) { if (lane == 0) { u64 slot = atomicAdd(&E.ctr->n_pl_dp, 1ull); pl_list[slot] = ii; } continue; }
         if (score < floor_n || score <= 0 || score < P.minscore || xm > P.max_xm) continue;   // BAM_tagFilter AS, XM
         u64 colbase = locus_colbase[it.locus];
@@ -1333,9 +1346,10 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     u64 nb = 256; while (nb * 4 < nk) nb <<= 1;
     if (nb > (1ull << 31)) return fail(h, MLST_E_LIMIT, "sieve too large");
     std::vector<u16> sv(nb * 8, 0); u32 smask = (u32)(nb - 1);
+    u32 sshift_h = 32; for (u64 t = nb; t > 1; t >>= 1) sshift_h--;      // nb = 2^(32 - sshift_h)
     for (u64 i = 0; i < nk; i++) {
         u32 lo = (u32)ukeys[i], hi = (u32)(ukeys[i] >> 32);
-        u32 fp = sieve_fp(lo, hi); u32 b = sieve_bucket_hash(lo, hi) & smask;
+        u32 fp = sieve_fp(lo, hi); u32 b = sieve_bucket_hash(lo, hi) >> sshift_h;
         for (u64 step = 0; step < nb; step++) {
             u16* B = &sv[(u64)b * 8]; int k; bool done = false;
             for (k = 0; k < 8; k++) { if (B[k] == fp) { done = true; break; } if (B[k] == 0) { B[k] = (u16)fp; done = true; break; } }
@@ -1477,7 +1491,9 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     }
     { Prof pf(h, 1);
       hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand); }
-    { Prof pf(h, 2); hipLaunchKernelGGL(k_extend, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
+    { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
+      if (wpr <= 10) hipLaunchKernelGGL(k_extend<10>, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
+      else hipLaunchKernelGGL(k_extend<RW>, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
       hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, h->d_E); }

@@ -276,8 +276,9 @@ static void align_pair(const orc_ref* r, const uint8_t* rb, const uint8_t* pen, 
     int trig = r->prm.gap_trigger_mm;
     int i0 = d < 0 ? -d : 0, i1 = (m - d) < n ? (m - d) : n;
     int overlap = i1 > i0 ? i1 - i0 : 0;
+    int clipped = overlap - o->n_cols;            /* overlap columns the ungapped alignment left out */
     int run_dp = trig < 0 ? 1 : (o->mm_total > trig && o->score >= r->floor_tab[n] &&
-                                 overlap - o->n_cols >= r->prm.gap_trigger_clip);
+                                 clipped >= r->prm.gap_trigger_clip && 2 * (o->mm_total - o->xm) >= clipped);
     if (run_dp) { int mm = o->mm_total; align_banded(r, rb, pen, n, ab, m, d, o); o->mm_total = mm; }
 }
 
