@@ -174,7 +174,8 @@ def main():
                 return split_counts(idx, chosen, allreduce_pileup(port, chosen, n_cols, device))
             return eng.pileup(chosen)
 
-        res = type_sample(idx, st, pileup_fn, database, "sample", fast=True, cache=cache)
+        res = type_sample(idx, st, pileup_fn, database, "sample", fast=True, cache=cache,
+                          consensus_fn=eng.consensus if world == 1 else None)
         t_d = time.perf_counter()
         out = {}
         if rank == 0:

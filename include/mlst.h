@@ -140,6 +140,14 @@ int mlst_pileup(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n, u
 int mlst_pileup_device(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n,
                        uint32_t* d_counts /* device, n_cols*4, zeroed by the call */, uint64_t* n_cols);
 
+/* Pass 2 with the majority rule applied on the GPU: the string cmseq's
+ * reference_free_consensus(mincov, noneCharacter, ...) returns for each chosen contig
+ * (metaMLST_functions.py:258-259), concatenated in the order given.  A column with fewer than
+ * mincov counted bases is none_char; ties resolve A < C < G < T (MLST_TIE_ORDER).
+ *   out_seq : sum(len(chosen)) bytes;  counts (optional, may be NULL): as mlst_pileup. */
+int mlst_consensus(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n, uint32_t mincov,
+                   char none_char, uint8_t* out_seq, uint32_t* counts);
+
 /* Allele match: Hamming distance of `query` against every allele of `locus`, semantics of
  * stringDiff (metaMLST_functions.py:230-234: zip truncates, length difference not counted),
  * as used by metamlst-merge.py:177-181.  Outputs the first allele (load order) within z,

@@ -299,21 +299,24 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
     }
     __syncthreads();
     const u64 n_tiles = (n_reads + 1023) / 1024;
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    // software pipeline: the rows (and lengths) of the NEXT tile are requested before the current tile is processed
+    v2u xn[WPR / 2]; u16 len_raw = 0; bool live_next = false;   // the raw length is only looked at one iteration later
+    {
+        u64 r = (u64)blockIdx.x * 1024 + tid;
+        live_next = blockIdx.x < n_tiles && r < n_reads;
+        const v2u* row = reinterpret_cast<const v2u*>(packed + (live_next ? r : 0) * WPR);
+        #pragma unroll
+        for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2);
+        len_raw = lens[live_next ? r : 0];
+    }
     for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         u64 r = tile * 1024 + tid;
-        bool live = r < n_reads;
-        u32 n = live ? (u32)(lens[r] & 0x7FFFu) : 0u;
+        u32 n = live_next ? (u32)(len_raw & 0x7FFFu) : 0u;
         int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
         u32 w[WPR];
-        {
-            typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-            const v2u* row = reinterpret_cast<const v2u*>(packed + (live ? r : 0) * WPR);
-            v2u x[WPR / 2];
-            #pragma unroll
-            for (int t2 = 0; t2 < WPR / 2; t2++) x[t2] = __builtin_nontemporal_load(row + t2);
-            #pragma unroll
-            for (int t2 = 0; t2 < WPR / 2; t2++) { w[2 * t2] = x[t2].x; w[2 * t2 + 1] = x[t2].y; }
-        }
+        #pragma unroll
+        for (int t2 = 0; t2 < WPR / 2; t2++) { w[2 * t2] = xn[t2].x; w[2 * t2 + 1] = xn[t2].y; }
         u32 klo[NT], khi[NT]; u32 pass = 0;
         #pragma unroll
         for (int t = 0; t < NT; t++) {
@@ -322,34 +325,43 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
             u32 bit = (s_bm[bi >> 5] >> (bi & 31)) & 1u;
             pass |= (t < nseeds ? bit : 0u) << t;
         }
+        // second level: the fingerprint sieve, only for seeds whose bit is set.  Order matters: probes are issued
+        // first, then the next tile's rows (vmcnt retires in order, so waiting for the probes leaves the younger
+        // row loads in flight across the rest of this tile).
+        v4u bv[NT];
+        #pragma unroll
+        for (int t = 0; t < NT; t++) {
+            bv[t] = v4u{0u, 0u, 0u, 0u};
+            if ((pass >> t) & 1u) bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) >> sshift];
+        }
+        {
+            u64 tn = tile + gridDim.x; u64 rn = tn * 1024 + tid;
+            live_next = tn < n_tiles && rn < n_reads;
+            const v2u* row = reinterpret_cast<const v2u*>(packed + (live_next ? rn : 0) * WPR);
+            #pragma unroll
+            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2);
+            len_raw = lens[live_next ? rn : 0];
+        }
+        tie_all<NT>(bv);
         bool hit = false;
-        if (pass) {      // second level: the fingerprint sieve, only for seeds whose bit is set
-            v4u bv[NT];
+        u32 pending = 0;
+        #pragma unroll
+        for (int t = 0; t < NT; t++) {
+            bool full; bool f = bucket_has(make_uint4(bv[t].x, bv[t].y, bv[t].z, bv[t].w), sieve_fp(klo[t], khi[t]), full);
+            bool valid = (pass >> t) & 1u;
+            hit |= valid && f;
+            pending |= (valid && !f && full) ? (1u << t) : 0u;
+        }
+        while (pending && !hit) {   // overflow chain: the key may sit in a following bucket
+            int t = __ffs(pending) - 1; pending &= pending - 1;
+            u32 lo = 0, hi = 0;
             #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                bv[t] = v4u{0u, 0u, 0u, 0u};
-                if ((pass >> t) & 1u) bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) >> sshift];
-            }
-            tie_all<NT>(bv);
-            u32 pending = 0;
-            #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                bool full; bool f = bucket_has(make_uint4(bv[t].x, bv[t].y, bv[t].z, bv[t].w), sieve_fp(klo[t], khi[t]), full);
-                bool valid = (pass >> t) & 1u;
-                hit |= valid && f;
-                pending |= (valid && !f && full) ? (1u << t) : 0u;
-            }
-            while (pending && !hit) {   // overflow chain: the key may sit in a following bucket
-                int t = __ffs(pending) - 1; pending &= pending - 1;
-                u32 lo = 0, hi = 0;
-                #pragma unroll
-                for (int u = 0; u < NT; u++) if (u == t) { lo = klo[u]; hi = khi[u]; }
-                u32 fp = sieve_fp(lo, hi); u32 bi = sieve_bucket_hash(lo, hi) >> sshift;
-                for (int step = 0; step < 64; step++) {
-                    bi = (bi + 1) & smask; bool full; uint4 bb = sieve[bi];
-                    if (bucket_has(bb, fp, full)) { hit = true; break; }
-                    if (!full) break;
-                }
+            for (int u = 0; u < NT; u++) if (u == t) { lo = klo[u]; hi = khi[u]; }
+            u32 fp = sieve_fp(lo, hi); u32 bi = sieve_bucket_hash(lo, hi) >> sshift;
+            for (int step = 0; step < 64; step++) {
+                bi = (bi + 1) & smask; bool full; uint4 bb = sieve[bi];
+                if (bucket_has(bb, fp, full)) { hit = true; break; }
+                if (!full) break;
             }
         }
         u64 mask = __ballot(hit);
@@ -669,7 +681,11 @@ __global__ __launch_bounds__(256, EXT_WAVES) void k_extend(const EngineDev* __re
         if (it.res_off + L.n_pad > E.cap_res) continue;      // flagged by k_seed
         const int floor_n = E.floor_tab[n];
         u32 nrec = 0, ndp = 0;
+#ifdef EXP_NO_ALLELES
+        for (u32 a = tid; a < 0; a += 256) {
+#else
         for (u32 a = tid; a < L.n_alleles; a += 256) {
+#endif
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
             int best = ungapped<NW>(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_odd, s_pen, (int)s_pentab[40], read_has_n, mm, bs, be);
@@ -1043,6 +1059,18 @@ __global__ __launch_bounds__(64) void k_pileup_dp(const EngineDev* __restrict__ 
             } else if (state == 1) { int ext = t & 4; b--; state = ext ? 1 : 0; }
             else { int ext = t & 8; i--; b++; state = ext ? 2 : 0; }
         }
+    }
+}
+
+// majority base per column (cmseq reference_free_consensus [NOT IN TREE]: ties alphabetical, < mincov -> none_char)
+__global__ __launch_bounds__(256) void k_consensus(const u32* __restrict__ counts, u64 n_cols, u32 mincov, u8 none_char, u8* __restrict__ out) {
+    for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += (u64)gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4*>(counts)[c];
+        u32 best = v.x; u8 ch = 'A';
+        if (v.y > best) { best = v.y; ch = 'C'; }
+        if (v.z > best) { best = v.z; ch = 'G'; }
+        if (v.w > best) { best = v.w; ch = 'T'; }
+        out[c] = (v.x + v.y + v.z + v.w) >= mincov ? ch : none_char;
     }
 }
 
@@ -1650,6 +1678,28 @@ extern "C" int mlst_pileup(mlst_handle* h, const uint32_t* chosen, uint32_t n, u
     if (ncols) HIPCHK(h, hipMemcpyAsync(stage, h->d_counts, ncols * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (ncols) memcpy(counts, stage, ncols * 16);
+    return MLST_OK;
+}
+
+extern "C" int mlst_consensus(mlst_handle* h, const uint32_t* chosen, uint32_t n, uint32_t mincov, char none_char,
+                              uint8_t* out_seq, uint32_t* counts) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (!out_seq) return fail(h, MLST_E_INVALID, "out_seq is NULL");
+    hipSetDevice(h->device);
+    u64 ncols = 0;
+    for (u32 k = 0; k < n; k++) { if (chosen[k] >= h->n_alleles) return fail(h, MLST_E_INVALID, "chosen allele out of range"); ncols += h->aoff[chosen[k] + 1] - h->aoff[chosen[k]]; }
+    const u64 need = ncols * 4 + 4 + (ncols + 15) / 4 + 8;       // counts + letters (u32 units)
+    if (h->cap_counts < need) { hipStreamSynchronize(h->stream); hipFree(h->d_counts); h->d_counts = nullptr; HIPCHK(h, dmalloc(&h->d_counts, need)); h->cap_counts = need; }
+    uint64_t nc2 = 0; int rc = pileup_launch(h, chosen, n, h->d_counts, ncols * 17 + 64, &nc2); if (rc) return rc;
+    u8* d_letters = reinterpret_cast<u8*>(h->d_counts + ncols * 4 + 4);
+    if (ncols) hipLaunchKernelGGL(k_consensus, dim3(grid_for(ncols, 256, 256)), dim3(256), 0, h->stream, h->d_counts, (u64)ncols, mincov, (u8)none_char, d_letters);
+    HIPCHK(h, hipGetLastError());
+    u8* stage = h->h_pin + (u64)h->n_loci * 12 + 16; stage = (u8*)(((uintptr_t)stage + 15) & ~(uintptr_t)15);
+    if (ncols) HIPCHK(h, hipMemcpyAsync(stage, d_letters, ncols, hipMemcpyDeviceToHost, h->stream));
+    if (ncols && counts) HIPCHK(h, hipMemcpyAsync(stage + ((ncols + 15) & ~15ull), h->d_counts, ncols * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ncols) memcpy(out_seq, stage, ncols);
+    if (ncols && counts) memcpy(counts, stage + ((ncols + 15) & ~15ull), ncols * 16);
     return MLST_OK;
 }
 

@@ -86,6 +86,7 @@ def load_library(path: str | None = None):
         "mlst_import_stats_device": (C.c_int, [H, i64p, i64p]),
         "mlst_pileup": (C.c_int, [H, u32p, C.c_uint32, u32p]),
         "mlst_pileup_device": (C.c_int, [H, u32p, C.c_uint32, u32p, C.POINTER(C.c_uint64)]),
+        "mlst_consensus": (C.c_int, [H, u32p, C.c_uint32, C.c_uint32, C.c_char, u8p, u32p]),
         "mlst_hamming_le": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
         "mlst_hamming_all": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, u32p]),
         "mlst_reset_sample": (C.c_int, [H]),
@@ -204,6 +205,22 @@ class Engine:
             out[int(a)] = counts[at:at + L]
             at += L
         return out
+
+    def consensus(self, chosen: list[int], mincov: int = 1, none_char: str = "N") -> dict[int, bytes]:
+        """{allele idx: consensus bytes}: what cmseq's reference_free_consensus returns per contig (majority base,
+        none_char below mincov), computed on the GPU from the pileup."""
+        ch = np.ascontiguousarray(chosen, dtype=np.uint32)
+        if any(int(a) >= self.index.n_alleles for a in chosen):
+            raise MlstError("mlst_consensus: chosen allele out of range")
+        lens = [int(self.index.off[a + 1] - self.index.off[a]) for a in chosen]
+        out = np.zeros(max(1, sum(lens)), np.uint8)
+        self._check(self.lib.mlst_consensus(self._h, _ptr(ch), len(chosen), int(mincov), none_char.encode(), _ptr(out), None), "mlst_consensus")
+        res, at = {}, 0
+        buf = out.tobytes()
+        for a, L in zip(chosen, lens):
+            res[int(a)] = buf[at:at + L]
+            at += L
+        return res
 
     def pileup_device(self, chosen: list[int], d_counts: int) -> int:
         ch = np.ascontiguousarray(chosen, dtype=np.uint32)

@@ -49,9 +49,50 @@ class AlleleIndex:
 
     def __post_init__(self):
         self._locus_map = {k: i for i, k in enumerate(self.loci)}
+        self.locus_id_ip = self.locus_id.astype(np.intp)       # fancy-index form (uint32 indices are converted on every use)
+        self.locus_begin_ip = self.locus_begin.astype(np.intp)
 
 
-def load_index(db_path: str, species_filter: list[str] | None = None) -> AlleleIndex:
+def similarity_order(seqs: list[bytes]) -> list[int]:
+    """Order the alleles of one locus so that neighbours are similar (greedy nearest-neighbour chain on
+    Hamming distance over 2-bit packed sequences).  The engine extends a read against the alleles of a
+    locus 64 at a time (one per lane); lanes with similar mismatch patterns diverge less.  Purely a
+    layout choice: every output is keyed by alleleVariant, not by position in the index."""
+    n = len(seqs)
+    if n <= 2:
+        return list(range(n))
+    L = max(len(s) for s in seqs)
+    W = (L + 31) // 32
+    code = np.zeros(256, np.uint64)
+    for k, c in enumerate(b"ACGT"):
+        code[c] = k
+        code[c + 32] = k
+    packed = np.zeros((n, W), np.uint64)
+    other = np.zeros((n, W), np.uint64)          # non-ACGT or past-the-end positions count as differences
+    for i, s in enumerate(seqs):
+        a = np.frombuffer(s, np.uint8)
+        c = np.zeros(W * 32, np.uint64)
+        c[:len(a)] = code[a]
+        ok = np.zeros(W * 32, bool)
+        ok[:len(a)] = np.isin(a, np.frombuffer(b"ACGTacgt", np.uint8))
+        sh = (np.arange(W * 32, dtype=np.uint64) % np.uint64(32)) * np.uint64(2)
+        packed[i] = np.bitwise_or.reduce((c << sh).reshape(W, 32), axis=1)
+        other[i] = np.bitwise_or.reduce(((~ok).astype(np.uint64) << sh).reshape(W, 32), axis=1)
+    m55 = np.uint64(0x5555555555555555)
+    order, left = [0], np.ones(n, bool)
+    left[0] = False
+    cur = 0
+    for _ in range(n - 1):
+        x = packed ^ packed[cur]
+        d = np.bitwise_count(((x | (x >> np.uint64(1))) & m55) | other | other[cur]).sum(axis=1).astype(np.int64)
+        d[~left] = np.iinfo(np.int64).max
+        cur = int(d.argmin())
+        order.append(cur)
+        left[cur] = False
+    return order
+
+
+def load_index(db_path: str, species_filter: list[str] | None = None, cluster: bool = True) -> AlleleIndex:
     """Read alleles as dump_db_to_fasta does (sequence <> ''), optionally restricted to
     the --filter species (metamlst.py:114 applies the filter per record; not loading the
     other species' alleles is equivalent for every output of the path)."""
@@ -62,8 +103,18 @@ def load_index(db_path: str, species_filter: list[str] | None = None) -> AlleleI
     if species_filter:
         keep = set(species_filter)
         rows = [r for r in rows if r[1] in keep]
-    # contiguous loci; allele order inside a locus = (alleleVariant, recID)
+    # contiguous loci; allele order inside a locus = (alleleVariant, recID), then optionally similarity order
     rows.sort(key=lambda r: (r[1], r[2], int(r[3]), r[0]))
+    if cluster and rows:
+        out, i = [], 0
+        while i < len(rows):
+            j = i
+            while j < len(rows) and rows[j][1] == rows[i][1] and rows[j][2] == rows[i][2]:
+                j += 1
+            grp = rows[i:j]
+            out += [grp[k] for k in similarity_order([r[4].encode() for r in grp])]
+            i = j
+        rows = out
     species, loci = [], []
     sp_map, lo_map = {}, {}
     n = len(rows)

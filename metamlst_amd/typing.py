@@ -103,15 +103,14 @@ def pick_alleles_fast(index: AlleleIndex, st: SampleStats, penalty: int) -> dict
     nh = st.n_hits.astype(np.int64)
     if nh.size == 0:
         return {}
-    begins = index.locus_begin
-    lid = index.locus_id
+    begins, lid = index.locus_begin_ip, index.locus_id_ip
     maxlen = np.maximum.reduceat(nh, begins)                       # per locus: max hits over its alleles
     local = st.sum_score - (maxlen[lid] - nh) * penalty            # metamlst.py:146-147
-    hit = nh > 0
-    x = np.full(nh.shape, -np.inf)
-    np.divide(local, nh, out=x, where=hit)
+    x = local / np.maximum(nh, 1)                                  # same IEEE division as float(a)/float(b); alleles without hits excluded below
+    x[nh == 0] = -np.inf
     xmax = np.maximum.reduceat(x, begins)
-    near = np.nonzero(hit & (x >= xmax[lid] - 0.11) & (st.locus_first[lid] != NO_READ))[0]
+    near = np.nonzero(x >= xmax[lid] - 0.11)[0]
+    near = near[(nh[near] > 0) & (st.locus_first[lid[near]] != NO_READ)]
     best: dict = {}
     for a in near.tolist():
         r = round(float(int(local[a])) / float(int(nh[a])), 1)
@@ -152,6 +151,36 @@ def build_consensus(chromosomeList: dict, counts_by_label: dict, mincov: int = 1
     counts = counts_by_label[labels[0]] if len(labels) == 1 else np.concatenate([counts_by_label[l] for l in labels])
     dbarr = np.frombuffer("".join(chromosomeList[l] for l in labels).encode("latin-1"), dtype=np.uint8)
     cons = _consensus_bytes(counts, mincov)
+    isN = cons == ord("N")
+    upper = (dbarr >= 65) & (dbarr <= 90)
+    out = np.where(isN, np.where(upper, dbarr + 32, dbarr), cons).astype(np.uint8).tobytes().decode("latin-1")
+    offs = np.concatenate(([0], np.cumsum(lens)))
+    cI = np.add.reduceat(isN.astype(np.int64), offs[:-1])
+    sn = np.add.reduceat(((cons != dbarr) & ~isN).astype(np.int64), offs[:-1])
+    return [SeqRecordLite(out[int(offs[k]):int(offs[k + 1])], l, "CI::" + str(int(cI[k])) + "_SP::" + str(int(sn[k])))
+            for k, l in enumerate(labels)]
+
+
+def build_consensus_from_letters(chromosomeList: dict, letters_by_label: dict) -> list[SeqRecordLite]:
+    """The tail of buildConsensus (metaMLST_functions.py:260-276) when the consensus string itself comes from
+    the engine (mlst_consensus = cmseq's reference_free_consensus): gap-fill and SNP count only."""
+    labels = list(chromosomeList)
+    if not labels:
+        return []
+    lens = [len(chromosomeList[l]) for l in labels]
+    if any(len(letters_by_label[l]) != n for l, n in zip(labels, lens)) or min(lens) == 0:
+        out = []
+        for l in labels:      # literal loop for odd cases
+            rSequen = list(letters_by_label[l].decode("latin-1")); dbSequen = chromosomeList[l]; cIndex = SNPs = 0
+            for i, ch in enumerate(rSequen):
+                if ch == "N":
+                    rSequen[i] = dbSequen[i].lower(); cIndex += 1
+                elif rSequen[i] != dbSequen[i]:
+                    SNPs += 1
+            out.append(SeqRecordLite("".join(rSequen), l, "CI::" + str(cIndex) + "_SP::" + str(SNPs)))
+        return out
+    cons = np.frombuffer(b"".join(letters_by_label[l] for l in labels), dtype=np.uint8)
+    dbarr = np.frombuffer("".join(chromosomeList[l] for l in labels).encode("latin-1"), dtype=np.uint8)
     isN = cons == ord("N")
     upper = (dbarr >= 65) & (dbarr <= 90)
     out = np.where(isN, np.where(upper, dbarr + 32, dbarr), cons).astype(np.uint8).tobytes().decode("latin-1")
@@ -222,7 +251,7 @@ def _detected_loci(index: AlleleIndex, st: SampleStats) -> dict:
 
 def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.metaMLST_db, fileName: str,
                 args: TypingArgs | None = None, out_dir: str | None = None, fast: bool = False,
-                cache: mdb.DbCache | None = None) -> list[SpeciesResult]:
+                cache: mdb.DbCache | None = None, consensus_fn=None) -> list[SpeciesResult]:
     """metamlst.py:133-289 for one sample.
 
     pileup_fn(list of allele indices) -> {allele idx: uint32[len, 4]} is pass 2 of the engine
@@ -275,7 +304,9 @@ def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.me
             res.chosen.append((speciesKey + "_" + g1 + "_" + k, index.sequence(a)))
             plan.append((res, a))
     # pass 2 once for every species that passed (identical to one buildConsensus per species)
-    counts = pileup_fn([a for _, a in plan]) if plan else {}
+    # consensus_fn(list of allele indices) -> {allele idx: consensus bytes} (mlst_consensus) replaces counts + majority
+    letters = consensus_fn([a for _, a in plan]) if (plan and consensus_fn is not None) else None
+    counts = pileup_fn([a for _, a in plan]) if (plan and letters is None) else {}
     for res in results:
         if not res.passed_nloci:
             continue
@@ -283,8 +314,9 @@ def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.me
         by_label = {}
         for (r2, a) in plan:
             if r2 is res:
-                by_label[index.label(a)] = counts[a]
-        consenSeq = build_consensus(chromosomeList, by_label, mincov=1)
+                by_label[index.label(a)] = counts[a] if letters is None else letters[a]
+        consenSeq = (build_consensus(chromosomeList, by_label, mincov=1) if letters is None else
+                     build_consensus_from_letters(chromosomeList, by_label))
         finWrite = 1
         for l in sorted(consenSeq, key=lambda x: x.id):
             holes = str(l.description.split("_")[0].split("::")[1])

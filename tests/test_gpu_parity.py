@@ -29,11 +29,15 @@ def run_both(eng, orc, fb, fq, off):
 
 
 def check_pileup(eng, orc, idx, s):
+    from metamlst_amd.typing import consensus_from_counts
     chosen = sorted(pick_alleles_fast(idx, s, 100).values())
     pc, po = eng.pileup(chosen), orc.pileup(chosen)
     assert set(pc) == set(po)
     for a in pc:
         assert np.array_equal(pc[a], po[a]), "pileup differs for allele %d" % a
+    cons = eng.consensus(chosen)            # GPU majority rule == host majority rule on the oracle's counts
+    for a in chosen:
+        assert cons[a].decode() == "".join(consensus_from_counts(po[a])), "consensus differs for allele %d" % a
     return chosen, pc
 
 
