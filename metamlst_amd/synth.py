@@ -55,7 +55,7 @@ def gen_locus_alleles(rng: np.random.Generator, length: int, n_alleles: int, max
         child = alleles[p].copy()
         pos = rng.choice(len(child), size=k, replace=False)
         child[pos] = (child[pos] + rng.integers(1, 4, size=k, dtype=np.uint8)) % 4
-        if indel_every and len(alleles) % indel_every == 0 and len(child) == length:
+        if indel_every and len(alleles) % indel_every == 0 and len(child) == length and length > 130:
             dl = int(rng.integers(1, 4))
             at = int(rng.integers(60, len(child) - 60))
             child = np.delete(child, np.arange(at, at + dl))
