@@ -2,6 +2,7 @@
 
     python -m metamlst_amd.cli type  SAMPLE.fastq[.gz] [-2 MATES.fastq] -d DB [-o out] [--penalty ...]   (metamlst.py:34-49)
     python -m metamlst_amd.cli merge FOLDER -d DB [-z 5] [--filter ...] [--meta ...] [--idField ...]       (metamlst-merge.py:35-49)
+    python -m metamlst_amd.cli index -d DB [-s seqs.fasta,...] [-t typings.txt,...] [-q dump.fa] [--list]   (metamlst-index.py:24-33)
 
 `type` takes reads instead of a bowtie2 BAM: the alignment happens on the GPU.  Everything it
 writes (<out>/<sample>.nfo, optional --log file) has the reference's format; `merge` writes
@@ -54,6 +55,38 @@ def _merge_parser(sub):
     p.add_argument("--idField", default=0, type=int)
     p.add_argument("--device", default=0, type=int)
     return p
+
+
+def _index_parser(sub):
+    p = sub.add_parser("index", help="build / extend a MetaMLST SQLite database (ingest half of metamlst-index.py; no bowtie2 index is needed)")
+    p.add_argument("-t", "--typings")
+    p.add_argument("-s", "--sequences")
+    p.add_argument("-q", "--dump_db")
+    p.add_argument("-i", "--buildindex", help="accepted and ignored: the GPU index is built from the database when it is loaded")
+    p.add_argument("-d", "--database", metavar="DB PATH", required=True)
+    p.add_argument("--list", action="store_true")
+    p.add_argument("--filter", default=None)
+    return p
+
+
+def run_index(a) -> int:
+    from . import dbbuild
+    conn = dbbuild.open_db(a.database)
+    if a.list:      # metamlst-index.py:80-86
+        for key, label in mdb.db_getOrganisms(conn).items():
+            print(key.ljust(30) + " " * 5 + label.ljust(30))
+        return 0
+    if a.sequences:
+        for f, r in dbbuild.add_sequences(conn, a.sequences.split(",")).items():
+            print("ADDING SEQUENCES %s Added %d seqs (%d skipped)" % (f, r["added"], len(r["skipped"])))
+    if a.typings:
+        for f, r in dbbuild.add_typings(conn, a.typings.split(",")).items():
+            print("%d/%d PROFILES LOADED from %s" % (r["loaded"], r["lines"], f))
+    if a.dump_db:
+        print("%d sequences written to %s" % (dbbuild.dump_db_to_fasta(conn, a.dump_db, a.filter), a.dump_db))
+    conn.commit()
+    conn.close()
+    return 0
 
 
 def run_type(a) -> int:
@@ -112,8 +145,9 @@ def main(argv=None) -> int:
     sub = ap.add_subparsers(dest="cmd", required=True)
     _type_parser(sub)
     _merge_parser(sub)
+    _index_parser(sub)
     a = ap.parse_args(argv)
-    return run_type(a) if a.cmd == "type" else run_merge(a)
+    return {"type": run_type, "merge": run_merge, "index": run_index}[a.cmd](a)
 
 
 if __name__ == "__main__":

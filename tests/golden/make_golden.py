@@ -301,6 +301,65 @@ def part_c(dbpath):
     conn.close()
 
 
+# ------------------------------------------------------------------ part D: metamlst-index.py (FASTA + typings ingest)
+def dump_tables(dbpath):
+    conn = sqlite3.connect(dbpath)
+    out = {t: [list(r) for r in conn.execute("SELECT * FROM %s ORDER BY rowid" % t)] for t in ("organisms", "genes", "alleles", "profiles")}
+    conn.close()
+    return out
+
+
+def part_d(dbpath):
+    rng = np.random.default_rng(5)
+    base = os.path.join(HERE, "dbbuild")
+    if os.path.isdir(base):
+        shutil.rmtree(base)
+    os.makedirs(base)
+
+    def rnd(n):
+        return "".join(rng.choice(list("ACGT"), n))
+
+    recs = []
+    for g, L in (("g1", 60), ("g2", 75)):
+        for a in range(1, 5):
+            recs.append(("spC_%s_%d" % (g, a), rnd(L)))
+    recs.append(("sp-D_hk_1 some description", rnd(40)))
+    recs.append(("spC_g1", rnd(30)))                 # malformed: two parts
+    recs.append(("spC_g+1_3", rnd(30)))              # invalid character in the gene
+    recs.append(("spC_g1_x3", rnd(30)))              # allele not numeric
+    recs.append(("spC_g2_4", rnd(75)))               # same id again inside one file: both are inserted (quirk)
+    recs.append(("spC_g2_7", rnd(75).lower()))       # lower case kept as is
+    with open(os.path.join(base, "a.fasta"), "w") as f:
+        for k, (i, sq) in enumerate(recs):
+            f.write(">" + i + "\n")
+            f.write((sq[:25] + "\n" + sq[25:] + "\n") if k % 2 else sq + "\n")       # multi-line records
+    with open(os.path.join(base, "b.fasta"), "w") as f:
+        f.write(">spC_g1_2\n" + rnd(60) + "\n>spC_g1_9\n" + rnd(60) + "\n>spE_q_1\n" + rnd(50) + "\n")   # first one already present
+    with open(os.path.join(base, "typ.txt"), "w") as f:
+        f.write("@ a comment line\n#spC|Species C label\nST\tg1\tg2\tclonal_complex\n1\t1\t1\tCC1\n2\t2\t1\tCC1\n3\t5\t1\t-\n4\t1\t2\n5\t9\t7\tCC9\n")
+    with open(os.path.join(base, "typ2.txt"), "w") as f:
+        f.write("#sp_E\nST\tq\tspecies\n1\t1\tsomething\n2\t2\tsomething\n")
+    work = tempfile.mkdtemp()
+    for fn in ("a.fasta", "b.fasta", "typ.txt", "typ2.txt"):
+        shutil.copy(os.path.join(base, fn), work)
+    env = dict(os.environ)
+    env["PYTHONPATH"] = STUBS + os.pathsep + REF
+    r = subprocess.run([sys.executable, os.path.join(REF, "metamlst-index.py"), "-d", "new.db", "-s", "a.fasta,b.fasta", "-t", "typ.txt,typ2.txt"],
+                       env=env, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode != 0:
+        raise RuntimeError("reference metamlst-index.py failed: " + r.stderr.decode()[-2000:])
+    json.dump(dump_tables(os.path.join(work, "new.db")), open(os.path.join(base, "expected_tables.json"), "w"), indent=0)
+    lf = os.path.join(work, "metamlst_logfile.log")
+    open(os.path.join(base, "expected_logfile.log"), "wb").write(open(lf, "rb").read() if os.path.exists(lf) else b"")
+    # second run on the same database: everything is already present, profiles are replaced
+    r = subprocess.run([sys.executable, os.path.join(REF, "metamlst-index.py"), "-d", "new.db", "-s", "a.fasta", "-t", "typ.txt"],
+                       env=env, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode != 0:
+        raise RuntimeError("reference metamlst-index.py (2nd run) failed: " + r.stderr.decode()[-2000:])
+    json.dump(dump_tables(os.path.join(work, "new.db")), open(os.path.join(base, "expected_tables_second_run.json"), "w"), indent=0)
+    shutil.rmtree(work)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("needs /root/reference (authoring container only)")
@@ -310,6 +369,7 @@ def main():
     part_a(dbpath)
     part_b(dbpath)
     part_c(dbpath)
+    part_d(dbpath)
     print("golden vectors written under", HERE)
 
 
