@@ -93,6 +93,12 @@ int mlst_load_reference(mlst_handle* h, const uint8_t* ascii_concat, const uint6
 int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uint8_t* quals,
                       const uint64_t* off, uint64_t n_reads, int paired);
 
+/* Pass 1 straight from FASTQ TEXT (uncompressed, 4 lines per record, LF or CRLF) held in host memory: the bytes
+ * cross PCIe once and are parsed on the GPU (line starts by block newline counts + scan, then packed).  The chunk
+ * must hold whole records (cut it after a multiple of four lines).  Replaces the FASTQ reader in front of
+ * bowtie2 [NOT IN TREE].  n_reads_out (optional) receives the number of records found. */
+int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int paired, uint64_t* n_reads_out);
+
 /* Same, with the three arrays already in DEVICE memory (GPU-side FASTQ decode feeds this). */
 int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
                              const uint64_t* d_off, uint64_t n_reads, uint32_t max_len, int paired);

@@ -17,7 +17,7 @@ import time
 
 from . import db as mdb
 from .engine import Engine, default_params
-from .fastq import interleave, read_batches
+from .fastq import text_chunks
 from .index import load_index
 from .merge import EngineMatcher, merge_folder
 from .typing import TypingArgs, log_table, sample_name, type_sample
@@ -100,9 +100,11 @@ def run_type(a) -> int:
     prm.minscore, prm.max_xm, prm.min_read_len = a.minscore, a.max_xM, a.min_read_len
     eng = Engine(a.device, prm)
     eng.load_reference(idx)
-    batches = interleave(a.READS, a.mates) if a.mates else read_batches(a.READS)
-    for bases, quals, off, _ in batches:
-        eng.submit_reads(bases, quals, off, paired=bool(a.mates))
+    # FASTQ text goes to the GPU as is and is parsed there (mlst_submit_fastq).  Mates are unpaired reads for this
+    # pipeline (bowtie2 -U), so a second file is simply submitted after the first.
+    for path in [a.READS] + ([a.mates] if a.mates else []):
+        for chunk in text_chunks(path):
+            eng.submit_fastq(chunk, paired=False)
     st = eng.stats()
     targs = TypingArgs(penalty=a.penalty, minscore=a.minscore, max_xM=a.max_xM, min_read_len=a.min_read_len,
                        min_accuracy=a.min_accuracy, nloci=a.nloci, a=a.a, quiet=a.quiet, filter=a.filter, log=a.log)

@@ -387,6 +387,94 @@ __device__ inline u32 wave_excl_scan_u32(u32 v, u32& total) {      // exclusive 
 __device__ inline u64 wave_sum_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 __device__ inline u64 wave_min_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) { u64 w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
 __device__ inline u32 wave_sum_u32(u32 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+// ------------------------------------------------------------------ FASTQ text -> packed reads (GPU parser)
+#define FQ_BLOCK 4096        // bytes of text per workgroup
+// pass A: newlines per FQ_BLOCK bytes
+__global__ __launch_bounds__(256) void k_fq_count(const u8* __restrict__ text, u64 n_bytes, u32* __restrict__ blk_count) {
+    __shared__ u32 s_c[4];
+    u64 base = (u64)blockIdx.x * FQ_BLOCK; u32 c = 0;
+    for (u32 i = threadIdx.x; i < FQ_BLOCK; i += 256) { u64 p = base + i; if (p < n_bytes && text[p] == '\n') c++; }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+// pass B: exclusive scan of the block counts (one workgroup; n_blocks is small: 4 GB of text = 1 M blocks)
+__global__ __launch_bounds__(1024) void k_fq_scan(u32* __restrict__ blk_count, u32 n_blocks, u64* __restrict__ n_lines_out, u64 n_bytes, const u8* __restrict__ text) {
+    __shared__ u64 s_part[1024];
+    u32 per = (n_blocks + 1023) / 1024; u32 lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    u64 sum = 0; for (u32 i = lo; i < hi; i++) sum += blk_count[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { u64 run = 0; for (int i = 0; i < 1024; i++) { u64 t = s_part[i]; s_part[i] = run; run += t; }
+                            // a last line without a trailing newline still counts as a line
+                            *n_lines_out = run + ((n_bytes > 0 && text[n_bytes - 1] != '\n') ? 1 : 0); }
+    __syncthreads();
+    u64 run = s_part[threadIdx.x];
+    for (u32 i = lo; i < hi; i++) { u32 t = blk_count[i]; blk_count[i] = (u32)run; run += t; }     // < 2^32 lines per chunk (checked on the host)
+}
+// pass C: start offset of every line: line 0 starts at 0, line k+1 starts after the k-th newline
+__global__ __launch_bounds__(256) void k_fq_lines(const u8* __restrict__ text, u64 n_bytes, const u32* __restrict__ blk_excl, u64* __restrict__ line_start) {
+    __shared__ u32 s_w[4];
+    u64 base = (u64)blockIdx.x * FQ_BLOCK; u32 run = blk_excl[blockIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0;
+    for (u32 i0 = 0; i0 < FQ_BLOCK; i0 += 256) {
+        u64 p = base + i0 + threadIdx.x; bool nl = p < n_bytes && text[p] == '\n';
+        u64 m = __ballot(nl); int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) s_w[wv] = (u32)__popcll(m);
+        __syncthreads();
+        u32 before = 0; for (int w = 0; w < wv; w++) before += s_w[w];
+        if (nl) line_start[(u64)run + before + __popcll(m & ((1ull << lane) - 1)) + 1] = p + 1;
+        run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+// pass D: per record the byte ranges of the sequence line (4r+1) and the quality line (4r+3); CR stripped
+__global__ __launch_bounds__(256) void k_fq_records(const u8* __restrict__ text, u64 n_bytes, const u64* __restrict__ line_start, u64 n_lines, u64 n_reads,
+                                                     u64* __restrict__ seq_off, u64* __restrict__ qual_off, u16* __restrict__ lens, u32* __restrict__ flags /* [0]=max len, [1]=errors */) {
+    u32 mx = 0, err = 0;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (u64)gridDim.x * blockDim.x) {
+        u64 s0 = line_start[4 * r + 1], s1 = line_start[4 * r + 2], q0 = line_start[4 * r + 3];
+        u64 se = s1 - 1;
+        u64 qe = (4 * r + 4 < n_lines) ? line_start[4 * r + 4] - 1 : n_bytes;      // last record: up to the end of the chunk ...
+        if (qe > q0 && text[qe - 1] == '\n') qe--;                                 // ... minus its newline when there is one
+        if (se > s0 && text[se - 1] == '\r') se--;
+        if (qe > q0 && text[qe - 1] == '\r') qe--;
+        u64 ls = se - s0, lq = qe - q0;
+        if (text[line_start[4 * r]] != '@' || ls != lq) err = 1;
+        if (ls > MLST_MAX_READ_LEN) { err |= 2; ls = MLST_MAX_READ_LEN; }
+        seq_off[r] = s0; qual_off[r] = q0; lens[r] = (u16)ls;
+        if ((u32)ls > mx) mx = (u32)ls;
+    }
+    if (mx) atomicMax(&flags[0], mx);
+    if (err) atomicOr(&flags[1], err);
+}
+// pack from text: same output format as k_pack, reads addressed by separate sequence / quality offsets
+__global__ __launch_bounds__(256) void k_pack_text(const u8* __restrict__ text, const u64* __restrict__ seq_off, const u64* __restrict__ qual_off,
+                                                    u16* __restrict__ lens, u64 n_reads, u32* __restrict__ packed, u8* __restrict__ qrows, u32 wpr, u32 qstride) {
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 total = n_reads * wpr;
+    for (; gid < total; gid += (u64)gridDim.x * blockDim.x) {
+        u64 r = gid / wpr; u32 w = (u32)(gid - r * wpr);
+        u64 so = seq_off[r], qo = qual_off[r]; u32 n = lens[r] & 0x7FFFu;
+        u32 word = 0; u32 anyn = 0;
+        for (int k = 0; k < 16; k++) {
+            u32 i = w * 16 + k;
+            if (i < n) {
+                u8 c = text[so + i]; u32 b; u32 isn = 0;
+                switch (c) { case 'A': case 'a': b = 0; break; case 'C': case 'c': b = 1; break;
+                             case 'G': case 'g': b = 2; break; case 'T': case 't': b = 3; break; default: b = 0; isn = 1; }
+                word |= b << (2 * k);
+                int q = (int)text[qo + i] - 33; q = q < 0 ? 0 : (q > 127 ? 127 : q);
+                if (i < qstride) qrows[r * qstride + i] = (u8)q | (u8)(isn << 7);
+                anyn |= isn;
+            } else if (i < qstride) qrows[r * qstride + i] = 0;
+        }
+        packed[gid] = word;
+        if (anyn) atomicOr((u32*)(lens + (r & ~1ull)), (r & 1) ? 0x80000000u : 0x00008000u);
+    }
+}
+
 // ------------------------------------------------------------------ K2: exact seeds -> work items
 struct Bin { u32 locus; int diag; u16 strand, votes; };
 
@@ -1143,6 +1231,8 @@ struct mlst_handle {
     u8* d_in_bases = nullptr; u8* d_in_quals = nullptr; u64* d_in_off = nullptr; u64 cap_in_bytes = 0, cap_in_reads = 0;
     u32* d_packed = nullptr; u8* d_qrows = nullptr; u16* d_lens = nullptr; u64 cap_packed_words = 0, cap_qrow_bytes = 0, cap_lens = 0;
     u64 reads_seen = 0;
+    u8* d_fq_text = nullptr; u64 cap_fq_text = 0; u32* d_fq_blk = nullptr; u64 cap_fq_blk = 0;
+    u64* d_fq_lines = nullptr; u64 cap_fq_lines = 0; u64* d_fq_soff = nullptr; u64* d_fq_qoff = nullptr; u64 cap_fq_reads = 0; u64* d_fq_meta = nullptr;
     // pileup scratch
     int* d_locus_chosen = nullptr; u64* d_locus_colbase = nullptr; u64* d_pl_list = nullptr; u8* d_tb = nullptr;
     u32* d_counts = nullptr; u64 cap_counts = 0;
@@ -1255,6 +1345,7 @@ extern "C" void mlst_destroy(mlst_handle* h) {
     free_ref(h); free_state(h);
     if (h->h_pin) hipHostFree(h->h_pin);
     hipFree(h->d_cand); hipFree(h->d_in_bases); hipFree(h->d_in_quals); hipFree(h->d_in_off);
+    hipFree(h->d_fq_text); hipFree(h->d_fq_blk); hipFree(h->d_fq_lines); hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); hipFree(h->d_fq_meta);
     hipFree(h->d_packed); hipFree(h->d_qrows); hipFree(h->d_lens); hipFree(h->d_counts); hipFree(h->d_dist); hipFree(h->d_query);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1574,6 +1665,62 @@ extern "C" int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uin
     HIPCHK(h, hipMemcpy(h->d_in_quals, quals + off[0], nbytes, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_in_off, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
     return mlst_submit_reads_device(h, h->d_in_bases, h->d_in_quals, (const uint64_t*)h->d_in_off, n_reads, max_len, paired);
+}
+
+extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int paired, uint64_t* n_reads_out) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (n_reads_out) *n_reads_out = 0;
+    if (n_bytes == 0) return MLST_OK;
+    if (!text) return fail(h, MLST_E_INVALID, "NULL argument");
+    if (n_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
+    hipSetDevice(h->device);
+    const u64 n_blocks = (n_bytes + FQ_BLOCK - 1) / FQ_BLOCK;
+    hipStreamSynchronize(h->stream);     // the previous chunk may still be read
+    if (h->cap_fq_text < n_bytes) { hipFree(h->d_fq_text); h->d_fq_text = nullptr; HIPCHK(h, dmalloc(&h->d_fq_text, n_bytes + 16)); h->cap_fq_text = n_bytes; }
+    if (h->cap_fq_blk < n_blocks) { hipFree(h->d_fq_blk); h->d_fq_blk = nullptr; HIPCHK(h, dmalloc(&h->d_fq_blk, n_blocks + 1)); h->cap_fq_blk = n_blocks; }
+    if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
+    HIPCHK(h, hipMemcpyAsync(h->d_fq_text, text, n_bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_fq_meta, 0, 32, h->stream));
+    Prof pf(h, 6);
+    hipLaunchKernelGGL(k_fq_count, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_blk);
+    hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, h->stream, h->d_fq_blk, (u32)n_blocks, h->d_fq_meta, (u64)n_bytes, h->d_fq_text);
+    u64 n_lines = 0;
+    HIPCHK(h, hipMemcpyAsync(&n_lines, h->d_fq_meta, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_lines >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "more than 2^32 lines in one FASTQ chunk");
+    if (n_lines % 4 != 0) return fail(h, MLST_E_INVALID, "FASTQ chunk holds %llu lines: not a whole number of 4-line records", (unsigned long long)n_lines);
+    const u64 n_reads = n_lines / 4;
+    if (n_reads == 0) return MLST_OK;
+    if (h->cap_fq_lines < n_lines + 2) { hipFree(h->d_fq_lines); h->d_fq_lines = nullptr; HIPCHK(h, dmalloc(&h->d_fq_lines, n_lines + 2)); h->cap_fq_lines = n_lines + 2; }
+    if (h->cap_fq_reads < n_reads) { hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); h->d_fq_soff = h->d_fq_qoff = nullptr;
+                                     HIPCHK(h, dmalloc(&h->d_fq_soff, n_reads)); HIPCHK(h, dmalloc(&h->d_fq_qoff, n_reads)); h->cap_fq_reads = n_reads; }
+    // lengths are needed before the packed buffers can be sized: worst-case row width first, then the real one
+    int rc = ensure_pack_buffers(h, n_reads, 2, 8); if (rc) return rc;
+    u32* d_flags = reinterpret_cast<u32*>(h->d_fq_meta + 1);
+    hipLaunchKernelGGL(k_fq_lines, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_blk, h->d_fq_lines);
+    hipLaunchKernelGGL(k_fq_records, dim3(grid_for(n_reads, 256)), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_lines, n_lines, n_reads,
+                       h->d_fq_soff, h->d_fq_qoff, h->d_lens, d_flags);
+    u32 flags[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (flags[1] & 2) return fail(h, MLST_E_LIMIT, "a FASTQ read is longer than %d bases", MLST_MAX_READ_LEN);
+    if (flags[1] & 1) return fail(h, MLST_E_INVALID, "malformed FASTQ: a record does not start with '@' or its sequence and quality lengths differ");
+    u32 max_len = flags[0];
+    u32 wpr = (max_len + 15) / 16; if (wpr < 2) wpr = 2; wpr = (wpr + 1) & ~1u;
+    u32 qstride = (max_len + 7) & ~7u; if (qstride < 8) qstride = 8;
+    {   // k_fq_records wrote the lengths into d_lens; growing the pack buffers must keep them
+        std::vector<u16> keep;
+        if (h->cap_packed_words < n_reads * wpr + 4 || h->cap_qrow_bytes < n_reads * qstride) {
+            keep.resize(n_reads); HIPCHK(h, hipMemcpy(keep.data(), h->d_lens, n_reads * 2, hipMemcpyDeviceToHost));
+            rc = ensure_pack_buffers(h, n_reads, wpr, qstride); if (rc) return rc;
+            HIPCHK(h, hipMemcpy(h->d_lens, keep.data(), n_reads * 2, hipMemcpyHostToDevice));
+        }
+    }
+    hipLaunchKernelGGL(k_pack_text, dim3(grid_for(n_reads * wpr, 256, 8192)), dim3(256), 0, h->stream, h->d_fq_text, h->d_fq_soff, h->d_fq_qoff,
+                       h->d_lens, n_reads, h->d_packed, h->d_qrows, wpr, qstride);
+    HIPCHK(h, hipGetLastError());
+    if (n_reads_out) *n_reads_out = n_reads;
+    return mlst_submit_packed_device(h, h->d_packed, h->d_qrows, h->d_lens, n_reads, wpr, qstride, paired);
 }
 
 // one D2H copy of the whole statistics block into pinned memory, one synchronisation

@@ -77,6 +77,7 @@ def load_library(path: str | None = None):
         "mlst_last_error": (C.c_char_p, [H]),
         "mlst_load_reference": (C.c_int, [H, u8p, u64p, u32p, u32p, i32p, C.c_uint32]),
         "mlst_submit_reads": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_int]),
+        "mlst_submit_fastq": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
         "mlst_submit_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_int]),
         "mlst_pack_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, u32p, u8p, u16p, C.c_uint32, C.c_uint32]),
         "mlst_submit_packed_device": (C.c_int, [H, u32p, u8p, u16p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
@@ -157,6 +158,13 @@ class Engine:
         off = np.ascontiguousarray(off, dtype=np.uint64)
         self._check(self.lib.mlst_submit_reads(self._h, _ptr(bases), _ptr(quals), _ptr(off), len(off) - 1, int(paired)),
                     "mlst_submit_reads")
+
+    def submit_fastq(self, text, paired: bool = False) -> int:
+        """Pass 1 straight from FASTQ text (bytes / bytearray / uint8 array holding whole 4-line records); parsed on the GPU."""
+        buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+        n = C.c_uint64()
+        self._check(self.lib.mlst_submit_fastq(self._h, _ptr(buf) if buf.size else None, buf.size, int(paired), C.byref(n)), "mlst_submit_fastq")
+        return int(n.value)
 
     def submit_reads_device(self, d_bases: int, d_quals: int, d_off: int, n_reads: int, max_len: int, paired: bool = False):
         self._check(self.lib.mlst_submit_reads_device(self._h, d_bases, d_quals, d_off, n_reads, max_len, int(paired)),

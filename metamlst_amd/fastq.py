@@ -53,3 +53,27 @@ def interleave(path1: str, path2: str, batch_pairs: int = 1_000_000, max_len: in
             seqs += [b1[int(o1[k]):int(o1[k + 1])].tobytes(), b2[int(o2[k]):int(o2[k + 1])].tobytes()]
             quals += [q1[int(o1[k]):int(o1[k + 1])].tobytes(), q2[int(o2[k]):int(o2[k + 1])].tobytes()]
         yield _pack(seqs, quals, [x for p in zip(n1, n2) for x in p])
+
+
+def text_chunks(path: str, chunk_bytes: int = 256 << 20):
+    """Yield byte chunks of an uncompressed (or .gz) FASTQ that each hold whole records, for Engine.submit_fastq.
+    The only host work is cutting after a multiple of four lines; parsing happens on the GPU."""
+    carry = b""
+    lines_in_carry = 0
+    with _open(path) as f:
+        while True:
+            block = f.read(chunk_bytes)
+            if not block:
+                break
+            data = carry + block
+            arr = np.frombuffer(data, np.uint8)
+            nl = np.flatnonzero(arr == 10)
+            whole = (len(nl) // 4) * 4
+            if whole == 0:
+                carry = data
+                continue
+            cut = int(nl[whole - 1]) + 1
+            yield data[:cut]
+            carry = data[cut:]
+    if carry.strip():
+        yield carry

@@ -38,3 +38,20 @@ for _ in range(5):
 t = float(np.median(ts))
 print(json.dumps({"entry": "mlst_submit_reads (pageable host ASCII bases + quals, 300 B/read over PCIe)", "reads": 4_000_000,
                   "ms": round(t * 1e3, 2), "Mreads_per_s": round(4.0 / t, 1), "GB_per_s_host_to_device": round(4e6 * 300 / t / 1e9, 1)}))
+
+# FASTQ text parsed on the GPU (mlst_submit_fastq): the bytes of the file cross PCIe once
+text = b"".join(b"@r%d\n" % k + b[k].tobytes() + b"\n+\n" + q[k].tobytes() + b"\n" for k in range(1_000_000))
+buf = np.frombuffer(text, np.uint8)
+eng.reset_sample()
+eng.submit_fastq(buf)
+eng.stats()
+ts = []
+for _ in range(5):
+    eng.reset_sample()
+    t0 = time.perf_counter()
+    eng.submit_fastq(buf)
+    eng.stats()
+    ts.append(time.perf_counter() - t0)
+t = float(np.median(ts))
+print(json.dumps({"entry": "mlst_submit_fastq (FASTQ text in pageable host memory, parsed on the GPU)", "reads": 1_000_000, "text_bytes": len(text),
+                  "ms": round(t * 1e3, 2), "Mreads_per_s": round(1.0 / t, 1), "GB_per_s_host_to_device": round(len(text) / t / 1e9, 1)}))

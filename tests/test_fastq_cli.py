@@ -48,3 +48,52 @@ def test_cli_type_then_merge_end_to_end():
     assert main(["merge", d + "/out", "-d", db.path]) == 0
     rep = open(d + "/out/merged/ecoli_report.txt").read().splitlines()
     assert rep[0].startswith("ST\tConfidence") and rep[1].split("\t") == ["7", "100.0", "iso7"]
+
+
+@pytest.mark.gpu
+def test_gpu_fastq_parser_equals_host_parser():
+    """mlst_submit_fastq (FASTQ text parsed on the GPU) gives the statistics of the host-parsed path: LF and CRLF,
+    with and without a final newline, ragged lengths, N bases, several chunks."""
+    from metamlst_amd.engine import Engine, MlstError
+    from metamlst_amd.fastq import text_chunks
+    import fixtures as fx2
+    db, idx = fx2.ecoli_small(40)
+    rng = np.random.default_rng(3)
+    g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][2], size=60_000)
+    recs = []
+    for k in range(5000):
+        L = int(rng.choice([150, 150, 101, 75, 36, 250, 320, 1]))
+        at = int(rng.integers(0, len(g) - L))
+        r = bytearray(g[at:at + L].tobytes())
+        if k % 7 == 0 and L > 5:
+            r[int(rng.integers(L))] = ord("N")
+        q = bytes((rng.integers(2, 42, size=L)).astype(np.uint8) + 33)
+        recs.append((b"r%d some comment" % k, bytes(r), q))
+    eng = Engine(0)
+    eng.load_reference(idx)
+    eng.submit_reads(*synth.ragged_reads([r for _, r, _ in recs], [q for _, _, q in recs]))
+    want = eng.stats()
+    want_items = fx2.sorted_items(eng.items(1 << 16))
+    d = tempfile.mkdtemp()
+    for eol, final in ((b"\n", True), (b"\r\n", True), (b"\n", False)):
+        text = eol.join(b"@" + n + eol + r + eol + b"+" + eol + q for n, r, q in recs) + (eol if final else b"")
+        eng.reset_sample()
+        assert eng.submit_fastq(text) == len(recs)
+        fx2.assert_stats_equal(eng.stats(), want)
+        assert np.array_equal(fx2.sorted_items(eng.items(1 << 16)), want_items)
+    # chunked through the file helper (chunks cut after whole records), read indices continue across chunks
+    path = d + "/x.fastq"
+    open(path, "wb").write(b"\n".join(b"@" + n + b"\n" + r + b"\n+\n" + q for n, r, q in recs) + b"\n")
+    eng.reset_sample()
+    n = sum(eng.submit_fastq(c) for c in text_chunks(path, chunk_bytes=200_000))
+    assert n == len(recs)
+    fx2.assert_stats_equal(eng.stats(), want)
+    # malformed input is refused
+    eng.reset_sample()
+    with pytest.raises(MlstError, match="4-line records"):
+        eng.submit_fastq(b"@a\nACGT\n+\n")
+    with pytest.raises(MlstError, match="malformed FASTQ"):
+        eng.submit_fastq(b"@a\nACGT\n+\nIII\n")
+    with pytest.raises(MlstError, match="longer than 320"):
+        eng.submit_fastq(b"@a\n" + b"A" * 400 + b"\n+\n" + b"I" * 400 + b"\n")
+    assert eng.submit_fastq(b"") == 0
