@@ -87,7 +87,8 @@ __host__ __device__ inline u64 canon40(u64 s, u32& flag) {
     u64 r = revcomp40(s); flag = r < s ? 1u : 0u; return flag ? r : s;
 }
 #define BITMAP_BITS 20                  // LDS first-level filter: 2^20 bits = 128 KiB
-__host__ __device__ inline u32 bitmap_hash(u32 lo, u32 hi) { u32 t = seed_premix(lo, hi); t ^= t >> 13; return (t * 0xC2B2AE35u) >> (32 - BITMAP_BITS); }
+__host__ __device__ inline u32 bitmap_hash_bits(u32 lo, u32 hi, u32 bits) { u32 t = seed_premix(lo, hi); t ^= t >> 13; return (t * 0xC2B2AE35u) >> (32 - bits); }
+__host__ __device__ inline u32 bitmap_hash(u32 lo, u32 hi) { return bitmap_hash_bits(lo, hi, BITMAP_BITS); }
 
 // ------------------------------------------------------------------ device-side views
 struct LocusDev {
@@ -121,7 +122,8 @@ struct EngineDev {
     // reference
     const u32* arena; const u32* nmask; const u16* allele_len; const u32* allele_locus; const LocusDev* loci;
     const uint4* sieve; u32 sieve_mask;
-    const u32* bitmap;        // first-level 2^20-bit filter (nullptr when the database is too large for it to be selective)
+    const u32* bitmap;        // first-level 2^20-bit filter kept in LDS (nullptr when the database is too large for it to be selective)
+    const u32* gbitmap; u32 gbitmap_bits;   // larger first-level filter in global memory (L2 resident) for big databases
     const u64* keys; const u32* vals; const u32* posts; u32 table_mask;
     const int* floor_tab; const u8* pen_tab;
     u32 n_alleles, n_loci;
@@ -200,7 +202,7 @@ __device__ inline bool bucket_has(uint4 b, u32 fp, bool& full) {
 // probe a harmless bucket and are masked), so a lane has WPR-1 independent 16-byte loads in flight.
 template <int WPR>
 __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
-                                                const uint4* __restrict__ sieve, u32 smask,
+                                                const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ gbm, u32 gbm_bits,
                                                 u32* __restrict__ cand, Counters* __restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) u32 s_rows[256 * WPR];
     const u32 sshift = (u32)__clz((int)smask);       // buckets = smask + 1 = 2^(32 - sshift)
@@ -238,10 +240,23 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             u32 klo[NT], khi[NT];
             #pragma unroll
             for (int t = 0; t < NT; t++) { u32 fl; u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl); klo[t] = (u32)c; khi[t] = (u32)(c >> 32); }
+            // optional first level for big databases: a bitmap in global memory that mostly lives in L2, so that
+            // only seeds whose bit is set go to the (much larger, Infinity-Cache resident) fingerprint sieve
+            u32 pass = nseeds >= 32 ? 0xFFFFFFFFu : ((1u << nseeds) - 1u);
+            if (gbm) {
+                u32 gw[NT], gi[NT];
+                #pragma unroll
+                for (int t = 0; t < NT; t++) { gi[t] = bitmap_hash_bits(klo[t], khi[t], gbm_bits); gw[t] = gbm[gi[t] >> 5]; }
+                tie_all<NT>(gw);
+                #pragma unroll
+                for (int t = 0; t < NT; t++) if (!((gw[t] >> (gi[t] & 31)) & 1u)) pass &= ~(1u << t);
+            }
             v4u bv[NT];
             #pragma unroll
-            for (int t = 0; t < NT; t++)
-                bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) >> sshift];
+            for (int t = 0; t < NT; t++) {
+                bv[t] = v4u{0u, 0u, 0u, 0u};
+                if ((pass >> t) & 1u) bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) >> sshift];
+            }
             tie_all<NT>(bv);
             uint4 b[NT];
             #pragma unroll
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             #pragma unroll
             for (int t = 0; t < NT; t++) {
                 bool full; bool f = bucket_has(b[t], sieve_fp(klo[t], khi[t]), full);
-                bool valid = t < nseeds;
+                bool valid = (pass >> t) & 1u;
                 hit |= valid && f;
                 pending |= (valid && !f && full) ? (1u << t) : 0u;
             }
@@ -1221,7 +1236,7 @@ struct mlst_handle {
     std::vector<u32> allele_locus;
     // device memory
     u32* d_arena = nullptr; u32* d_nmask = nullptr; u16* d_allele_len = nullptr; u32* d_allele_locus = nullptr;
-    LocusDev* d_loci = nullptr; uint4* d_sieve = nullptr; u32* d_bitmap = nullptr; u64* d_keys = nullptr; u32* d_vals = nullptr; u32* d_posts = nullptr;
+    LocusDev* d_loci = nullptr; uint4* d_sieve = nullptr; u32* d_bitmap = nullptr; u32* d_gbitmap = nullptr; u64* d_keys = nullptr; u32* d_vals = nullptr; u32* d_posts = nullptr;
     int* d_floor = nullptr; u8* d_pen = nullptr; u8* d_ascii = nullptr; u64* d_aoff = nullptr;
     u64 bytes_arena = 0, bytes_sieve = 0, bytes_table = 0;
     EngineDev E; EngineDev* d_E = nullptr;      // host copy and its device-resident twin
@@ -1317,7 +1332,7 @@ extern "C" int mlst_create(int device, const mlst_params* p, mlst_handle** out) 
 
 static void free_ref(mlst_handle* h) {
     hipFree(h->d_arena); hipFree(h->d_nmask); hipFree(h->d_allele_len); hipFree(h->d_allele_locus); hipFree(h->d_loci);
-    hipFree(h->d_sieve); hipFree(h->d_bitmap); h->d_bitmap = nullptr; hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
+    hipFree(h->d_sieve); hipFree(h->d_bitmap); h->d_bitmap = nullptr; hipFree(h->d_gbitmap); h->d_gbitmap = nullptr; hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
     hipFree(h->d_ascii); hipFree(h->d_aoff);
     h->d_arena = h->d_nmask = nullptr; h->d_allele_len = nullptr; h->d_allele_locus = nullptr; h->d_loci = nullptr; h->d_sieve = nullptr;
     h->d_keys = nullptr; h->d_vals = h->d_posts = nullptr; h->d_floor = nullptr; h->d_pen = nullptr; h->d_ascii = nullptr; h->d_aoff = nullptr;
@@ -1486,6 +1501,16 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
             for (u64 i = 0; i < nk; i++) { u32 bi = bitmap_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32)); bitmap[bi >> 5] |= 1u << (bi & 31); }
         }
     }
+    // ---- larger first-level bitmap in global memory when the LDS one is not used (big databases)
+    std::vector<u32> gbitmap; u32 gbits = 0;
+    if (bitmap.empty() && nk > 0) {
+        const char* gsw = getenv("MLST_GBM_BITS");            // tuning switch: 0 disables, default 25 (4 MiB)
+        gbits = gsw ? (u32)atoi(gsw) : 25u;
+        if (gbits >= 16 && gbits <= 31 && nk <= (1ull << gbits)) {      // keep the expected fill below ~63 %
+            gbitmap.assign((1ull << gbits) / 32, 0);
+            for (u64 i = 0; i < nk; i++) { u32 bi = bitmap_hash_bits((u32)ukeys[i], (u32)(ukeys[i] >> 32), gbits); gbitmap[bi >> 5] |= 1u << (bi & 31); }
+        } else gbits = 0;
+    }
     // ---- tables derived from the parameters
     std::vector<int> floor_tab(MLST_MAX_READ_LEN + 1);
     for (int n = 0; n <= MLST_MAX_READ_LEN; n++) {
@@ -1502,6 +1527,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_loci, (u64)n_loci)); HIPCHK(h, hipMemcpy(h->d_loci, loci.data(), (u64)n_loci * sizeof(LocusDev), hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_sieve, nb)); HIPCHK(h, hipMemcpy(h->d_sieve, sv.data(), nb * 16, hipMemcpyHostToDevice));
     if (!bitmap.empty()) { HIPCHK(h, dmalloc(&h->d_bitmap, (u64)bitmap.size())); HIPCHK(h, hipMemcpy(h->d_bitmap, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice)); }
+    if (!gbitmap.empty()) { HIPCHK(h, dmalloc(&h->d_gbitmap, (u64)gbitmap.size())); HIPCHK(h, hipMemcpy(h->d_gbitmap, gbitmap.data(), gbitmap.size() * 4, hipMemcpyHostToDevice)); }
     HIPCHK(h, dmalloc(&h->d_keys, tcap)); HIPCHK(h, hipMemcpy(h->d_keys, tkeys.data(), tcap * 8, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_vals, tcap)); HIPCHK(h, hipMemcpy(h->d_vals, tvals.data(), tcap * 4, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_posts, (u64)posts.size())); if (!posts.empty()) HIPCHK(h, hipMemcpy(h->d_posts, posts.data(), posts.size() * 4, hipMemcpyHostToDevice));
@@ -1510,12 +1536,12 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     u64 abytes = off[n_alleles];
     HIPCHK(h, dmalloc(&h->d_ascii, abytes)); if (abytes) HIPCHK(h, hipMemcpy(h->d_ascii, ascii, abytes, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_aoff, (u64)n_alleles + 1)); HIPCHK(h, hipMemcpy(h->d_aoff, off, ((u64)n_alleles + 1) * 8, hipMemcpyHostToDevice));
-    h->bytes_arena = arena.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
+    h->bytes_arena = arena.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
     h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
     // ---- sample state
     EngineDev& E = h->E;
     E.arena = h->d_arena; E.nmask = h->d_nmask; E.allele_len = h->d_allele_len; E.allele_locus = h->d_allele_locus; E.loci = h->d_loci;
-    E.sieve = h->d_sieve; E.sieve_mask = smask; E.bitmap = h->d_bitmap; E.keys = h->d_keys; E.vals = h->d_vals; E.posts = h->d_posts; E.table_mask = tmask;
+    E.sieve = h->d_sieve; E.sieve_mask = smask; E.bitmap = h->d_bitmap; E.gbitmap = h->d_gbitmap; E.gbitmap_bits = gbitmap.empty() ? 0 : gbits; E.keys = h->d_keys; E.vals = h->d_vals; E.posts = h->d_posts; E.table_mask = tmask;
     E.floor_tab = h->d_floor; E.pen_tab = h->d_pen; E.n_alleles = n_alleles; E.n_loci = n_loci;
     E.cap_ret = h->prm.max_retained_reads; E.cap_items = h->prm.max_items; E.cap_res = h->prm.max_pair_results; E.cap_dp = h->prm.max_items * 4;
     {   // statistics live in ONE device block so that a sample needs one memset pair and one D2H copy
@@ -1602,7 +1628,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       } else {
         u64 nblk = (n_reads + 255) / 256;
         dim3 grid(grid_for(nblk, 1, 256 * 8)), block(256);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_sieve<W>, grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, h->d_cand, E.ctr); break;
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_sieve<W>, grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.gbitmap, E.gbitmap_bits, h->d_cand, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE

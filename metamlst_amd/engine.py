@@ -64,6 +64,13 @@ def load_library(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # The PyTorch ROCm wheel bundles its own HIP / HSA runtime, this library links the system one.  Both can live in
+    # one process only if torch's runtime initialises first ("No HIP GPUs are available" otherwise), so when torch
+    # is installed it is imported before the engine is loaded.  torch is not needed by the engine itself.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(path):
         raise MlstError("HIP engine library not built: %s is missing (run __graft_entry__.build()); "
                         "there is no CPU fallback" % path)

@@ -331,3 +331,16 @@ def test_error_codes_capacity_and_limits():
     p.band_w = 40
     with pytest.raises(MlstError, match="band_w"):
         Engine(0, p)
+
+
+def test_plain_sieve_with_global_bitmap_and_without(monkeypatch):
+    """Big-database sieve variants on a small database: plain kernel with the global first-level bitmap
+    (forced small so that it is selective) and with it disabled."""
+    db, idx = fx.ecoli_small(80)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 8, n_reads=9000)
+    monkeypatch.setenv("MLST_NO_LDS_SIEVE", "1")
+    for bits in ("18", "25", "0"):
+        monkeypatch.setenv("MLST_GBM_BITS", bits)
+        eng, orc = both(idx)
+        s, _ = run_both(eng, orc, fb, fq, off)
+        check_pileup(eng, orc, idx, s)
