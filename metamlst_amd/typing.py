@@ -100,21 +100,35 @@ def pick_alleles_fast(index: AlleleIndex, st: SampleStats, penalty: int) -> dict
     average is round(max x); only alleles with x within 0.11 of the maximum can tie with it, and
     those few are rounded with Python's own round().  Array operations run over all loci together
     (alleles of a locus are contiguous in the index)."""
-    nh = st.n_hits.astype(np.int64)
-    if nh.size == 0:
+    if st.n_hits.size == 0:
         return {}
-    begins, lid = index.locus_begin_ip, index.locus_id_ip
+    hl = np.nonzero(st.locus_first != NO_READ)[0]                  # loci with an accepted record
+    if hl.size == 0:
+        return {}
+    if hl.size == index.n_loci:                                    # every locus hit: work on the arrays as they are
+        sel = None
+        nh = st.n_hits.astype(np.int64)
+        ssum = st.sum_score
+        begins, lid = index.locus_begin_ip, index.locus_id_ip
+    else:                                                          # metagenome against a big database: only the hit loci
+        counts = index.locus_count[hl].astype(np.intp)
+        begins = np.concatenate(([0], np.cumsum(counts)[:-1])).astype(np.intp)
+        lid = np.repeat(np.arange(hl.size, dtype=np.intp), counts)
+        sel = np.repeat(index.locus_begin_ip[hl] - begins, counts) + np.arange(int(counts.sum()), dtype=np.intp)
+        nh = st.n_hits[sel].astype(np.int64)
+        ssum = st.sum_score[sel]
     maxlen = np.maximum.reduceat(nh, begins)                       # per locus: max hits over its alleles
-    local = st.sum_score - (maxlen[lid] - nh) * penalty            # metamlst.py:146-147
+    local = ssum - (maxlen[lid] - nh) * penalty                    # metamlst.py:146-147
     x = local / np.maximum(nh, 1)                                  # same IEEE division as float(a)/float(b); alleles without hits excluded below
     x[nh == 0] = -np.inf
     xmax = np.maximum.reduceat(x, begins)
     near = np.nonzero(x >= xmax[lid] - 0.11)[0]
-    near = near[(nh[near] > 0) & (st.locus_first[lid[near]] != NO_READ)]
+    near = near[nh[near] > 0]
     best: dict = {}
-    for a in near.tolist():
-        r = round(float(int(local[a])) / float(int(nh[a])), 1)
-        l = int(lid[a])
+    for k in near.tolist():
+        r = round(float(int(local[k])) / float(int(nh[k])), 1)
+        a = k if sel is None else int(sel[k])
+        l = int(index.locus_id[a])
         no = int(index.allele_no[a])
         cur = best.get(l)
         if cur is None or r > cur[0] or (r == cur[0] and no < cur[1]):
