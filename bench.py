@@ -123,7 +123,7 @@ def main():
         dist.barrier()
     from metamlst_amd import db as mdb
     from metamlst_amd import synth
-    from metamlst_amd.dist import DeviceStatsPort, allreduce_pileup, allreduce_stats, split_counts
+    from metamlst_amd.dist import DeviceStatsPort, allreduce_consensus, allreduce_pileup, allreduce_stats, split_counts
     from metamlst_amd.engine import Engine
     from metamlst_amd.index import load_index
     from metamlst_amd.merge import EngineMatcher, SpeciesSession, parse_nfo_line
@@ -174,8 +174,13 @@ def main():
                 return split_counts(idx, chosen, allreduce_pileup(port, chosen, n_cols, device))
             return eng.pileup(chosen)
 
-        res = type_sample(idx, st, pileup_fn, database, "sample", fast=True, cache=cache,
-                          consensus_fn=eng.consensus if world == 1 else None)
+        def consensus_fn(chosen):
+            if world > 1:
+                n_cols = sum(int(idx.off[a + 1] - idx.off[a]) for a in chosen)
+                return allreduce_consensus(port, idx, chosen, n_cols, device)
+            return eng.consensus(chosen)
+
+        res = type_sample(idx, st, pileup_fn, database, "sample", fast=True, cache=cache, consensus_fn=consensus_fn)
         t_d = time.perf_counter()
         out = {}
         if rank == 0:

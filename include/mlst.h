@@ -154,6 +154,11 @@ int mlst_pileup_device(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32
 int mlst_consensus(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n, uint32_t mincov,
                    char none_char, uint8_t* out_seq, uint32_t* counts);
 
+/* Multi-GPU variant: majority rule over pileup counts that already sit in DEVICE memory (the all-reduced
+ * counts of every rank); out_seq is host memory, n_cols bytes. */
+int mlst_consensus_from_counts_device(mlst_handle* h, const uint32_t* d_counts, uint64_t n_cols, uint32_t mincov,
+                                      char none_char, uint8_t* out_seq);
+
 /* Allele match: Hamming distance of `query` against every allele of `locus`, semantics of
  * stringDiff (metaMLST_functions.py:230-234: zip truncates, length difference not counted),
  * as used by metamlst-merge.py:177-181.  Outputs the first allele (load order) within z,

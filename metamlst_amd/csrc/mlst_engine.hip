@@ -764,12 +764,12 @@ __device__ inline bool accept_rec(const KParams& P, u32 r, int n, bool use_xo) {
 #define EXT_WAVES 4          // waves per SIMD the register allocator must leave room for (swept on MI355X)
 #endif
 template <int NW>
-__global__ __launch_bounds__(256, EXT_WAVES) void k_extend(const EngineDev* __restrict__ Ep, KParams P) {
+__global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ Ep, KParams P) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u32 s_odd[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
-    __shared__ u32 s_cnt[4][3];
-    const int tid = threadIdx.x;
-    if (tid < 128) s_pentab[tid] = E.pen_tab[tid];
+    __shared__ u32 s_cnt[16][3];
+    const int tid = threadIdx.x, nthr = blockDim.x, nwv = blockDim.x >> 6;      // 64..1024 threads per work item
+    for (int i = tid; i < 128; i += nthr) s_pentab[i] = E.pen_tab[i];
     u64 c_tot = 0, c_ign = 0;                     // block-level counters, flushed once at the end (thread 0)
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
     for (u64 ii = begin + blockIdx.x; ii < end; ii += gridDim.x) {
@@ -778,16 +778,16 @@ __global__ __launch_bounds__(256, EXT_WAVES) void k_extend(const EngineDev* __re
         u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu); bool read_has_n = (lw & 0x8000u) != 0;
         u8 state = E.item_state[ii];
         __syncthreads();
-        stage_read(E, P, it, n, s_rw, s_rn, s_odd, s_pen, nullptr, s_pentab, tid, 256);
+        stage_read(E, P, it, n, s_rw, s_rn, s_odd, s_pen, nullptr, s_pentab, tid, nthr);
         if (tid == 0) { s_rw[RW] = s_rw[RW + 1] = 0; }
         __syncthreads();
         if (it.res_off + L.n_pad > E.cap_res) continue;      // flagged by k_seed
         const int floor_n = E.floor_tab[n];
         u32 nrec = 0, ndp = 0;
 #ifdef EXP_NO_ALLELES
-        for (u32 a = tid; a < 0; a += 256) {
+        for (u32 a = tid; a < 0; a += nthr) {
 #else
-        for (u32 a = tid; a < L.n_alleles; a += 256) {
+        for (u32 a = tid; a < L.n_alleles; a += nthr) {
 #endif
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
@@ -811,8 +811,8 @@ __global__ __launch_bounds__(256, EXT_WAVES) void k_extend(const EngineDev* __re
         nrec = wave_sum_u32(nrec); ndp = wave_sum_u32(ndp);
         if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = nrec; s_cnt[tid >> 6][1] = ndp; }
         __syncthreads();
-        u32 tot_rec = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
-        u32 tot_dp = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+        u32 tot_rec = 0, tot_dp = 0;
+        for (int w = 0; w < nwv; w++) { tot_rec += s_cnt[w][0]; tot_dp += s_cnt[w][1]; }
         if (tid == 0 && tot_rec) atomicAdd(&E.ret_nrec[it.ret], tot_rec);   // per-read record count (Q1)
         // Fused accumulation (metamlst.py:101-130) when everything about this read is known here:
         // it has a single work item and no pair is waiting for the banded SW.
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256, EXT_WAVES) void k_extend(const EngineDev* __re
         if ((state & IS_SINGLE) && tot_dp == 0) {
             bool use_xo = P.quirk && tot_rec == 1;
             u32 acc = 0, ign = 0;
-            for (u32 a = tid; a < L.n_alleles; a += 256) {
+            for (u32 a = tid; a < L.n_alleles; a += nthr) {
                 u32 r = E.res[it.res_off + a];
                 if (!(r & R_REC)) continue;
                 if (accept_rec(P, r, n, use_xo)) {
@@ -834,7 +834,8 @@ __global__ __launch_bounds__(256, EXT_WAVES) void k_extend(const EngineDev* __re
             if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = acc; s_cnt[tid >> 6][1] = ign; }
             __syncthreads();
             if (tid == 0) {
-                u32 A = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0], I = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+                u32 A = 0, I = 0;
+                for (int w = 0; w < nwv; w++) { A += s_cnt[w][0]; I += s_cnt[w][1]; }
                 c_tot += tot_rec; c_ign += I;
                 E.item_state[ii] = (u8)(state | IS_DONE | (A ? IS_ACC : 0));
             }
@@ -1246,6 +1247,7 @@ struct mlst_handle {
     u8* d_in_bases = nullptr; u8* d_in_quals = nullptr; u64* d_in_off = nullptr; u64 cap_in_bytes = 0, cap_in_reads = 0;
     u32* d_packed = nullptr; u8* d_qrows = nullptr; u16* d_lens = nullptr; u64 cap_packed_words = 0, cap_qrow_bytes = 0, cap_lens = 0;
     u64 reads_seen = 0;
+    int ext_threads = 256, ext_blocks = 1024;    // k_extend launch shape (set in mlst_load_reference)
     u8* d_fq_text = nullptr; u64 cap_fq_text = 0; u32* d_fq_blk = nullptr; u64 cap_fq_blk = 0;
     u64* d_fq_lines = nullptr; u64 cap_fq_lines = 0; u64* d_fq_soff = nullptr; u64* d_fq_qoff = nullptr; u64 cap_fq_reads = 0; u64* d_fq_meta = nullptr;
     // pileup scratch
@@ -1566,6 +1568,13 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_pl_list, E.cap_items));
     HIPCHK(h, dmalloc(&h->d_tb, (u64)64 * 64 * MLST_MAX_READ_LEN * (2 * MAX_W + 1)));
     HIPCHK(h, dmalloc(&h->d_E, (u64)1)); HIPCHK(h, hipMemcpy(h->d_E, &h->E, sizeof(EngineDev), hipMemcpyHostToDevice));
+    {   // k_extend launch shape: threads per work item from the largest locus (MLST_EXT_THREADS / MLST_EXT_BLOCKS override it)
+        u32 mx = 0; for (auto& L : loci) mx = std::max(mx, L.n_alleles);
+        int thr = mx <= 64 ? 64 : (mx <= 128 ? 128 : (mx <= 192 ? 192 : 256));
+        const char* e1 = getenv("MLST_EXT_THREADS"); if (e1 && atoi(e1) >= 64 && atoi(e1) <= 1024 && atoi(e1) % 64 == 0) thr = atoi(e1);
+        int blocks = 1024 * 256 / thr; const char* e2 = getenv("MLST_EXT_BLOCKS"); if (e2 && atoi(e2) > 0) blocks = atoi(e2);
+        h->ext_threads = thr; h->ext_blocks = blocks;
+    }
     h->have_ref = h->have_state = true;
     int rc = reset_sample_state(h); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1637,8 +1646,9 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     { Prof pf(h, 1);
       hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand); }
     { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
-      if (wpr <= 10) hipLaunchKernelGGL(k_extend<10>, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
-      else hipLaunchKernelGGL(k_extend<RW>, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
+      const int thr = h->ext_threads, blocks = h->ext_blocks;
+      if (wpr <= 10) hipLaunchKernelGGL(k_extend<10>, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
+      else hipLaunchKernelGGL(k_extend<RW>, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
       hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, h->d_E); }
@@ -1873,6 +1883,25 @@ extern "C" int mlst_consensus(mlst_handle* h, const uint32_t* chosen, uint32_t n
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (ncols) memcpy(out_seq, stage, ncols);
     if (ncols && counts) memcpy(counts, stage + ((ncols + 15) & ~15ull), ncols * 16);
+    return MLST_OK;
+}
+
+extern "C" int mlst_consensus_from_counts_device(mlst_handle* h, const uint32_t* d_counts, uint64_t n_cols, uint32_t mincov,
+                                                 char none_char, uint8_t* out_seq) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (n_cols == 0) return MLST_OK;
+    if (!d_counts || !out_seq) return fail(h, MLST_E_INVALID, "NULL argument");
+    hipSetDevice(h->device);
+    const u64 need = (n_cols + 15) / 4 + 8;
+    if (h->cap_counts < need) { hipStreamSynchronize(h->stream); hipFree(h->d_counts); h->d_counts = nullptr; HIPCHK(h, dmalloc(&h->d_counts, need)); h->cap_counts = need; }
+    int rc = ensure_pin(h, (u64)h->n_loci * 12 + n_cols + 128); if (rc) return rc;
+    u8* d_letters = reinterpret_cast<u8*>(h->d_counts);
+    hipLaunchKernelGGL(k_consensus, dim3(grid_for(n_cols, 256, 256)), dim3(256), 0, h->stream, d_counts, (u64)n_cols, mincov, (u8)none_char, d_letters);
+    HIPCHK(h, hipGetLastError());
+    u8* stage = h->h_pin + (u64)h->n_loci * 12 + 16; stage = (u8*)(((uintptr_t)stage + 15) & ~(uintptr_t)15);
+    HIPCHK(h, hipMemcpyAsync(stage, d_letters, n_cols, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(out_seq, stage, n_cols);
     return MLST_OK;
 }
 

@@ -29,10 +29,23 @@ def shard_range(n_units: int, rank: int, world: int, pair: bool = False) -> tupl
 
 
 class DeviceStatsPort:
-    """Adapter between metamlst_amd.engine.Engine and torch tensors on its GPU."""
+    """Adapter between metamlst_amd.engine.Engine and torch tensors on its GPU.  Exchange tensors are allocated
+    once and reused (a typing pass is ~1 ms; per-step allocations would show)."""
 
     def __init__(self, engine, device: torch.device):
         self.engine, self.device = engine, device
+        self._cache: dict = {}
+
+    def buffer(self, name: str, n: int, dtype) -> torch.Tensor:
+        t = self._cache.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.zeros(max(1, n), dtype=dtype, device=self.device)
+            self._cache[name] = t
+        return t[:max(1, n)]
+
+    def consensus_from_counts(self, t_counts: torch.Tensor, n_cols: int) -> bytes:
+        torch.cuda.synchronize(self.device)
+        return self.engine.consensus_from_counts_device(t_counts.data_ptr(), n_cols)
 
     def flat_sizes(self):
         return self.engine.flat_sizes()
@@ -51,8 +64,11 @@ class DeviceStatsPort:
 def allreduce_stats(port, device: torch.device, group=None) -> None:
     """Collective 1: make every rank's pass-1 statistics the whole-job statistics."""
     n_sum, n_min = port.flat_sizes()
-    t_sum = torch.empty(n_sum, dtype=torch.int64, device=device)
-    t_min = torch.empty(max(1, n_min), dtype=torch.int64, device=device)
+    if hasattr(port, "buffer"):
+        t_sum, t_min = port.buffer("sum", n_sum, torch.int64), port.buffer("min", max(1, n_min), torch.int64)
+    else:
+        t_sum = torch.empty(n_sum, dtype=torch.int64, device=device)
+        t_min = torch.empty(max(1, n_min), dtype=torch.int64, device=device)
     port.export_stats(t_sum, t_min)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t_sum, op=dist.ReduceOp.SUM, group=group)
@@ -67,6 +83,22 @@ def allreduce_pileup(port, chosen: list[int], n_cols: int, device: torch.device,
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy().view(np.uint32).reshape(-1, 4)[:n_cols]
+
+
+def allreduce_consensus(port: DeviceStatsPort, index, chosen: list[int], n_cols: int, device: torch.device, group=None) -> dict[int, bytes]:
+    """Collective 2, GPU form: all-reduce the pileup counts on the device and apply the majority rule there
+    (mlst_consensus_from_counts_device); returns {allele idx: consensus bytes} on every rank."""
+    t = port.buffer("counts", max(1, n_cols) * 4, torch.int32)
+    port.pileup_into(chosen, t)                # zeroes the buffer, then counts
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    letters = port.consensus_from_counts(t, n_cols)
+    out, at = {}, 0
+    for a in chosen:
+        L = int(index.off[a + 1] - index.off[a])
+        out[int(a)] = letters[at:at + L]
+        at += L
+    return out
 
 
 def split_counts(index, chosen: list[int], counts: np.ndarray) -> dict[int, np.ndarray]:

@@ -95,6 +95,7 @@ def load_library(path: str | None = None):
         "mlst_pileup": (C.c_int, [H, u32p, C.c_uint32, u32p]),
         "mlst_pileup_device": (C.c_int, [H, u32p, C.c_uint32, u32p, C.POINTER(C.c_uint64)]),
         "mlst_consensus": (C.c_int, [H, u32p, C.c_uint32, C.c_uint32, C.c_char, u8p, u32p]),
+        "mlst_consensus_from_counts_device": (C.c_int, [H, u32p, C.c_uint64, C.c_uint32, C.c_char, u8p]),
         "mlst_hamming_le": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
         "mlst_hamming_all": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, u32p]),
         "mlst_reset_sample": (C.c_int, [H]),
@@ -236,6 +237,12 @@ class Engine:
             res[int(a)] = buf[at:at + L]
             at += L
         return res
+
+    def consensus_from_counts_device(self, d_counts: int, n_cols: int, mincov: int = 1, none_char: str = "N") -> bytes:
+        out = np.zeros(max(1, n_cols), np.uint8)
+        self._check(self.lib.mlst_consensus_from_counts_device(self._h, d_counts, n_cols, int(mincov), none_char.encode(), _ptr(out)),
+                    "mlst_consensus_from_counts_device")
+        return out.tobytes()[:n_cols]
 
     def pileup_device(self, chosen: list[int], d_counts: int) -> int:
         ch = np.ascontiguousarray(chosen, dtype=np.uint32)

@@ -212,10 +212,14 @@ def test_sharded_engines_reduce_to_the_single_engine_result():
         t = torch.zeros(n_cols * 4, dtype=torch.int32, device=dev)
         assert p.pileup_into(chosen, t) == n_cols
         parts.append(t)
-    merged = split_counts(idx, chosen, (parts[0] + parts[1]).cpu().numpy().view(np.uint32).reshape(-1, 4))
+    summed = parts[0] + parts[1]
+    merged = split_counts(idx, chosen, summed.cpu().numpy().view(np.uint32).reshape(-1, 4))
     ref = whole.pileup(chosen)
     for a in chosen:
         assert np.array_equal(merged[a], ref[a])
+    # majority rule on the reduced counts, on the device (what rank 0 does in the multi-GPU flow)
+    letters = ports[0].consensus_from_counts(summed, n_cols)
+    assert letters == b"".join(whole.consensus(chosen)[a] for a in chosen)
 
 
 def test_plain_sieve_kernel_without_lds_bitmap(monkeypatch):
