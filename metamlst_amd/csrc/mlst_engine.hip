@@ -98,6 +98,9 @@ struct LocusDev {
     u32 words;          // 2-bit words per allele (ceil(max_len/16) + 2 zero words)
     u32 nwords;         // N-mask words per allele (ceil(max_len/32) + 1)
     u32 has_n, species, max_len;
+    u64 plane_off;      // word offset of this locus in the bit-plane arena
+    u32 pblocks;        // 32-base blocks per allele in the bit-plane arena (ceil(max_len/32) + 1)
+    u32 pad_;
 };
 struct ItemDev {         // one (read, locus, strand, diagonal) unit of extension work
     u64 res_off;         // offset of its result row in the pair-result arena
@@ -108,6 +111,7 @@ struct ItemDev {         // one (read, locus, strand, diagonal) unit of extensio
 };
 struct Counters {
     u64 n_cand, n_ret, n_items, n_res, n_dp, items_done, dp_done, n_pl_dp;
+    u64 ext_next;        // k_extend work queue: items of this submission handed out so far
     u64 err;             // bit0 retained overflow, bit1 item overflow, bit2 result overflow, bit3 dp overflow
     u64 cnt[MLST_CNT_N];
 };
@@ -118,20 +122,38 @@ struct Counters {
 struct KParams {
     int minscore, max_xm, min_read_len, minqual, match_bonus, n_penalty, open_p, ext_p, gbar, band_w, trig, quirk, clip;
 };
+// A pointer field of the device descriptor.  The fields are loaded from memory at run time, so the compiler cannot
+// prove that they point to global memory and would emit flat_* accesses -- slower, and they count on lgkmcnt as
+// well as vmcnt, which ties every LDS wait to the outstanding global loads.  On the device the accessor
+// round-trips through address space 1, from which the address-space inference makes every use a global_* access.
+template <typename T> struct GP {
+    T* p;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(1))) T G;
+#else
+    typedef T G;                   // host pass: device functions are only type-checked
+#endif
+    __host__ __device__ GP& operator=(T* q) { p = q; return *this; }
+    template <typename I> __device__ G& operator[](I i) const { return ((G*)p)[i]; }
+    __device__ G* operator->() const { return (G*)p; }
+    __host__ __device__ operator T*() const { return p; }     // generic pointer: host code, pointer arithmetic
+    __device__ G* g() const { return (G*)p; }
+};
+
 struct EngineDev {
     // reference
-    const u32* arena; const u32* nmask; const u16* allele_len; const u32* allele_locus; const LocusDev* loci;
-    const uint4* sieve; u32 sieve_mask;
-    const u32* bitmap;        // first-level 2^20-bit filter kept in LDS (nullptr when the database is too large for it to be selective)
-    const u32* gbitmap; u32 gbitmap_bits;   // larger first-level filter in global memory (L2 resident) for big databases
-    const u64* keys; const u32* vals; const u32* posts; u32 table_mask;
-    const int* floor_tab; const u8* pen_tab;
+    GP<const u32> arena; GP<const u32> planes; GP<const u32> nmask; GP<const u16> allele_len; GP<const u32> allele_locus; GP<const LocusDev> loci;
+    GP<const uint4> sieve; u32 sieve_mask;
+    GP<const u32> bitmap;     // first-level 2^20-bit filter kept in LDS (nullptr when the database is too large for it to be selective)
+    GP<const u32> gbitmap; u32 gbitmap_bits;   // larger first-level filter in global memory (L2 resident) for big databases
+    GP<const u64> keys; GP<const u32> vals; GP<const u32> posts; u32 table_mask;
+    GP<const int> floor_tab; GP<const u8> pen_tab;
     u32 n_alleles, n_loci;
     // sample state
-    long long* sum_score; u32* n_hits; u64* locus_len; u64* locus_first;
-    Counters* ctr;
-    u32* ret_bases; u8* ret_quals; u16* ret_len; u64* ret_ridx; u32* ret_nrec;
-    ItemDev* items; u8* item_state; u32* res; u64* dp_list;
+    GP<long long> sum_score; GP<u32> n_hits; GP<u64> locus_len; GP<u64> locus_first;
+    GP<Counters> ctr;
+    GP<u32> ret_bases; GP<u8> ret_quals; GP<u16> ret_len; GP<u64> ret_ridx; GP<u32> ret_nrec;
+    GP<ItemDev> items; GP<u8> item_state; GP<u32> res; GP<u64> dp_list;
     u64 cap_ret, cap_items, cap_res, cap_dp;
 };
 
@@ -147,6 +169,10 @@ template <int N, typename T> __device__ inline void tie_all(T (&v)[N]) {
     for (int i = 0; i + 4 <= N; i += 4) TIE4(v[i], v[i + 1], v[i + 2], v[i + 3]);
     #pragma unroll
     for (int i = N - (N % 4); i < N; i++) TIE1(v[i]);
+}
+
+__device__ inline u64 uniform_u64(u64 v) {
+    return ((u64)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) | (u64)__builtin_amdgcn_readfirstlane((u32)v);
 }
 
 // ------------------------------------------------------------------ K0: pack
@@ -582,7 +608,7 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             u64 sl = __shfl(slot, src);
             const u32* row = packed + (u64)rr * wpr;
             const u32* qrow32 = reinterpret_cast<const u32*>(qrows + (u64)rr * qstride);
-            u32* dq = reinterpret_cast<u32*>(E.ret_quals + sl * RQ);
+            auto dq = reinterpret_cast<GP<u32>::G*>(E.ret_quals.g() + sl * RQ);
             if (lane < RW) E.ret_bases[sl * RW + lane] = (u32)lane < wpr ? row[lane] : 0u;
             u32 nq = (nn < qstride ? nn : qstride);        // bytes to keep; rows hold zeros beyond the read length
             for (u32 w = lane; w < RQ / 4; w += 64) dq[w] = (w * 4 < nq) ? qrow32[w] : 0u;
@@ -623,8 +649,8 @@ __device__ inline u32 src_base(const u32* rb, int s) { return (rb[s >> 4] >> (2 
 __device__ inline void stage_read(const EngineDev& E, const KParams& P, const ItemDev& it, int n,
                                   u32* s_rw, u32* s_rn, u32* s_odd, u8* s_pen, u8* s_q, const u8* s_pentab, int tid, int nthreads) {
     const u8 pen_def = s_pentab[40];     // s_odd marks the positions whose penalty is not the Phred-40 one
-    const u32* rb = E.ret_bases + (u64)it.ret * RW;
-    const u8* rq = E.ret_quals + (u64)it.ret * RQ;
+    auto rb = E.ret_bases.g() + (u64)it.ret * RW;
+    auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
     for (int i0 = 0; i0 < RQ; i0 += nthreads) {
         int i = i0 + tid; u32 v = 0, nb = 0, ob = 0;
         if (i < n) {
@@ -679,7 +705,7 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
     const int MA = P.match_bonus << MLST_P_SHIFT;
     const int nw = (n + 15) >> 4;                  // read words in use (block-uniform)
     const int q0 = d >> 4, r2 = (d & 15) * 2;      // allele word of read position 0 (floor), bit shift
-    const u32* abase = E.arena + L.arena_off;      // uniform base of the locus; lanes differ only in a_local
+    auto abase = E.arena.g() + L.arena_off;          // uniform base of the locus; lanes differ only in a_local
     u32 Aw[NW + 1];
     #pragma unroll
     for (int t = 0; t <= NW; t++) {
@@ -744,6 +770,145 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
     be = bend; bs = bend - blen;
     return best;
 }
+// ---- bit-plane form of the same alignment (k_extend).  A base is two bits; kept as two planes of 32 bases per
+// word (low bits, high bits), the mismatch mask of 32 columns is (rl ^ al) | (rh ^ ah): no bit gathering, and the
+// read planes come straight out of ballots.  k_extend is VALU-bound (a wave64 VALU op takes 4 cycles on a SIMD16),
+// so what counts here is instructions per (read, allele) pair.
+__device__ inline void stage_read_planes(const EngineDev& E, const KParams& P, const ItemDev& it, int n,
+                                         u32* s_rl, u32* s_rh, u32* s_rn, u32* s_odd, u8* s_pen, const u8* s_pentab, int tid, int nthreads) {
+    const u8 pen_def = s_pentab[40];
+    auto rb = E.ret_bases.g() + (u64)it.ret * RW;
+    auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
+    for (int i0 = 0; i0 < RQ; i0 += nthreads) {
+        int i = i0 + tid; u32 b = 0, isn = 0, odd = 0;
+        if (i < n) {
+            int s = it.strand ? n - 1 - i : i; u8 qb = rq[s];
+            b = (rb[s >> 4] >> (2 * (s & 15))) & 3u; if (it.strand) b ^= 3u;
+            isn = qb >> 7;
+            u8 pen = isn ? (u8)P.n_penalty : s_pentab[qb & 0x7F];
+            s_pen[i] = pen;
+            odd = pen != pen_def;
+        }
+        u64 bl = __ballot(b & 1u), bh = __ballot(b >> 1), bn = __ballot(isn != 0), bo = __ballot(odd != 0);
+        if ((tid & 63) == 0 && i < RQ) {
+            int w = i >> 5;
+            s_rl[w] = (u32)bl; s_rl[w + 1] = (u32)(bl >> 32); s_rh[w] = (u32)bh; s_rh[w + 1] = (u32)(bh >> 32);
+            s_rn[w] = (u32)bn; s_rn[w + 1] = (u32)(bn >> 32); s_odd[w] = (u32)bo; s_odd[w + 1] = (u32)(bo >> 32);
+        }
+    }
+}
+
+// NB = 32-base read blocks the instantiation supports.  TRACK = also report the aligned span [bs, be) (only the
+// gap-trigger policy needs it, and only for pairs with many mismatches).  Value-identical to ungapped<>.
+template <int NB, bool TRACK>
+__device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, const LocusDev& L, u32 a_local, int m, int n, int d,
+                                      const u32* s_rl, const u32* s_rh, const u32* s_rn, const u32* s_odd, const u8* s_pen, int pen_def,
+                                      bool read_has_n, int& mm_total, int& bs, int& be) {
+    const int i0 = d < 0 ? -d : 0;                             // block-uniform
+    const int i1 = (m - d) < n ? (m - d) : n;                  // per allele
+    mm_total = 0; bs = be = i0;
+    if (i1 <= i0) return P0;
+    const int MA = P.match_bonus << MLST_P_SHIFT;
+    const int nb = (n + 31) >> 5;                              // read blocks in use (block-uniform)
+    const int q0 = d >> 5, r = d & 31;                         // allele block of read position 0 (floor), bit shift
+    auto pbase = E.planes.g() + L.plane_off;
+    u32 A[2 * (NB + 1)];
+    #pragma unroll
+    for (int t = 0; t <= NB; t++) {
+        A[2 * t] = 0; A[2 * t + 1] = 0;
+        if (t <= nb) {                                         // uniform guard
+            int q = q0 + t; u32 qc = (u32)(q < 0 ? 0 : (q >= (int)L.pblocks ? (int)L.pblocks - 1 : q));
+            A[2 * t] = pbase[(qc * 2) * L.n_pad + a_local];
+            A[2 * t + 1] = pbase[(qc * 2 + 1) * L.n_pad + a_local];
+        }
+    }
+    // clamped blocks only ever meet read positions outside [i0, i1), which the masks below remove
+    tie_all<2 * (NB + 1)>(A);
+    u32 M[NB], AN[NB];
+    const bool lane_mask = __any(i1 < n);                      // some allele of this wave ends inside the read
+    #pragma unroll
+    for (int w = 0; w < NB; w++) {
+        M[w] = 0; AN[w] = 0;
+        if (w < nb) {                                          // uniform guard
+            u32 lo = __builtin_amdgcn_alignbit(A[2 * w + 2], A[2 * w], r), hi = __builtin_amdgcn_alignbit(A[2 * w + 3], A[2 * w + 1], r);
+            M[w] = (lo ^ s_rl[w]) | (hi ^ s_rh[w]);
+            if (read_has_n) M[w] |= s_rn[w];
+            if (L.has_n) {                                     // allele N bits for allele bases 32w+d .. 32w+d+31
+                int gg = 32 * w + d; int nq = gg >> 5, nr = gg & 31;
+                AN[w] = __builtin_amdgcn_alignbit(nmask_word(E, L, nq + 1, a_local), nmask_word(E, L, nq, a_local), nr);
+                M[w] |= AN[w];
+            }
+            int lo_i = i0 - 32 * w; lo_i = lo_i < 0 ? 0 : (lo_i > 32 ? 32 : lo_i);        // uniform: scalar unit
+            int hi_u = n - 32 * w; hi_u = hi_u < 0 ? 0 : (hi_u > 32 ? 32 : hi_u);
+            M[w] &= (hi_u >= 32 ? 0xFFFFFFFFu : ((1u << hi_u) - 1u)) & ~(lo_i >= 32 ? 0xFFFFFFFFu : ((1u << lo_i) - 1u));
+            if (lane_mask) {
+                int hi_i = i1 - 32 * w; hi_i = hi_i < 0 ? 0 : (hi_i > 32 ? 32 : hi_i);
+                M[w] &= hi_i >= 32 ? 0xFFFFFFFFu : ((1u << hi_i) - 1u);
+            }
+            mm_total += __popc(M[w]);
+        }
+    }
+    const int PD = (pen_def << MLST_P_SHIFT) + 1;
+    if (!TRACK) {
+        // g = cur - last*MA, so the running value just before column i is g + i*MA
+        int g = P0 - i0 * MA, best = P0;
+        #pragma unroll
+        for (int w = 0; w < NB; w++) {
+            if (w < nb) {
+                u32 Mw = M[w];
+#ifdef EXP_NO_KADANE
+                Mw = 0;
+#endif
+                const u32 special = s_odd[w] | AN[w];
+                const int ub = 32 * w * MA;
+                if (__any((Mw & special) != 0)) {              // some mismatch of this wave has a non-default penalty
+                    while (Mw) {
+                        int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
+                        int u = bit * MA + ub, t = g + u;
+                        best = t > best ? t : best;
+                        int dec = PD;
+                        if ((special >> bit) & 1u) dec = ((((AN[w] >> bit) & 1u) ? P.n_penalty : (int)s_pen[32 * w + bit]) << MLST_P_SHIFT) + 1;
+                        t -= dec; t = t > P0 ? t : P0;
+                        g = t - u - MA;
+                    }
+                } else {
+                    while (Mw) {
+                        int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
+                        int u = bit * MA + ub, t = g + u;
+                        best = t > best ? t : best;
+                        t -= PD; t = t > P0 ? t : P0;
+                        g = t - u - MA;
+                    }
+                }
+            }
+        }
+        int t = g + i1 * MA;
+        return t > best ? t : best;
+    }
+    int cur = P0, best = P0, cs = i0, last = i0, blen = 0, bend = i0;
+    #pragma unroll
+    for (int w = 0; w < NB; w++) {
+        if (w < nb) {
+            u32 Mw = M[w];
+            const u32 special = s_odd[w] | AN[w];
+            while (Mw) {
+                int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
+                int i = 32 * w + bit;
+                cur += (i - last) * MA;
+                if (cur > best) { best = cur; blen = i - cs; bend = i; }
+                int dec = PD;
+                if ((special >> bit) & 1u) dec = ((((AN[w] >> bit) & 1u) ? P.n_penalty : (int)s_pen[i]) << MLST_P_SHIFT) + 1;
+                cur -= dec;
+                if (cur <= P0) { cur = P0; cs = i + 1; }
+                last = i + 1;
+            }
+        }
+    }
+    cur += (i1 - last) * MA;
+    if (cur > best) { best = cur; blen = i1 - cs; bend = i1; }
+    be = bend; bs = bend - blen;
+    return best;
+}
 // the policy deciding whether the banded Smith-Waterman runs for a pair (same expression as oracle align_pair)
 __device__ inline bool gap_trigger(const KParams& P, int mm, int xm, int score, int floor_n, int m, int n, int d, int bs, int be) {
     if (P.trig < 0) return true;
@@ -763,37 +928,49 @@ __device__ inline bool accept_rec(const KParams& P, u32 r, int n, bool use_xo) {
 #ifndef EXT_WAVES
 #define EXT_WAVES 4          // waves per SIMD the register allocator must leave room for (swept on MI355X)
 #endif
-template <int NW>
+template <int NB>
 __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ Ep, KParams P) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
-    __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u32 s_odd[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
+    __shared__ u32 s_rl[RW / 2 + 2]; __shared__ u32 s_rh[RW / 2 + 2]; __shared__ u32 s_rn[RW / 2 + 2]; __shared__ u32 s_odd[RW / 2 + 2];
+    __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
     __shared__ u32 s_cnt[16][3];
     const int tid = threadIdx.x, nthr = blockDim.x, nwv = blockDim.x >> 6;      // 64..1024 threads per work item
     for (int i = tid; i < 128; i += nthr) s_pentab[i] = E.pen_tab[i];
     u64 c_tot = 0, c_ign = 0;                     // block-level counters, flushed once at the end (thread 0)
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
-    for (u64 ii = begin + blockIdx.x; ii < end; ii += gridDim.x) {
+    // Work queue: items cost different amounts (mismatch density, allele count of the locus), so blocks take the
+    // next item from a counter instead of a fixed stride.  The ticket for item k+1 is drawn while item k is staged.
+    __shared__ u64 s_next;
+    if (tid == 0) s_next = begin + atomicAdd(&E.ctr->ext_next, 1ull);
+    __syncthreads();
+    u64 ii = uniform_u64(s_next);                 // readfirstlane: keeps the per-item descriptor loads and index math scalar
+    while (ii < end) {                            // block-uniform
+        u64 ticket = 0;
+        if (tid == 0) ticket = atomicAdd(&E.ctr->ext_next, 1ull);
         ItemDev it = E.items[ii];
         const LocusDev L = E.loci[it.locus];
         u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu); bool read_has_n = (lw & 0x8000u) != 0;
         u8 state = E.item_state[ii];
         __syncthreads();
-        stage_read(E, P, it, n, s_rw, s_rn, s_odd, s_pen, nullptr, s_pentab, tid, nthr);
-        if (tid == 0) { s_rw[RW] = s_rw[RW + 1] = 0; }
+        stage_read_planes(E, P, it, n, s_rl, s_rh, s_rn, s_odd, s_pen, s_pentab, tid, nthr);
         __syncthreads();
-        if (it.res_off + L.n_pad > E.cap_res) continue;      // flagged by k_seed
+        const bool res_ok = it.res_off + L.n_pad <= E.cap_res;      // else flagged by k_seed
         const int floor_n = E.floor_tab[n];
         u32 nrec = 0, ndp = 0;
 #ifdef EXP_NO_ALLELES
         for (u32 a = tid; a < 0; a += nthr) {
 #else
-        for (u32 a = tid; a < L.n_alleles; a += nthr) {
+        for (u32 a = tid; res_ok && a < L.n_alleles; a += nthr) {
 #endif
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
-            int best = ungapped<NW>(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_odd, s_pen, (int)s_pentab[40], read_has_n, mm, bs, be);
+            int best = ungapped_planes<NB, false>(E, P, L, a, m, n, it.diag, s_rl, s_rh, s_rn, s_odd, s_pen, (int)s_pentab[40], read_has_n, mm, bs, be);
             int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
-            bool need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
+            bool need_dp = P.trig < 0;
+            if (!need_dp && mm > P.trig && score >= floor_n) {       // rare: the policy needs the aligned span
+                ungapped_planes<NB, true>(E, P, L, a, m, n, it.diag, s_rl, s_rh, s_rn, s_odd, s_pen, (int)s_pentab[40], read_has_n, mm, bs, be);
+                need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
+            }
             u32 r = pack_result(score, xm, xo);
             if (need_dp) { r |= R_NEEDDP; ndp++; }
             else if (score >= floor_n && score > 0) { r |= R_REC; nrec++; }
@@ -817,7 +994,7 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
         // Fused accumulation (metamlst.py:101-130) when everything about this read is known here:
         // it has a single work item and no pair is waiting for the banded SW.
 #ifndef EXP_NO_ACC
-        if ((state & IS_SINGLE) && tot_dp == 0) {
+        if (res_ok && (state & IS_SINGLE) && tot_dp == 0) {
             bool use_xo = P.quirk && tot_rec == 1;
             u32 acc = 0, ign = 0;
             for (u32 a = tid; a < L.n_alleles; a += nthr) {
@@ -841,6 +1018,9 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
             }
         }
 #endif
+        if (tid == 0) s_next = begin + ticket;
+        __syncthreads();
+        ii = uniform_u64(s_next);
     }
     if (tid == 0) {
         if (c_tot) atomicAdd(&E.ctr->cnt[MLST_CNT_TOTAL_RECORDS], c_tot);
@@ -857,8 +1037,8 @@ __device__ inline int banded(const EngineDev& E, const KParams& P, const ItemDev
     const int W = P.band_w, BW = 2 * W + 1, G = P.gbar, d = it.diag;
     const int m = (int)E.allele_len[L.a_begin + a_local];
     const int OPEN = P.open_p, EXT = P.ext_p, MA = P.match_bonus << MLST_P_SHIFT;
-    const u32* rb = E.ret_bases + (u64)it.ret * RW;
-    const u8* rq = E.ret_quals + (u64)it.ret * RQ;
+    auto rb = E.ret_bases.g() + (u64)it.ret * RW;
+    auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
     int Hp[2 * MAX_W + 2], Fp[2 * MAX_W + 2];
     #pragma unroll
     for (int b = 0; b < 2 * MAX_W + 2; b++) { Hp[b] = P0; Fp[b] = NEGP; }
@@ -942,8 +1122,8 @@ __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep
         const int m = live ? (int)E.allele_len[L.a_begin + a_local] : 0;
         __syncthreads();                      // previous pair's rows are no longer read (trip count is block-uniform)
         {
-            const u32* gq = reinterpret_cast<const u32*>(E.ret_quals + (u64)it.ret * RQ);
-            const u32* gb = E.ret_bases + (u64)it.ret * RW;
+            auto gq = reinterpret_cast<GP<const u32>::G*>(E.ret_quals.g() + (u64)it.ret * RQ);
+            auto gb = E.ret_bases.g() + (u64)it.ret * RW;
             for (int w = b; w < RQ / 4; w += 32) s_qrow[gl][w] = live ? gq[w] : 0u;
             if (b < RW) s_brow[gl][b] = live ? gb[b] : 0u;
         }
@@ -1077,7 +1257,7 @@ __global__ void k_advance(Counters* c, u64 n_reads) {
     u64 ni = c->n_items, nd = c->n_dp;
     c->cnt[MLST_CNT_CANDIDATES] += c->n_cand;
     c->cnt[MLST_CNT_READS_SEEN] += n_reads;
-    c->items_done = ni; c->dp_done = nd; c->n_cand = 0;
+    c->items_done = ni; c->dp_done = nd; c->n_cand = 0; c->ext_next = 0;
 }
 
 // ------------------------------------------------------------------ K6: pileup against the chosen allele of each locus
@@ -1087,7 +1267,7 @@ __device__ inline void pile_base(const EngineDev& E, const KParams& P, const Ite
     int s = it.strand ? n - 1 - i : i;
     u8 qb = E.ret_quals[(u64)it.ret * RQ + s];
     if ((qb & 0x80) || (int)(qb & 0x7F) < P.minqual) return;
-    u32 b = src_base(E.ret_bases + (u64)it.ret * RW, s); if (it.strand) b ^= 3u;
+    u32 b = src_base(E.ret_bases.g() + (u64)it.ret * RW, s); if (it.strand) b ^= 3u;
     atomicAdd(&counts[(colbase + (u64)j) * 4 + b], 1u);
 }
 
@@ -1236,7 +1416,7 @@ struct mlst_handle {
     u32 n_alleles = 0, n_loci = 0;
     std::vector<u32> allele_locus;
     // device memory
-    u32* d_arena = nullptr; u32* d_nmask = nullptr; u16* d_allele_len = nullptr; u32* d_allele_locus = nullptr;
+    u32* d_arena = nullptr; u32* d_planes = nullptr; u32* d_nmask = nullptr; u16* d_allele_len = nullptr; u32* d_allele_locus = nullptr;
     LocusDev* d_loci = nullptr; uint4* d_sieve = nullptr; u32* d_bitmap = nullptr; u32* d_gbitmap = nullptr; u64* d_keys = nullptr; u32* d_vals = nullptr; u32* d_posts = nullptr;
     int* d_floor = nullptr; u8* d_pen = nullptr; u8* d_ascii = nullptr; u64* d_aoff = nullptr;
     u64 bytes_arena = 0, bytes_sieve = 0, bytes_table = 0;
@@ -1275,6 +1455,7 @@ static int fail(mlst_handle* h, int code, const char* fmt, ...) {
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, MLST_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
 template <typename T> static hipError_t dmalloc(T** p, u64 n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
+template <typename T> static hipError_t dmalloc(GP<T>* p, u64 n) { return hipMalloc((void**)&p->p, (n ? n : 1) * sizeof(T)); }
 
 static hipEvent_t ev_get(mlst_handle* h) {
     if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
@@ -1333,10 +1514,10 @@ extern "C" int mlst_create(int device, const mlst_params* p, mlst_handle** out) 
 }
 
 static void free_ref(mlst_handle* h) {
-    hipFree(h->d_arena); hipFree(h->d_nmask); hipFree(h->d_allele_len); hipFree(h->d_allele_locus); hipFree(h->d_loci);
+    hipFree(h->d_arena); hipFree(h->d_planes); hipFree(h->d_nmask); hipFree(h->d_allele_len); hipFree(h->d_allele_locus); hipFree(h->d_loci);
     hipFree(h->d_sieve); hipFree(h->d_bitmap); h->d_bitmap = nullptr; hipFree(h->d_gbitmap); h->d_gbitmap = nullptr; hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
     hipFree(h->d_ascii); hipFree(h->d_aoff);
-    h->d_arena = h->d_nmask = nullptr; h->d_allele_len = nullptr; h->d_allele_locus = nullptr; h->d_loci = nullptr; h->d_sieve = nullptr;
+    h->d_arena = h->d_planes = h->d_nmask = nullptr; h->d_allele_len = nullptr; h->d_allele_locus = nullptr; h->d_loci = nullptr; h->d_sieve = nullptr;
     h->d_keys = nullptr; h->d_vals = h->d_posts = nullptr; h->d_floor = nullptr; h->d_pen = nullptr; h->d_ascii = nullptr; h->d_aoff = nullptr;
     h->have_ref = false;
 }
@@ -1403,7 +1584,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         else if (L.a_begin + L.n_alleles != a) return fail(h, MLST_E_INVALID, "alleles of locus %u are not contiguous", locus_id[a]);
         L.n_alleles++; L.max_len = std::max(L.max_len, (u32)(off[a + 1] - off[a]));
     }
-    u64 arena_words = 0, nmask_words = 0;
+    u64 arena_words = 0, nmask_words = 0, plane_words = 0;
     std::vector<u16> alen(n_alleles); h->allele_locus.assign(locus_id, locus_id + n_alleles);
     for (u32 a = 0; a < n_alleles; a++) {
         alen[a] = (u16)(off[a + 1] - off[a]);
@@ -1414,9 +1595,10 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         L.n_pad = (L.n_alleles + 63) & ~63u; L.words = (L.max_len + 15) / 16 + 2; L.nwords = (L.max_len + 31) / 32 + 1;
         if ((u64)L.words * L.n_pad * 4 >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "a locus arena exceeds 4 GB");
         L.arena_off = arena_words; arena_words += (u64)L.words * L.n_pad;
+        L.pblocks = (L.max_len + 31) / 32 + 1; L.plane_off = plane_words; plane_words += (u64)L.pblocks * 2 * L.n_pad;
         if (L.has_n) { L.nmask_off = nmask_words; nmask_words += (u64)L.nwords * L.n_pad; }
     }
-    std::vector<u32> arena(arena_words ? arena_words : 1, 0), nmask(nmask_words ? nmask_words : 1, 0);
+    std::vector<u32> arena(arena_words ? arena_words : 1, 0), nmask(nmask_words ? nmask_words : 1, 0), planes(plane_words ? plane_words : 1, 0);
     // ---- arena fill + seed pairs
     struct KP { u64 key; u32 post; };
     std::vector<KP> kp;
@@ -1427,7 +1609,11 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         code.resize(len);
         for (u32 i = 0; i < len; i++) {
             int c = base_code(ascii[off[a] + i]); code[i] = (u8)c;
-            if (c < 4) arena[L.arena_off + (u64)(i >> 4) * L.n_pad + al] |= (u32)c << (2 * (i & 15));
+            if (c < 4) {
+                arena[L.arena_off + (u64)(i >> 4) * L.n_pad + al] |= (u32)c << (2 * (i & 15));
+                planes[L.plane_off + (u64)((i >> 5) * 2) * L.n_pad + al] |= (u32)(c & 1) << (i & 31);
+                planes[L.plane_off + (u64)((i >> 5) * 2 + 1) * L.n_pad + al] |= (u32)(c >> 1) << (i & 31);
+            }
             else nmask[L.nmask_off + (u64)(i >> 5) * L.n_pad + al] |= 1u << (i & 31);
         }
         if (len < MLST_SEED_LEN) continue;
@@ -1523,6 +1709,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     for (int q = 0; q < 256; q++) { int qq = q > 40 ? 40 : q; pen_tab[q] = (u8)(h->prm.mm_min + ((h->prm.mm_max - h->prm.mm_min) * qq) / 40); }
     // ---- upload
     HIPCHK(h, dmalloc(&h->d_arena, arena.size())); HIPCHK(h, hipMemcpy(h->d_arena, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, dmalloc(&h->d_planes, planes.size())); HIPCHK(h, hipMemcpy(h->d_planes, planes.data(), planes.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_nmask, nmask.size())); HIPCHK(h, hipMemcpy(h->d_nmask, nmask.data(), nmask.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_allele_len, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_len, alen.data(), (u64)n_alleles * 2, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_allele_locus, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_locus, locus_id, (u64)n_alleles * 4, hipMemcpyHostToDevice));
@@ -1538,11 +1725,11 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     u64 abytes = off[n_alleles];
     HIPCHK(h, dmalloc(&h->d_ascii, abytes)); if (abytes) HIPCHK(h, hipMemcpy(h->d_ascii, ascii, abytes, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_aoff, (u64)n_alleles + 1)); HIPCHK(h, hipMemcpy(h->d_aoff, off, ((u64)n_alleles + 1) * 8, hipMemcpyHostToDevice));
-    h->bytes_arena = arena.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
+    h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
     h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
     // ---- sample state
     EngineDev& E = h->E;
-    E.arena = h->d_arena; E.nmask = h->d_nmask; E.allele_len = h->d_allele_len; E.allele_locus = h->d_allele_locus; E.loci = h->d_loci;
+    E.arena = h->d_arena; E.planes = h->d_planes; E.nmask = h->d_nmask; E.allele_len = h->d_allele_len; E.allele_locus = h->d_allele_locus; E.loci = h->d_loci;
     E.sieve = h->d_sieve; E.sieve_mask = smask; E.bitmap = h->d_bitmap; E.gbitmap = h->d_gbitmap; E.gbitmap_bits = gbitmap.empty() ? 0 : gbits; E.keys = h->d_keys; E.vals = h->d_vals; E.posts = h->d_posts; E.table_mask = tmask;
     E.floor_tab = h->d_floor; E.pen_tab = h->d_pen; E.n_alleles = n_alleles; E.n_loci = n_loci;
     E.cap_ret = h->prm.max_retained_reads; E.cap_items = h->prm.max_items; E.cap_res = h->prm.max_pair_results; E.cap_dp = h->prm.max_items * 4;
@@ -1572,7 +1759,8 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         u32 mx = 0; for (auto& L : loci) mx = std::max(mx, L.n_alleles);
         int thr = mx <= 64 ? 64 : (mx <= 128 ? 128 : (mx <= 192 ? 192 : 256));
         const char* e1 = getenv("MLST_EXT_THREADS"); if (e1 && atoi(e1) >= 64 && atoi(e1) <= 1024 && atoi(e1) % 64 == 0) thr = atoi(e1);
-        int blocks = 1024 * 256 / thr; const char* e2 = getenv("MLST_EXT_BLOCKS"); if (e2 && atoi(e2) > 0) blocks = atoi(e2);
+        int blocks = 1792 * 256 / thr;     // 7 waves per SIMD fit at the kernel's 68 VGPRs; the work queue balances the rest
+        const char* e2 = getenv("MLST_EXT_BLOCKS"); if (e2 && atoi(e2) > 0) blocks = atoi(e2);
         h->ext_threads = thr; h->ext_blocks = blocks;
     }
     h->have_ref = h->have_state = true;
@@ -1647,8 +1835,8 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand); }
     { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
       const int thr = h->ext_threads, blocks = h->ext_blocks;
-      if (wpr <= 10) hipLaunchKernelGGL(k_extend<10>, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
-      else hipLaunchKernelGGL(k_extend<RW>, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
+      if (wpr <= 10) hipLaunchKernelGGL(k_extend<5>, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
+      else hipLaunchKernelGGL(k_extend<RW / 2>, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
       hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, h->d_E); }
@@ -1833,7 +2021,7 @@ static int pileup_launch(mlst_handle* h, const uint32_t* chosen, uint32_t n, uin
     if (n_cols_out) *n_cols_out = ncols;
     HIPCHK(h, hipMemcpyAsync(h->d_locus_colbase, h->h_pin, tab_bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(d_counts, 0, (ncols ? ncols : 1) * 16, h->stream));
-    HIPCHK(h, hipMemsetAsync(&h->E.ctr->n_pl_dp, 0, 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->E.ctr.p->n_pl_dp, 0, 8, h->stream));
     const int* d_lc = (const int*)((u8*)h->d_locus_colbase + nl * 8);
     { Prof pf(h, 5);
       hipLaunchKernelGGL(k_pileup, dim3(4096), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list);
