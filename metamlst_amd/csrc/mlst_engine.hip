@@ -109,9 +109,13 @@ struct ItemDev {         // one (read, locus, strand, diagonal) unit of extensio
     int diag;
     u16 strand, votes;
 };
+#define EXT_Q 32
 struct Counters {
     u64 n_cand, n_ret, n_items, n_res, n_dp, items_done, dp_done, n_pl_dp;
-    u64 ext_next;        // k_extend work queue: items of this submission handed out so far
+    // k_extend work queues: queue q hands out the items begin + q + EXT_Q * t of this submission.  One counter would
+    // see ~1 returning atomic per item, and a single word sustains only ~90 of those per microsecond; the queues
+    // sit in separate 128-byte lines.
+    u64 ext_q[EXT_Q][16];
     u64 err;             // bit0 retained overflow, bit1 item overflow, bit2 result overflow, bit3 dp overflow
     u64 cnt[MLST_CNT_N];
 };
@@ -798,55 +802,60 @@ __device__ inline void stage_read_planes(const EngineDev& E, const KParams& P, c
     }
 }
 
+// uniform row pointer (scalar registers) + 32-bit byte offset of the lane: the saddr form of global_load
+__device__ inline u32 ld_row(GP<const u32>::G* row, u32 byte_off) {
+    return *reinterpret_cast<GP<const u32>::G*>(reinterpret_cast<GP<const char>::G*>(row) + byte_off);
+}
+
 // NB = 32-base read blocks the instantiation supports.  TRACK = also report the aligned span [bs, be) (only the
 // gap-trigger policy needs it, and only for pairs with many mismatches).  Value-identical to ungapped<>.
+// rl/rh/od = read planes and the non-default-penalty mask, block-uniform (scalar registers); s_rn, s_pen stay in LDS
+// because they are needed only for reads with N / for the rare non-default penalty.
 template <int NB, bool TRACK>
 __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, const LocusDev& L, u32 a_local, int m, int n, int d,
-                                      const u32* s_rl, const u32* s_rh, const u32* s_rn, const u32* s_odd, const u8* s_pen, int pen_def,
-                                      bool read_has_n, int& mm_total, int& bs, int& be) {
+                                      const u32 (&rl)[NB], const u32 (&rh)[NB], const u32 (&od)[NB], const u32* s_rn, const u8* s_pen,
+                                      int pen_def, bool read_has_n, int& mm_total, int& bs, int& be) {
     const int i0 = d < 0 ? -d : 0;                             // block-uniform
-    const int i1 = (m - d) < n ? (m - d) : n;                  // per allele
-    mm_total = 0; bs = be = i0;
-    if (i1 <= i0) return P0;
     const int MA = P.match_bonus << MLST_P_SHIFT;
-    const int nb = (n + 31) >> 5;                              // read blocks in use (block-uniform)
     const int q0 = d >> 5, r = d & 31;                         // allele block of read position 0 (floor), bit shift
     auto pbase = E.planes.g() + L.plane_off;
-    u32 A[2 * (NB + 1)];
+    auto nbase = E.nmask.g() + L.nmask_off;
+    const u32 aoff = a_local * 4u;                             // byte offset of the lane's allele inside a row
+    // One batch of independent loads: uniform row pointer (scalar unit) + the lane's allele index.  Blocks outside
+    // the allele are clamped; they only ever meet read positions outside [i0, i1), which the masks below remove.
+    u32 A[2 * (NB + 1)], AW[NB + 1];
     #pragma unroll
     for (int t = 0; t <= NB; t++) {
-        A[2 * t] = 0; A[2 * t + 1] = 0;
-        if (t <= nb) {                                         // uniform guard
-            int q = q0 + t; u32 qc = (u32)(q < 0 ? 0 : (q >= (int)L.pblocks ? (int)L.pblocks - 1 : q));
-            A[2 * t] = pbase[(qc * 2) * L.n_pad + a_local];
-            A[2 * t + 1] = pbase[(qc * 2 + 1) * L.n_pad + a_local];
-        }
+        int q = q0 + t; u32 qc = (u32)(q < 0 ? 0 : (q >= (int)L.pblocks ? (int)L.pblocks - 1 : q));
+        auto row = pbase + (u64)(qc * 2) * L.n_pad;
+        A[2 * t] = ld_row(row, aoff);
+        A[2 * t + 1] = ld_row(row + L.n_pad, aoff);
+        AW[t] = 0;
+        if (L.has_n) AW[t] = ld_row(nbase + (u64)qc * L.n_pad, aoff);
     }
-    // clamped blocks only ever meet read positions outside [i0, i1), which the masks below remove
     tie_all<2 * (NB + 1)>(A);
+    if (L.has_n) tie_all<NB + 1>(AW);
+    // m (the caller's allele_len load) is first needed here, behind the batch: one round trip, not two.  An allele
+    // that does not overlap the read (i1 <= i0) falls out of the masks: M = 0 and the final value is <= P0.
+    const int i1 = (m - d) < n ? (m - d) : n;                  // per allele
+    mm_total = 0; bs = be = i0;
     u32 M[NB], AN[NB];
     const bool lane_mask = __any(i1 < n);                      // some allele of this wave ends inside the read
     #pragma unroll
     for (int w = 0; w < NB; w++) {
-        M[w] = 0; AN[w] = 0;
-        if (w < nb) {                                          // uniform guard
-            u32 lo = __builtin_amdgcn_alignbit(A[2 * w + 2], A[2 * w], r), hi = __builtin_amdgcn_alignbit(A[2 * w + 3], A[2 * w + 1], r);
-            M[w] = (lo ^ s_rl[w]) | (hi ^ s_rh[w]);
-            if (read_has_n) M[w] |= s_rn[w];
-            if (L.has_n) {                                     // allele N bits for allele bases 32w+d .. 32w+d+31
-                int gg = 32 * w + d; int nq = gg >> 5, nr = gg & 31;
-                AN[w] = __builtin_amdgcn_alignbit(nmask_word(E, L, nq + 1, a_local), nmask_word(E, L, nq, a_local), nr);
-                M[w] |= AN[w];
-            }
-            int lo_i = i0 - 32 * w; lo_i = lo_i < 0 ? 0 : (lo_i > 32 ? 32 : lo_i);        // uniform: scalar unit
-            int hi_u = n - 32 * w; hi_u = hi_u < 0 ? 0 : (hi_u > 32 ? 32 : hi_u);
-            M[w] &= (hi_u >= 32 ? 0xFFFFFFFFu : ((1u << hi_u) - 1u)) & ~(lo_i >= 32 ? 0xFFFFFFFFu : ((1u << lo_i) - 1u));
-            if (lane_mask) {
-                int hi_i = i1 - 32 * w; hi_i = hi_i < 0 ? 0 : (hi_i > 32 ? 32 : hi_i);
-                M[w] &= hi_i >= 32 ? 0xFFFFFFFFu : ((1u << hi_i) - 1u);
-            }
-            mm_total += __popc(M[w]);
+        u32 lo = __builtin_amdgcn_alignbit(A[2 * w + 2], A[2 * w], r), hi = __builtin_amdgcn_alignbit(A[2 * w + 3], A[2 * w + 1], r);
+        M[w] = (lo ^ rl[w]) | (hi ^ rh[w]);
+        if (read_has_n) M[w] |= s_rn[w];
+        AN[w] = 0;
+        if (L.has_n) { AN[w] = __builtin_amdgcn_alignbit(AW[w + 1], AW[w], r); M[w] |= AN[w]; }
+        int lo_i = i0 - 32 * w; lo_i = lo_i < 0 ? 0 : (lo_i > 32 ? 32 : lo_i);            // uniform: scalar unit
+        int hi_u = n - 32 * w; hi_u = hi_u < 0 ? 0 : (hi_u > 32 ? 32 : hi_u);
+        M[w] &= (hi_u >= 32 ? 0xFFFFFFFFu : ((1u << hi_u) - 1u)) & ~(lo_i >= 32 ? 0xFFFFFFFFu : ((1u << lo_i) - 1u));
+        if (lane_mask) {
+            int hi_i = i1 - 32 * w; hi_i = hi_i < 0 ? 0 : (hi_i > 32 ? 32 : hi_i);
+            M[w] &= hi_i >= 32 ? 0xFFFFFFFFu : ((1u << hi_i) - 1u);
         }
+        mm_total += __popc(M[w]);
     }
     const int PD = (pen_def << MLST_P_SHIFT) + 1;
     if (!TRACK) {
@@ -854,54 +863,51 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
         int g = P0 - i0 * MA, best = P0;
         #pragma unroll
         for (int w = 0; w < NB; w++) {
-            if (w < nb) {
-                u32 Mw = M[w];
+            u32 Mw = M[w];
 #ifdef EXP_NO_KADANE
-                Mw = 0;
+            Mw = 0;
 #endif
-                const u32 special = s_odd[w] | AN[w];
-                const int ub = 32 * w * MA;
-                if (__any((Mw & special) != 0)) {              // some mismatch of this wave has a non-default penalty
-                    while (Mw) {
-                        int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
-                        int u = bit * MA + ub, t = g + u;
-                        best = t > best ? t : best;
-                        int dec = PD;
-                        if ((special >> bit) & 1u) dec = ((((AN[w] >> bit) & 1u) ? P.n_penalty : (int)s_pen[32 * w + bit]) << MLST_P_SHIFT) + 1;
-                        t -= dec; t = t > P0 ? t : P0;
-                        g = t - u - MA;
-                    }
-                } else {
-                    while (Mw) {
-                        int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
-                        int u = bit * MA + ub, t = g + u;
-                        best = t > best ? t : best;
-                        t -= PD; t = t > P0 ? t : P0;
-                        g = t - u - MA;
-                    }
+            const u32 special = od[w] | AN[w];
+            const int ub = 32 * w * MA;
+            if (__any((Mw & special) != 0)) {                  // some mismatch of this wave has a non-default penalty
+                while (Mw) {
+                    int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
+                    int u = bit * MA + ub, t = g + u;
+                    best = t > best ? t : best;
+                    int dec = PD;
+                    if ((special >> bit) & 1u) dec = ((((AN[w] >> bit) & 1u) ? P.n_penalty : (int)s_pen[32 * w + bit]) << MLST_P_SHIFT) + 1;
+                    t -= dec; t = t > P0 ? t : P0;
+                    g = t - u - MA;
+                }
+            } else {
+                while (Mw) {
+                    int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
+                    int u = bit * MA + ub, t = g + u;
+                    best = t > best ? t : best;
+                    t -= PD; t = t > P0 ? t : P0;
+                    g = t - u - MA;
                 }
             }
         }
         int t = g + i1 * MA;
         return t > best ? t : best;
     }
+    if (i1 <= i0) return P0;
     int cur = P0, best = P0, cs = i0, last = i0, blen = 0, bend = i0;
     #pragma unroll
     for (int w = 0; w < NB; w++) {
-        if (w < nb) {
-            u32 Mw = M[w];
-            const u32 special = s_odd[w] | AN[w];
-            while (Mw) {
-                int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
-                int i = 32 * w + bit;
-                cur += (i - last) * MA;
-                if (cur > best) { best = cur; blen = i - cs; bend = i; }
-                int dec = PD;
-                if ((special >> bit) & 1u) dec = ((((AN[w] >> bit) & 1u) ? P.n_penalty : (int)s_pen[i]) << MLST_P_SHIFT) + 1;
-                cur -= dec;
-                if (cur <= P0) { cur = P0; cs = i + 1; }
-                last = i + 1;
-            }
+        u32 Mw = M[w];
+        const u32 special = od[w] | AN[w];
+        while (Mw) {
+            int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
+            int i = 32 * w + bit;
+            cur += (i - last) * MA;
+            if (cur > best) { best = cur; blen = i - cs; bend = i; }
+            int dec = PD;
+            if ((special >> bit) & 1u) dec = ((((AN[w] >> bit) & 1u) ? P.n_penalty : (int)s_pen[i]) << MLST_P_SHIFT) + 1;
+            cur -= dec;
+            if (cur <= P0) { cur = P0; cs = i + 1; }
+            last = i + 1;
         }
     }
     cur += (i1 - last) * MA;
@@ -928,6 +934,13 @@ __device__ inline bool accept_rec(const KParams& P, u32 r, int n, bool use_xo) {
 #ifndef EXT_WAVES
 #define EXT_WAVES 4          // waves per SIMD the register allocator must leave room for (swept on MI355X)
 #endif
+// Take a ticket from queue q unless a plain look shows it already drained (a stale look only costs one atomic).
+__device__ inline u64 ext_steal(const EngineDev& E, u32 q, u64 begin, u64 end) {
+    u64 seen = __hip_atomic_load((u64*)&E.ctr->ext_q[q][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (begin + q + (u64)EXT_Q * seen >= end) return end;
+    return begin + q + (u64)EXT_Q * atomicAdd(&E.ctr->ext_q[q][0], 1ull);
+}
+
 template <int NB>
 __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ Ep, KParams P) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
@@ -936,17 +949,28 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
     __shared__ u32 s_cnt[16][3];
     const int tid = threadIdx.x, nthr = blockDim.x, nwv = blockDim.x >> 6;      // 64..1024 threads per work item
     for (int i = tid; i < 128; i += nthr) s_pentab[i] = E.pen_tab[i];
+    const int pen_def = __builtin_amdgcn_readfirstlane((int)E.pen_tab[40]);     // penalty of a Phred-40 mismatch
     u64 c_tot = 0, c_ign = 0;                     // block-level counters, flushed once at the end (thread 0)
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
     // Work queue: items cost different amounts (mismatch density, allele count of the locus), so blocks take the
     // next item from a counter instead of a fixed stride.  The ticket for item k+1 is drawn while item k is staged.
     __shared__ u64 s_next;
-    if (tid == 0) s_next = begin + atomicAdd(&E.ctr->ext_next, 1ull);
+    u32 myq = blockIdx.x % EXT_Q, tried = 0;      // thread 0 only: current queue, exhausted queues seen in a row
+    if (tid == 0) s_next = begin + myq + (u64)EXT_Q * atomicAdd(&E.ctr->ext_q[myq][0], 1ull);
     __syncthreads();
     u64 ii = uniform_u64(s_next);                 // readfirstlane: keeps the per-item descriptor loads and index math scalar
+    if (ii >= end) {                              // own queue already empty: steal (block-uniform branch)
+        if (tid == 0) {
+            u64 nx = ii;
+            while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal(E, myq, begin, end); }
+            s_next = nx; tried = 0;
+        }
+        __syncthreads();
+        ii = uniform_u64(s_next);
+    }
     while (ii < end) {                            // block-uniform
         u64 ticket = 0;
-        if (tid == 0) ticket = atomicAdd(&E.ctr->ext_next, 1ull);
+        if (tid == 0) ticket = atomicAdd(&E.ctr->ext_q[myq][0], 1ull);
         ItemDev it = E.items[ii];
         const LocusDev L = E.loci[it.locus];
         u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu); bool read_has_n = (lw & 0x8000u) != 0;
@@ -956,6 +980,12 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
         __syncthreads();
         const bool res_ok = it.res_off + L.n_pad <= E.cap_res;      // else flagged by k_seed
         const int floor_n = E.floor_tab[n];
+        u32 rl[NB], rh[NB], od[NB];               // block-uniform read planes, held in scalar registers
+        #pragma unroll
+        for (int w = 0; w < NB; w++) {
+            rl[w] = __builtin_amdgcn_readfirstlane(s_rl[w]); rh[w] = __builtin_amdgcn_readfirstlane(s_rh[w]);
+            od[w] = __builtin_amdgcn_readfirstlane(s_odd[w]);
+        }
         u32 nrec = 0, ndp = 0;
 #ifdef EXP_NO_ALLELES
         for (u32 a = tid; a < 0; a += nthr) {
@@ -964,11 +994,14 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
 #endif
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
-            int best = ungapped_planes<NB, false>(E, P, L, a, m, n, it.diag, s_rl, s_rh, s_rn, s_odd, s_pen, (int)s_pentab[40], read_has_n, mm, bs, be);
+            int best = ungapped_planes<NB, false>(E, P, L, a, m, n, it.diag, rl, rh, od, s_rn, s_pen, pen_def, read_has_n, mm, bs, be);
+#ifdef EXP_NO_KADANE
+            mm = 0;
+#endif
             int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
             bool need_dp = P.trig < 0;
             if (!need_dp && mm > P.trig && score >= floor_n) {       // rare: the policy needs the aligned span
-                ungapped_planes<NB, true>(E, P, L, a, m, n, it.diag, s_rl, s_rh, s_rn, s_odd, s_pen, (int)s_pentab[40], read_has_n, mm, bs, be);
+                ungapped_planes<NB, true>(E, P, L, a, m, n, it.diag, rl, rh, od, s_rn, s_pen, pen_def, read_has_n, mm, bs, be);
                 need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
             }
             u32 r = pack_result(score, xm, xo);
@@ -1018,7 +1051,11 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
             }
         }
 #endif
-        if (tid == 0) s_next = begin + ticket;
+        if (tid == 0) {
+            u64 nx = begin + myq + (u64)EXT_Q * ticket;
+            while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal(E, myq, begin, end); }
+            s_next = nx; tried = 0;
+        }
         __syncthreads();
         ii = uniform_u64(s_next);
     }
@@ -1257,7 +1294,8 @@ __global__ void k_advance(Counters* c, u64 n_reads) {
     u64 ni = c->n_items, nd = c->n_dp;
     c->cnt[MLST_CNT_CANDIDATES] += c->n_cand;
     c->cnt[MLST_CNT_READS_SEEN] += n_reads;
-    c->items_done = ni; c->dp_done = nd; c->n_cand = 0; c->ext_next = 0;
+    c->items_done = ni; c->dp_done = nd; c->n_cand = 0;
+    for (int q = 0; q < EXT_Q; q++) c->ext_q[q][0] = 0;
 }
 
 // ------------------------------------------------------------------ K6: pileup against the chosen allele of each locus
