@@ -778,11 +778,15 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
 // word (low bits, high bits), the mismatch mask of 32 columns is (rl ^ al) | (rh ^ ah): no bit gathering, and the
 // read planes come straight out of ballots.  k_extend is VALU-bound (a wave64 VALU op takes 4 cycles on a SIMD16),
 // so what counts here is instructions per (read, allele) pair.
-__device__ inline void stage_read_planes(const EngineDev& E, const KParams& P, const ItemDev& it, int n,
-                                         u32* s_rl, u32* s_rh, u32* s_rn, u32* s_odd, u8* s_pen, const u8* s_pentab, int tid, int nthreads) {
-    const u8 pen_def = s_pentab[40];
+// Returns the read's default mismatch penalty: the penalty of its middle base (reads are mostly one quality value --
+// Phred 40 in simulations, the top bin of binned instruments -- and only positions whose penalty differs from the
+// default cost an LDS lookup in the Kadane pass).  Any choice gives the same result; this one is only the fast one.
+__device__ inline int stage_read_planes(const EngineDev& E, const KParams& P, const ItemDev& it, int n,
+                                        u32* s_rl, u32* s_rh, u32* s_rn, u32* s_odd, u8* s_pen, const u8* s_pentab, int tid, int nthreads) {
     auto rb = E.ret_bases.g() + (u64)it.ret * RW;
     auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
+    const u8 qmid = rq[n >> 1];
+    const u8 pen_def = (qmid >> 7) ? (u8)P.n_penalty : s_pentab[qmid & 0x7F];
     for (int i0 = 0; i0 < RQ; i0 += nthreads) {
         int i = i0 + tid; u32 b = 0, isn = 0, odd = 0;
         if (i < n) {
@@ -800,6 +804,7 @@ __device__ inline void stage_read_planes(const EngineDev& E, const KParams& P, c
             s_rn[w] = (u32)bn; s_rn[w + 1] = (u32)(bn >> 32); s_odd[w] = (u32)bo; s_odd[w + 1] = (u32)(bo >> 32);
         }
     }
+    return (int)pen_def;
 }
 
 // uniform row pointer (scalar registers) + 32-bit byte offset of the lane: the saddr form of global_load
@@ -949,7 +954,6 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
     __shared__ u32 s_cnt[16][3];
     const int tid = threadIdx.x, nthr = blockDim.x, nwv = blockDim.x >> 6;      // 64..1024 threads per work item
     for (int i = tid; i < 128; i += nthr) s_pentab[i] = E.pen_tab[i];
-    const int pen_def = __builtin_amdgcn_readfirstlane((int)E.pen_tab[40]);     // penalty of a Phred-40 mismatch
     u64 c_tot = 0, c_ign = 0;                     // block-level counters, flushed once at the end (thread 0)
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
     // Work queue: items cost different amounts (mismatch density, allele count of the locus), so blocks take the
@@ -976,7 +980,7 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
         u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu); bool read_has_n = (lw & 0x8000u) != 0;
         u8 state = E.item_state[ii];
         __syncthreads();
-        stage_read_planes(E, P, it, n, s_rl, s_rh, s_rn, s_odd, s_pen, s_pentab, tid, nthr);
+        const int pen_def = __builtin_amdgcn_readfirstlane(stage_read_planes(E, P, it, n, s_rl, s_rh, s_rn, s_odd, s_pen, s_pentab, tid, nthr));
         __syncthreads();
         const bool res_ok = it.res_off + L.n_pad <= E.cap_res;      // else flagged by k_seed
         const int floor_n = E.floor_tab[n];
