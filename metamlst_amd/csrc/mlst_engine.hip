@@ -1069,6 +1069,27 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
     }
 }
 
+// ---- DPP lane moves (gfx9 encodings).  update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): a lane whose
+// source is out of range, or whose row is masked off, keeps `old`.
+#define DPP_ROW_SHR(n)  (0x110 + (n))
+#define DPP_WAVE_SHL1   0x130      /* lane i <- lane i+1 */
+#define DPP_WAVE_SHR1   0x138      /* lane i <- lane i-1 */
+#define DPP_ROW_BCAST15 0x142      /* lane 15 of each 16-lane row -> every lane of the next row */
+template <int CTRL, int ROW_MASK = 0xF> __device__ inline int dpp_i32(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive prefix maximum inside each 32-lane half of the wave (identity NEGP); max is exact, so any order of
+// combination gives the same integers as the serial recurrence
+__device__ inline int seg32_prefix_max(int v) {
+    int t;
+    t = dpp_i32<DPP_ROW_SHR(1)>(NEGP, v); v = t > v ? t : v;
+    t = dpp_i32<DPP_ROW_SHR(2)>(NEGP, v); v = t > v ? t : v;
+    t = dpp_i32<DPP_ROW_SHR(4)>(NEGP, v); v = t > v ? t : v;
+    t = dpp_i32<DPP_ROW_SHR(8)>(NEGP, v); v = t > v ? t : v;
+    t = dpp_i32<DPP_ROW_BCAST15, 0xA>(NEGP, v); v = t > v ? t : v;      // rows 1 and 3 take the total of rows 0 and 2
+    return v;
+}
+
 // ------------------------------------------------------------------ K4: banded affine Smith-Waterman (one lane per pair)
 // Band arrays live in registers (fully unrolled to 2*MAX_W+1 with a uniform guard).  Same recurrence and tie
 // rules as oracle align_banded.  TB != nullptr additionally stores the traceback byte of every cell.
@@ -1140,8 +1161,9 @@ __device__ inline int banded(const EngineDev& E, const KParams& P, const ItemDev
 __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep, KParams P) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     __shared__ u8 s_pentab[128];
-    __shared__ u32 s_qrow[8][RQ / 4];       // per pair (8 pairs per block): the read's quality row ...
-    __shared__ u32 s_brow[8][RW];           // ... and its packed bases, so a DP row costs no global-memory round trip
+    // per pair (8 pairs per block) and oriented read position: mismatch penalty | N flag << 8 | base << 9, so that a DP
+    // row costs one LDS read (fetched a row ahead) and no global-memory round trip
+    __shared__ u16 s_info[8][RQ];
     if (threadIdx.x < 128) s_pentab[threadIdx.x] = E.pen_tab[threadIdx.x];
     __syncthreads();
     const int b = threadIdx.x & 31, gl = threadIdx.x >> 5;
@@ -1163,30 +1185,33 @@ __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep
         const int m = live ? (int)E.allele_len[L.a_begin + a_local] : 0;
         __syncthreads();                      // previous pair's rows are no longer read (trip count is block-uniform)
         {
-            auto gq = reinterpret_cast<GP<const u32>::G*>(E.ret_quals.g() + (u64)it.ret * RQ);
+            auto gq = E.ret_quals.g() + (u64)it.ret * RQ;
             auto gb = E.ret_bases.g() + (u64)it.ret * RW;
-            for (int w = b; w < RQ / 4; w += 32) s_qrow[gl][w] = live ? gq[w] : 0u;
-            if (b < RW) s_brow[gl][b] = live ? gb[b] : 0u;
+            for (int i = b; i < n; i += 32) {
+                int s = it.strand ? n - 1 - i : i;
+                u8 qb = gq[s]; u32 isn = qb >> 7;
+                u32 rbase = (gb[s >> 4] >> (2 * (s & 15))) & 3u; if (it.strand) rbase ^= 3u;
+                u32 pen = isn ? (u32)P.n_penalty : (u32)s_pentab[qb & 0x7F];
+                s_info[gl][i] = (u16)(pen | (isn << 8) | (rbase << 9));
+            }
         }
         __syncthreads();
-        const u32* rb = s_brow[gl];
-        const u8* rq = reinterpret_cast<const u8*>(s_qrow[gl]);
         int Hp = P0, Fp = NEGP, best = P0;
         int jb = d - W, q = jb >> 4;
-        u32 w0 = arena_word(E, L, q, a_local), w1 = arena_word(E, L, q + 1, a_local), w2 = arena_word(E, L, q + 2, a_local);
-        u8 qb_next = n > 0 ? rq[it.strand ? n - 1 : 0] : (u8)0;
-        u32 rword = 0; int rword_idx = -1;
+        // allele bases of the band: words q..q+2 are in use, q+3 is the prefetch for the next word crossing (its
+        // load is not waited for until then)
+        u32 w0 = arena_word(E, L, q, a_local), w1 = arena_word(E, L, q + 1, a_local), w2 = arena_word(E, L, q + 2, a_local),
+            w3 = arena_word(E, L, q + 3, a_local);
+        u32 info_next = n > 0 ? (u32)s_info[gl][0] : 0u;
         for (int i = 0; i < nmax; i++, jb++) {
             bool row = i < n;
-            int s = it.strand ? n - 1 - i : i; if (!row) s = 0;
-            u8 qb = qb_next;
-            if (i + 1 < n) qb_next = rq[it.strand ? n - 2 - i : i + 1];
-            if (row && (s >> 4) != rword_idx) { rword_idx = s >> 4; rword = rb[rword_idx]; }
-            bool rn = (qb & 0x80) != 0;
-            u32 rbase = (rword >> (2 * (s & 15))) & 3u; if (it.strand) rbase ^= 3u;
-            int pen = rn ? P.n_penalty : (int)s_pentab[qb & 0x7F];
+            u32 info = info_next;
+            if (i + 1 < n) info_next = s_info[gl][i + 1];
+            bool rn = (info >> 8) & 1u;
+            u32 rbase = (info >> 9) & 3u;
+            int pen = (int)(info & 0xFFu);
             bool gap_ok = row && (i >= G && i < n - G);
-            if (row && (jb >> 4) != q) { q++; w0 = w1; w1 = w2; w2 = arena_word(E, L, q + 2, a_local); }
+            if (row && (jb >> 4) != q) { q++; w0 = w1; w1 = w2; w2 = w3; w3 = arena_word(E, L, q + 3, a_local); }
             int sh = 2 * (jb - 16 * q);
             u64 lo64 = (u64)w0 | ((u64)w1 << 32);
             u64 rowbits = sh ? ((lo64 >> sh) | ((u64)w2 << (64 - sh))) : lo64;
@@ -1196,16 +1221,18 @@ __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep
             bool an = L.has_n && exists && allele_is_n(E, L, j, a_local);
             int delta = (!rn && !an && rbase == ab) ? MA : -(((rn || an) ? P.n_penalty : pen) << MLST_P_SHIFT) - 1;
             int diag = Hp + delta;
-            int Hup = __shfl_down(Hp, 1, 32), Fup = __shfl_down(Fp, 1, 32);
+            // neighbours through DPP (register-to-register lane moves), not ds_bpermute: a row is a serial chain of
+            // ~8 lane exchanges, and the kernel is that chain times the read length.  Lane 31/63 of wave_shl is never
+            // consumed (b < BW - 1 <= 30 below).
+            int Hup = dpp_i32<DPP_WAVE_SHL1>(Hp, Hp), Fup = dpp_i32<DPP_WAVE_SHL1>(Fp, Fp);
             int f = NEGP;
             if (gap_ok && b < BW - 1) { int f1 = Hup - OPEN, f2 = Fup - EXT; f = f2 > f1 ? f2 : f1; }
             int h1 = P0; if (diag > h1) h1 = diag; if (f > h1) h1 = f;
             if (!exists) { h1 = P0; f = NEGP; }
             // exclusive prefix max of g = H' + EXT*b over the 32 lanes of the pair
             int g = h1 + EXT * b;
-            int x = __shfl_up(g, 1, 32); if (b < 1) x = NEGP;
-            #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) { int y = __shfl_up(x, o, 32); if (b >= o + 1 && y > x) x = y; }
+            int x = dpp_i32<DPP_WAVE_SHR1>(NEGP, g); if (b < 1) x = NEGP;
+            x = seg32_prefix_max(x);
             int ee = (gap_ok && b > 0) ? x - OPEN - EXT * (b - 1) : NEGP;
             int h = h1; if (ee > h) h = ee;
             if (!exists) h = P0;
