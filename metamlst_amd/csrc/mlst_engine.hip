@@ -111,7 +111,7 @@ struct ItemDev {         // one (read, locus, strand, diagonal) unit of extensio
 };
 #define EXT_Q 32
 struct Counters {
-    u64 n_cand, n_ret, n_items, n_res, n_dp, items_done, dp_done, n_pl_dp;
+    u64 n_cand, n_ret, n_items, n_res, n_dp, items_done, dp_done, n_pl_dp, ret_done;
     // k_extend work queues: queue q hands out the items begin + q + EXT_Q * t of this submission.  One counter would
     // see ~1 returning atomic per item, and a single word sustains only ~90 of those per microsecond; the queues
     // sit in separate 128-byte lines.
@@ -554,32 +554,67 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             const u8* qrow = qrows + (u64)r * qstride;
             Bin* bins = s_bins[tid]; int nb = 0;
             int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-            for (int t = 0; t < nseeds; t++) {
-                int o = t * MLST_SEED_STEP;
-                if (has_n) { bool bad = false; for (int k = 0; k < MLST_SEED_LEN; k++) bad |= (qrow[o + k] & 0x80) != 0; if (bad) continue; }
-                u32 sflag; u64 ck = canon40((u64)row[t] | ((u64)(row[t + 1] & 0xFFu) << 32), sflag);
-                u32 lo = (u32)ck, hi = (u32)(ck >> 32), val;
-                if (!table_find(E, lo, hi, val)) continue;
-                u32 pstart, pcount; u32 single = 0;
-                if (val & 0x80000000u) { single = val & 0x7FFFFFFFu; pstart = 0; pcount = 1; }
-                else { pstart = val >> 5; pcount = val & 31u; }
-                // postings are stored sorted by (locus, flag, pos); visit them in (locus, strand, pos) order with
-                // strand = flag XOR sflag -- the order the non-canonical index of the oracle has
-                u32 last_key = 0; bool first = true;
-                for (u32 k = 0; k < pcount; k++) {
-                    u32 post;
-                    if (val & 0x80000000u) post = single ^ (sflag << 12);
-                    else if (!sflag) post = E.posts[pstart + k];
-                    else {      // k-th smallest of the flag-flipped postings (pcount <= 16)
-                        u32 bestp = 0xFFFFFFFFu;
-                        for (u32 pp = 0; pp < pcount; pp++) { u32 x = E.posts[pstart + pp] ^ (1u << 12); if ((first || x > last_key) && x < bestp) bestp = x; }
-                        post = bestp; last_key = bestp; first = false;
+            // The lane's work is a chain of dependent look-ups (key -> value -> postings); a kernel over ~10^4
+            // candidates is as long as one lane's chain.  So the look-ups of up to SEED_CHUNK seeds are issued
+            // together: all keys, then all values; only probe chains longer than one slot are walked serially.
+            constexpr int SEED_CHUNK = 10;
+            for (int t0 = 0; t0 < nseeds; t0 += SEED_CHUNK) {
+                u32 wv[SEED_CHUNK + 1];
+                #pragma unroll
+                for (int u = 0; u <= SEED_CHUNK; u++) { wv[u] = 0; if ((u32)(t0 + u) < wpr) wv[u] = row[t0 + u]; }
+                tie_all<SEED_CHUNK + 1>(wv);
+                u32 klo[SEED_CHUNK], khi[SEED_CHUNK], slot[SEED_CHUNK], sfl[SEED_CHUNK], k0[SEED_CHUNK], k1[SEED_CHUNK]; u32 okm = 0;
+                #pragma unroll
+                for (int u = 0; u < SEED_CHUNK; u++) {
+                    int t = t0 + u; bool ok = t < nseeds;
+                    klo[u] = khi[u] = slot[u] = sfl[u] = 0; k0[u] = k1[u] = 0xFFFFFFFFu;
+                    if (ok && has_n) { int o = t * MLST_SEED_STEP; bool bad = false; for (int k = 0; k < MLST_SEED_LEN; k++) bad |= (qrow[o + k] & 0x80) != 0; ok = !bad; }
+                    if (ok) {
+                        u32 sflag; u64 ck = canon40((u64)wv[u] | ((u64)(wv[u + 1] & 0xFFu) << 32), sflag);
+                        klo[u] = (u32)ck; khi[u] = (u32)(ck >> 32); sfl[u] = sflag;
+                        slot[u] = table_hash(klo[u], khi[u]) & E.table_mask;
+                        u64 kk = E.keys[slot[u]]; k0[u] = (u32)kk; k1[u] = (u32)(kk >> 32);
+                        okm |= 1u << u;
                     }
-                    u32 locus = post >> 13, strand = (post >> 12) & 1; int pos = (int)(post & 0xFFFu);
-                    int diag = strand ? pos + MLST_SEED_LEN + o - (int)n : pos - o;
-                    int kk; for (kk = 0; kk < nb; kk++) if (bins[kk].locus == locus && bins[kk].strand == strand && bins[kk].diag == diag) break;
-                    if (kk < nb) bins[kk].votes++;
-                    else if (nb < MLST_MAX_CAND) { bins[nb].locus = locus; bins[nb].strand = (u16)strand; bins[nb].diag = diag; bins[nb].votes = 1; nb++; }
+                }
+                tie_all<SEED_CHUNK>(k0); tie_all<SEED_CHUNK>(k1);
+                u32 vals[SEED_CHUNK]; u32 found = 0;
+                #pragma unroll
+                for (int u = 0; u < SEED_CHUNK; u++) {
+                    vals[u] = 0;
+                    if (!((okm >> u) & 1u)) continue;
+                    if (k0[u] == klo[u] && k1[u] == khi[u]) { vals[u] = E.vals[slot[u]]; found |= 1u << u; }
+                    else if (!(k0[u] == 0xFFFFFFFFu && k1[u] == 0xFFFFFFFFu)) {      // occupied by another key: walk the chain
+                        u32 v; if (table_find(E, klo[u], khi[u], v)) { vals[u] = v; found |= 1u << u; }
+                    }
+                }
+                tie_all<SEED_CHUNK>(vals);
+                #pragma unroll
+                for (int u = 0; u < SEED_CHUNK; u++) {
+                    if (!((found >> u) & 1u)) continue;
+                    const int o = (t0 + u) * MLST_SEED_STEP;
+                    const u32 val = vals[u], sflag = sfl[u];
+                    u32 pstart, pcount; u32 single = 0;
+                    if (val & 0x80000000u) { single = val & 0x7FFFFFFFu; pstart = 0; pcount = 1; }
+                    else { pstart = val >> 5; pcount = val & 31u; }
+                    // postings are stored sorted by (locus, flag, pos); visit them in (locus, strand, pos) order with
+                    // strand = flag XOR sflag -- the order the non-canonical index of the oracle has
+                    u32 last_key = 0; bool first = true;
+                    for (u32 k = 0; k < pcount; k++) {
+                        u32 post;
+                        if (val & 0x80000000u) post = single ^ (sflag << 12);
+                        else if (!sflag) post = E.posts[pstart + k];
+                        else {      // k-th smallest of the flag-flipped postings (pcount <= 16)
+                            u32 bestp = 0xFFFFFFFFu;
+                            for (u32 pp = 0; pp < pcount; pp++) { u32 x = E.posts[pstart + pp] ^ (1u << 12); if ((first || x > last_key) && x < bestp) bestp = x; }
+                            post = bestp; last_key = bestp; first = false;
+                        }
+                        u32 locus = post >> 13, strand = (post >> 12) & 1; int pos = (int)(post & 0xFFFu);
+                        int diag = strand ? pos + MLST_SEED_LEN + o - (int)n : pos - o;
+                        int kk; for (kk = 0; kk < nb; kk++) if (bins[kk].locus == locus && bins[kk].strand == strand && bins[kk].diag == diag) break;
+                        if (kk < nb) bins[kk].votes++;
+                        else if (nb < MLST_MAX_CAND) { bins[nb].locus = locus; bins[nb].strand = (u16)strand; bins[nb].diag = diag; bins[nb].votes = 1; nb++; }
+                    }
                 }
             }
             // one item per (locus, strand): most votes, then the smaller diagonal; first-seen order
@@ -605,19 +640,9 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
                 if (slot >= E.cap_ret) { atomicOr(&E.ctr->err, 1ull); slot = ~0ull; no = 0; }
             }
         }
-        u64 todo = __ballot(no > 0);
-        while (todo) {        // the 400-byte copy of each kept read is done by the whole wave
-            int src = __ffsll((long long)todo) - 1; todo &= todo - 1;
-            u32 rr = __shfl(r, src), nn = __shfl(n, src), lww = __shfl(lw, src);
-            u64 sl = __shfl(slot, src);
-            const u32* row = packed + (u64)rr * wpr;
-            const u32* qrow32 = reinterpret_cast<const u32*>(qrows + (u64)rr * qstride);
-            auto dq = reinterpret_cast<GP<u32>::G*>(E.ret_quals.g() + sl * RQ);
-            if (lane < RW) E.ret_bases[sl * RW + lane] = (u32)lane < wpr ? row[lane] : 0u;
-            u32 nq = (nn < qstride ? nn : qstride);        // bytes to keep; rows hold zeros beyond the read length
-            for (u32 w = lane; w < RQ / 4; w += 64) dq[w] = (w * 4 < nq) ? qrow32[w] : 0u;
-            if (lane == 0) { E.ret_len[sl] = (u16)lww; E.ret_ridx[sl] = read_base + rr; E.ret_nrec[sl] = 0; }
-        }
+        // the 400-byte copy of each kept read is left to k_retain (one half-block per read, all reads in parallel);
+        // doing it here, read after read inside the wave, was the longest chain of this kernel
+        if (no > 0) { E.ret_len[slot] = (u16)lw; E.ret_ridx[slot] = read_base + r; E.ret_nrec[slot] = 0; }
         // item slots and result rows: wave prefix sums, one atomic per counter per wave
         u32 my_res = 0;
         for (int u = 0; u < no; u++) my_res += E.loci[items[u].locus].n_pad;
@@ -639,6 +664,26 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             E.items[ib + u] = itd;
             E.item_state[ib + u] = (u8)(no == 1 ? IS_SINGLE : 0);
             ro += np;
+        }
+    }
+}
+
+// Copy the reads k_seed decided to keep into the retained-read arena: 128 lanes per read (20 base words + 80 quality
+// words), every read of the submission in parallel.
+__global__ __launch_bounds__(256) void k_retain(const EngineDev* __restrict__ Ep, const u32* __restrict__ packed, const u8* __restrict__ qrows,
+                                                 u32 wpr, u32 qstride, u64 read_base) {
+    const EngineDev& E = *Ep;
+    const u64 begin = E.ctr->ret_done, end = E.ctr->n_ret < E.cap_ret ? E.ctr->n_ret : E.cap_ret;
+    const u32 sub = threadIdx.x & 127;
+    for (u64 sl = begin + (u64)blockIdx.x * 2 + (threadIdx.x >> 7); sl < end; sl += (u64)gridDim.x * 2) {
+        const u64 rr = E.ret_ridx[sl] - read_base;
+        const u32 nn = E.ret_len[sl] & 0x7FFFu;
+        if (sub < RW) E.ret_bases[sl * RW + sub] = sub < wpr ? packed[rr * wpr + sub] : 0u;
+        else if (sub < RW + RQ / 4) {
+            const u32 w = sub - RW;
+            const u32 nq = nn < qstride ? nn : qstride;        // bytes to keep; rows hold zeros beyond the read length
+            const u32* qrow32 = reinterpret_cast<const u32*>(qrows + rr * qstride);
+            reinterpret_cast<GP<u32>::G*>(E.ret_quals.g() + sl * RQ)[w] = (w * 4 < nq) ? qrow32[w] : 0u;
         }
     }
 }
@@ -1322,7 +1367,7 @@ __global__ __launch_bounds__(256) void k_locus(const EngineDev* __restrict__ Ep)
 }
 
 __global__ void k_advance(Counters* c, u64 n_reads) {
-    u64 ni = c->n_items, nd = c->n_dp;
+    u64 ni = c->n_items, nd = c->n_dp; c->ret_done = c->n_ret;
     c->cnt[MLST_CNT_CANDIDATES] += c->n_cand;
     c->cnt[MLST_CNT_READS_SEEN] += n_reads;
     c->items_done = ni; c->dp_done = nd; c->n_cand = 0;
@@ -1901,7 +1946,8 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       }
     }
     { Prof pf(h, 1);
-      hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand); }
+      hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand);
+      hipLaunchKernelGGL(k_retain, dim3(1024), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
     { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
       const int thr = h->ext_threads, blocks = h->ext_blocks;
       if (wpr <= 10) hipLaunchKernelGGL(k_extend<5>, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
