@@ -192,7 +192,8 @@ int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint64_t* n);
 int mlst_set_profiling(mlst_handle* h, int on);
 int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms, uint64_t* launches);
 int mlst_reset_kernel_time(mlst_handle* h);
-/* Bytes of the device-resident index structures: [0]=allele arena [1]=sieve [2]=seed table */
+/* Bytes of the device-resident index structures: [0]=allele arena [1]=sieve [2]=seed table;
+ * [3]=fill of the LDS first-level bitmap in parts per million (0 when the plain sieve kernel is in use) */
 int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]);
 /* Block until all work queued on the engine's stream is done. */
 int mlst_synchronize(mlst_handle* h);

@@ -176,7 +176,7 @@ template <int N, typename T> __device__ inline void tie_all(T (&v)[N]) {
 }
 
 __device__ inline u64 uniform_u64(u64 v) {
-    return ((u64)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) | (u64)__builtin_amdgcn_readfirstlane((u32)v);
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)v);   // the builtin returns int: cast before widening
 }
 
 // ------------------------------------------------------------------ K0: pack
@@ -325,28 +325,48 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
     }
 }
 
-// Sieve with an LDS-resident first level.  One 1024-thread workgroup per CU keeps a 2^20-bit membership bitmap of
-// the canonical seeds in LDS (128 KiB); a seed costs an L2 request only when its bit is set.  Rows are read straight
-// from global memory (lane = read, 8-byte non-temporal loads; the wave's rows are contiguous).  Used when the
-// database is small enough for the bitmap to be selective.
+// Sieve with an LDS-resident first level.  One 1024-thread workgroup per CU keeps a 2^20-bit bitmap in LDS (128 KiB)
+// that is indexed DIRECTLY by one 10-base half of the seed, in an orientation that does not depend on the strand:
+//   A   = bases 0..9 of the seed,   rcB = reverse complement of bases 10..19   (the pair {A, rcB} is the same set for
+//   a seed and for its reverse complement);  L = sieve_half_pick(A, rcB) picks one of the two by a circular
+//   comparison, which keeps L uniformly distributed.
+// Indexing by half of the bases makes the alleles' SNP variants collapse: a SNP changes 20 seeds but only ~10 distinct
+// L values, so the bitmap of an MLST database is about half as full as a hashed bitmap of whole seeds (measured on
+// the 7 x 1430-allele database: 19 % against 35 %), and it needs no multiply.  The builder sets the bit of BOTH
+// orientations of every database seed, so the pick never has to be consistent across strands.
+// Seeds whose bit is set (a fifth of them) are compacted per wave into an LDS queue and only the queue is checked
+// against the fingerprint sieve -- two rounds of 64 probes per 64 reads instead of nine.  Rows are read straight from
+// global memory (lane = read, 8-byte non-temporal loads, the next tile requested a whole tile ahead).
+#define SV_CAP 224            // queue entries per wave (8 bytes each); drained early when it could overflow
+__host__ __device__ inline u32 sieve_half_pick(u32 A, u32 rcB) { return ((A - rcB) & 0x80000u) ? rcB : A; }
+__host__ inline u32 sieve_half_of(u64 s) {            // host restatement for the builder: s = 40-bit seed, base t at bits 2t
+    u32 A = (u32)(s & 0xFFFFFu), rcB = 0;
+    for (int q = 0; q < 10; q++) rcB |= (u32)(3u - (u32)((s >> (2 * (19 - q))) & 3u)) << (2 * q);
+    return sieve_half_pick(A, rcB);
+}
 template <int WPR>
 __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
                                                      const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ bitmap,
                                                      u32* __restrict__ cand, Counters* __restrict__ ctr) {
-    __shared__ __attribute__((aligned(16))) u32 s_bm[(1u << BITMAP_BITS) / 32];
+    // one LDS block, queue first so that its addresses fit the DS offset field: [queues 16 x SV_CAP x 8 B][hit masks][bitmap]
+    constexpr u32 Q_WORDS = 16 * SV_CAP * 2, H_WORDS = 32, BM_OFF = Q_WORDS + H_WORDS;
+    __shared__ __attribute__((aligned(16))) u32 s_all[BM_OFF + (1u << BITMAP_BITS) / 32];
+    u32* const s_bm = s_all + BM_OFF;
     const u32 sshift = (u32)__clz((int)smask);       // buckets = smask + 1 = 2^(32 - sshift)
     constexpr int NT = WPR - 1;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u64* const queue = reinterpret_cast<u64*>(s_all) + wave * SV_CAP;
+    u32* const hitw = s_all + Q_WORDS + wave * 2;
     {   // 32768 words, 16-byte vectors
         const v4u* g4 = reinterpret_cast<const v4u*>(bitmap); v4u* s4 = reinterpret_cast<v4u*>(s_bm);
         #pragma unroll
         for (int k = 0; k < 8; k++) s4[tid + 1024 * k] = g4[tid + 1024 * k];
+        if (tid < (int)H_WORDS) s_all[Q_WORDS + tid] = 0;
     }
     __syncthreads();
     const u64 n_tiles = (n_reads + 1023) / 1024;
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-    // software pipeline: the rows (and lengths) of the NEXT tile are requested before the current tile is processed
-    v2u xn[WPR / 2]; u16 len_raw = 0; bool live_next = false;   // the raw length is only looked at one iteration later
+    v2u xn[WPR / 2]; u16 len_raw = 0; bool live_next = false;
     {
         u64 r = (u64)blockIdx.x * 1024 + tid;
         live_next = blockIdx.x < n_tiles && r < n_reads;
@@ -356,67 +376,93 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
         len_raw = lens[live_next ? r : 0];
     }
     for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        u64 r = tile * 1024 + tid;
-        u32 n = live_next ? (u32)(len_raw & 0x7FFFu) : 0u;
-        int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
+        const u64 r = tile * 1024 + tid;
+        const u32 n = live_next ? (u32)(len_raw & 0x7FFFu) : 0u;
+        const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
         u32 w[WPR];
         #pragma unroll
         for (int t2 = 0; t2 < WPR / 2; t2++) { w[2 * t2] = xn[t2].x; w[2 * t2 + 1] = xn[t2].y; }
-        u32 klo[NT], khi[NT]; u32 pass = 0;
-        #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            u32 fl; u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl); klo[t] = (u32)c; khi[t] = (u32)(c >> 32);
-            u32 bi = bitmap_hash(klo[t], khi[t]);
-            u32 bit = (s_bm[bi >> 5] >> (bi & 31)) & 1u;
-            pass |= (t < nseeds ? bit : 0u) << t;
-        }
-        // second level: the fingerprint sieve, only for seeds whose bit is set.  Order matters: probes are issued
-        // first, then the next tile's rows (vmcnt retires in order, so waiting for the probes leaves the younger
-        // row loads in flight across the rest of this tile).
-        v4u bv[NT];
-        #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            bv[t] = v4u{0u, 0u, 0u, 0u};
-            if ((pass >> t) & 1u) bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) >> sshift];
-        }
-        {
+        {   // rows of the next tile: requested now, used one iteration later.  The memory clobber keeps the compiler
+            // from sinking the loads to the end of the iteration (it would, to their first use).
             u64 tn = tile + gridDim.x; u64 rn = tn * 1024 + tid;
             live_next = tn < n_tiles && rn < n_reads;
             const v2u* row = reinterpret_cast<const v2u*>(packed + (live_next ? rn : 0) * WPR);
             #pragma unroll
             for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2);
             len_raw = lens[live_next ? rn : 0];
+            asm volatile("" ::: "memory");
         }
-        tie_all<NT>(bv);
-        bool hit = false;
-        u32 pending = 0;
+        // ---- first level: per word the bit-reversed swapped complement (rb[i] base p = complement of w[i] base 15-p),
+        // per seed the two halves, the pick and one LDS bit
+        u32 rb[WPR];
+        #pragma unroll
+        for (int i = 0; i < WPR; i++) {
+            u32 x = w[i];
+            rb[i] = __brev(~(((x >> 1) & 0x55555555u) | ((x + x) & 0xAAAAAAAAu)));
+        }
+        const bool all_full = __all(nseeds >= NT) != 0;
+        u64 pm[NT];
         #pragma unroll
         for (int t = 0; t < NT; t++) {
-            bool full; bool f = bucket_has(make_uint4(bv[t].x, bv[t].y, bv[t].z, bv[t].w), sieve_fp(klo[t], khi[t]), full);
-            bool valid = (pass >> t) & 1u;
-            hit |= valid && f;
-            pending |= (valid && !f && full) ? (1u << t) : 0u;
+            u32 A = w[t] & 0xFFFFFu;
+            u32 rcB = __builtin_amdgcn_alignbit(rb[t], rb[t + 1], 24) & 0xFFFFFu;
+            u32 L = sieve_half_pick(A, rcB);
+            u32 word = s_bm[L >> 5];
+            pm[t] = __ballot(((word >> (L & 31)) & 1u) != 0);
         }
-        while (pending && !hit) {   // overflow chain: the key may sit in a following bucket
-            int t = __ffs(pending) - 1; pending &= pending - 1;
-            u32 lo = 0, hi = 0;
+        if (!all_full) {
             #pragma unroll
-            for (int u = 0; u < NT; u++) if (u == t) { lo = klo[u]; hi = khi[u]; }
-            u32 fp = sieve_fp(lo, hi); u32 bi = sieve_bucket_hash(lo, hi) >> sshift;
-            for (int step = 0; step < 64; step++) {
-                bi = (bi + 1) & smask; bool full; uint4 bb = sieve[bi];
-                if (bucket_has(bb, fp, full)) { hit = true; break; }
-                if (!full) break;
-            }
+            for (int t = 0; t < NT; t++) pm[t] &= __ballot(t < nseeds);
         }
-        u64 mask = __ballot(hit);
+        // ---- second level: queue the passing seeds of the wave, then probe the fingerprint sieve queue-wise
+        int t0 = 0;
+        do {
+            u32 cnt = 0; int t_next = NT;
+            #pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (t < t0 || t >= t_next) continue;
+                const u64 m = pm[t];
+                if (m == 0) continue;
+                if (cnt > SV_CAP - 64) { t_next = t; continue; }
+                u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, cnt));
+                if (__builtin_amdgcn_inverse_ballot_w64(m))
+                    queue[pos] = (u64)w[t] | ((u64)((w[t + 1] & 0xFFu) | ((u32)lane << 8)) << 32);
+                cnt += (u32)__popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (u32 base = 0; base < cnt; base += 64) {
+                const u32 e = base + (u32)lane; const bool act = e < cnt;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const u64 ent = act ? queue[e] : 0ull;
+                u32 fl; const u64 c = canon40(ent & 0xFFFFFFFFFFull, fl);
+                const u32 klo = (u32)c, khi = (u32)(c >> 32), src = (u32)(ent >> 40) & 63u;
+                v4u bv = v4u{0u, 0u, 0u, 0u};
+                if (act) bv = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo, khi) >> sshift];
+                const u32 fp = sieve_fp(klo, khi);
+                bool full; bool hit = bucket_has(make_uint4(bv.x, bv.y, bv.z, bv.w), fp, full);
+                hit = hit && act;
+                if (act && !hit && full) {   // overflow chain: the key may sit in a following bucket
+                    u32 bi = sieve_bucket_hash(klo, khi) >> sshift;
+                    for (int step = 0; step < 64; step++) {
+                        bi = (bi + 1) & smask; bool f2; uint4 bb = sieve[bi];
+                        if (bucket_has(bb, fp, f2)) { hit = true; break; }
+                        if (!f2) break;
+                    }
+                }
+                if (hit) atomicOr(&hitw[src >> 5], 1u << (src & 31));
+            }
+            t0 = t_next;
+        } while (t0 < NT);
+        // ---- candidates of the wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u64 mask = (u64)hitw[0] | ((u64)hitw[1] << 32);
+        mask = uniform_u64(mask);
         if (mask) {
-            int lane = tid & 63;
-            int leader = __ffsll((long long)mask) - 1;
+            if (lane < 2) hitw[lane] = 0;
             u64 base = 0;
-            if (lane == leader) base = atomicAdd(&ctr->n_cand, (u64)__popcll(mask));
-            base = __shfl(base, leader);
-            if (hit) cand[base + __popcll(mask & ((1ull << lane) - 1))] = (u32)r;
+            if (lane == 0) base = atomicAdd(&ctr->n_cand, (u64)__popcll(mask));
+            base = __shfl(base, 0);
+            if ((mask >> lane) & 1ull) cand[base + __popcll(mask & ((1ull << lane) - 1))] = (u32)r;
         }
     }
 }
@@ -1533,7 +1579,7 @@ struct mlst_handle {
     u32* d_arena = nullptr; u32* d_planes = nullptr; u32* d_nmask = nullptr; u16* d_allele_len = nullptr; u32* d_allele_locus = nullptr;
     LocusDev* d_loci = nullptr; uint4* d_sieve = nullptr; u32* d_bitmap = nullptr; u32* d_gbitmap = nullptr; u64* d_keys = nullptr; u32* d_vals = nullptr; u32* d_posts = nullptr;
     int* d_floor = nullptr; u8* d_pen = nullptr; u8* d_ascii = nullptr; u64* d_aoff = nullptr;
-    u64 bytes_arena = 0, bytes_sieve = 0, bytes_table = 0;
+    u64 bytes_arena = 0, bytes_sieve = 0, bytes_table = 0; double bitmap_fill = 0.0;
     EngineDev E; EngineDev* d_E = nullptr;      // host copy and its device-resident twin
     bool have_ref = false, have_state = false;
     // batch scratch
@@ -1798,9 +1844,16 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     {
         const u64 nbits = 1ull << BITMAP_BITS;
         const char* off_sw = getenv("MLST_NO_LDS_SIEVE");   // test / tuning switch: force the plain sieve kernel
-        if (nk * 2 <= nbits && !(off_sw && off_sw[0] == '1')) {       // expected fill <= 1 - exp(-0.5) = 39 %
+        if (nk <= 4 * nbits && !(off_sw && off_sw[0] == '1')) {       // kept only if it turns out at most half full
             bitmap.assign(nbits / 32, 0);
-            for (u64 i = 0; i < nk; i++) { u32 bi = bitmap_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32)); bitmap[bi >> 5] |= 1u << (bi & 31); }
+            u64 set = 0;
+            for (u64 i = 0; i < nk; i++) {      // both orientations of every seed (see k_sieve_lds)
+                u32 b0 = sieve_half_of(ukeys[i]), b1 = sieve_half_of(revcomp40(ukeys[i]));
+                if (!((bitmap[b0 >> 5] >> (b0 & 31)) & 1u)) { bitmap[b0 >> 5] |= 1u << (b0 & 31); set++; }
+                if (!((bitmap[b1 >> 5] >> (b1 & 31)) & 1u)) { bitmap[b1 >> 5] |= 1u << (b1 & 31); set++; }
+            }
+            h->bitmap_fill = (double)set / (double)nbits;
+            if (set * 2 > nbits) { bitmap.clear(); h->bitmap_fill = 0.0; }   // more than half full: not selective, use the plain kernel
         }
     }
     // ---- larger first-level bitmap in global memory when the LDS one is not used (big databases)
@@ -2267,6 +2320,6 @@ extern "C" int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms,
 extern "C" int mlst_reset_kernel_time(mlst_handle* h) { if (!h) return MLST_E_INVALID; drain_events(h); for (int i = 0; i < 8; i++) { h->k_ms[i] = 0; h->k_n[i] = 0; } return MLST_OK; }
 extern "C" int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]) {
     if (!h || !out) return MLST_E_INVALID;
-    out[0] = h->bytes_arena; out[1] = h->bytes_sieve; out[2] = h->bytes_table; out[3] = 0; return MLST_OK;
+    out[0] = h->bytes_arena; out[1] = h->bytes_sieve; out[2] = h->bytes_table; out[3] = (u64)(h->bitmap_fill * 1e6); return MLST_OK;
 }
 extern "C" int mlst_synchronize(mlst_handle* h) { if (!h) return MLST_E_INVALID; hipSetDevice(h->device); HIPCHK(h, hipStreamSynchronize(h->stream)); return MLST_OK; }
