@@ -65,7 +65,7 @@ def synth_reads_gpu(eng, torch, device, genome: np.ndarray, n_reads: int, L: int
     for k, a in enumerate(b"ACGT"):
         code[a] = k
     acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
-    packed = torch.zeros(n_reads * wpr + 4, dtype=torch.int32, device=device)
+    packed = torch.zeros((n_reads + 63) // 64 * 64 * wpr + 4, dtype=torch.int32, device=device)   # whole groups of 64 rows (mlst.h)
     qrows = torch.zeros(n_reads * qstride, dtype=torch.uint8, device=device)
     lens = torch.zeros(n_reads + 2, dtype=torch.int16, device=device)
     ar = torch.arange(L, device=device)
@@ -89,6 +89,22 @@ def synth_reads_gpu(eng, torch, device, genome: np.ndarray, n_reads: int, L: int
         eng.synchronize()
         del b, q, err, sub, start, rev, off
     return packed, qrows, lens, wpr, qstride
+
+
+def tiled_to_rows(packed, n_reads: int, wpr: int):
+    """Resident 2-bit rows (groups of 64 reads, transposed in 8-byte units, include/mlst.h) -> plain [n_reads, wpr] rows."""
+    g = (n_reads + 63) // 64
+    return packed[:g * 64 * wpr].view(g, wpr // 2, 64, 2).permute(0, 2, 1, 3).reshape(g * 64, wpr)[:n_reads]
+
+
+def rows_to_tiled(rows, torch):
+    """Plain [n, wpr] rows -> the resident group-transposed layout (+4 words of slack)."""
+    n, wpr = rows.shape
+    g = (n + 63) // 64
+    pad = torch.zeros((g * 64, wpr), dtype=rows.dtype, device=rows.device)
+    pad[:n] = rows
+    t = pad.view(g, 64, wpr // 2, 2).permute(0, 2, 1, 3).contiguous().view(-1)
+    return torch.cat([t, torch.zeros(4, dtype=rows.dtype, device=rows.device)])
 
 
 def main():

@@ -33,7 +33,7 @@ def main():
     import torch
     import __graft_entry__ as ge
     ge.build()
-    from bench import synth_reads_gpu
+    from bench import rows_to_tiled, synth_reads_gpu, tiled_to_rows
     from metamlst_amd import db as mdb
     from metamlst_amd import synth
     from metamlst_amd.engine import Engine
@@ -66,13 +66,12 @@ def main():
         g, _ = synth.make_genome(sdb, sp, sdb.profiles[sp][st_row], size=a.genome_size, seed=1000 + k)
         n = max(1000, int(a.reads * frac))
         p, q, l, wpr, qstride = synth_reads_gpu(eng, torch, device, g, n, 150, seed=2000 + k)
-        packed_all.append(p[:n * wpr]); q_all.append(q[:n * qstride]); l_all.append(l[:n]); parts.append((sp, n))
+        packed_all.append(tiled_to_rows(p, n, wpr)); q_all.append(q[:n * qstride]); l_all.append(l[:n]); parts.append((sp, n))
     n_total = sum(n for _, n in parts)
     perm = torch.randperm(n_total, device=device)
-    packed = torch.cat(packed_all).view(n_total, wpr)[perm].contiguous().view(-1)
+    packed = rows_to_tiled(torch.cat(packed_all)[perm].contiguous(), torch)
     qrows = torch.cat(q_all).view(n_total, qstride)[perm].contiguous().view(-1)
     lens = torch.cat([torch.cat(l_all)[perm], torch.zeros(2, dtype=torch.int16, device=device)])
-    packed = torch.cat([packed, torch.zeros(4, dtype=torch.int32, device=device)])
     del packed_all, q_all, l_all
     database = mdb.metaMLST_db(sdb.path)
     cache = mdb.DbCache(database.conn)
@@ -112,7 +111,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         n_o = min(a.oracle_reads, n_total)
-        pk = packed[:n_o * wpr].cpu().numpy().view(np.uint32).reshape(n_o, wpr)
+        pk = tiled_to_rows(packed, n_total, wpr)[:n_o].cpu().numpy().view(np.uint32).reshape(n_o, wpr)
         qr = qrows[:n_o * qstride].cpu().numpy().reshape(n_o, qstride)
         codes = np.zeros((n_o, wpr * 16), np.uint8)
         for k in range(16):

@@ -103,10 +103,18 @@ int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int
 int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
                              const uint64_t* d_off, uint64_t n_reads, uint32_t max_len, int paired);
 
-/* Pack ASCII reads (device) into the resident format (device): 2-bit bases in fixed-stride
- * rows of words_per_read uint32 (base k at bits 2(k%16) of word k/16, A=0 C=1 G=2 T=3),
- * quality rows of qual_stride bytes holding raw Phred with bit 7 set for a non-ACGT base,
- * and uint16 lengths.  This is the layout SURVEY.md 8(d) prices at 38+150 B per 150 bp read. */
+/* Pack ASCII reads (device) into the resident format (device): 2-bit bases in rows of
+ * words_per_read uint32 (even; base k at bits 2(k%16) of word k/16, A=0 C=1 G=2 T=3), quality rows
+ * of qual_stride bytes holding raw Phred with bit 7 set for a non-ACGT base, and uint16 lengths
+ * (bit 15 = the read holds a non-ACGT base).  This is the layout SURVEY.md 8(d) prices at 38+150 B
+ * per 150 bp read.
+ * The 2-bit rows are stored in groups of 64 reads, transposed in 8-byte units so that 64 lanes
+ * owning the 64 reads of a group load every unit with one coalesced 512-byte access: words 2u and
+ * 2u+1 of read r are the uint32 at
+ *     (r / 64) * 64 * words_per_read  +  ((u * 64 + r % 64) * 2)   and the one after it.
+ * d_packed must hold ceil(n_reads / 64) * 64 * words_per_read words (the rows that pad the last
+ * group are written as zeros) and be 16-byte aligned; a batch that is packed in pieces must cut the
+ * pieces at multiples of 64 reads. */
 int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
                            const uint64_t* d_off, uint64_t n_reads,
                            uint32_t* d_packed, uint8_t* d_qual_rows, uint16_t* d_lens,

@@ -179,15 +179,27 @@ __device__ inline u64 uniform_u64(u64 v) {
     return ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)v);   // the builtin returns int: cast before widening
 }
 
+// ------------------------------------------------------------------ resident read format
+// 2-bit rows are stored in groups of 64 reads, transposed in 8-byte units: unit u (words 2u, 2u+1) of read i of a group
+// sits at 8-byte index group*64*(wpr/2) + u*64 + i.  A wave whose lanes own the 64 reads of a group reads every unit
+// with one fully coalesced 512-byte access (row-major 40-byte rows cost three L2 requests per 128-byte line and
+// streamed at 4.3 TB/s; this layout streams at 6.4 TB/s).  A buffer holds ceil(n/64)*64 rows.
+__host__ __device__ inline u64 packed_index(u64 r, u32 wpr, u32 c) {
+    return (r >> 6) * 64 * wpr + ((((u64)(c >> 1)) * 64 + (r & 63)) << 1) + (c & 1);
+}
+__host__ __device__ inline u64 packed_words(u64 n_reads, u32 wpr) { return ((n_reads + 63) & ~63ull) * wpr; }
+
 // ------------------------------------------------------------------ K0: pack
 // One thread packs 16 bases (one 32-bit word) and their 16 Phred bytes.  lens[r] bit 15 = read has a non-ACGT base.
 __global__ __launch_bounds__(256) void k_pack(const u8* __restrict__ bases, const u8* __restrict__ quals,
                                                const u64* __restrict__ off, u64 n_reads, u32* __restrict__ packed,
                                                u8* __restrict__ qrows, u16* __restrict__ lens, u32 wpr, u32 qstride) {
     u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 total = n_reads * wpr;
+    u64 total = packed_words(n_reads, wpr);      // one thread per output word, in output order (coalesced stores)
     for (; gid < total; gid += (u64)gridDim.x * blockDim.x) {
-        u64 r = gid / wpr; u32 w = (u32)(gid - r * wpr);
+        u64 grp = gid / (64ull * wpr); u32 in = (u32)(gid - grp * 64ull * wpr);
+        u64 r = grp * 64 + ((in >> 1) & 63); u32 w = ((in >> 7) << 1) | (in & 1);
+        if (r >= n_reads) { packed[gid] = 0; continue; }         // padding rows of the last group
         u64 o = off[r]; u32 n = (u32)(off[r + 1] - o);
         u32 word = 0; u32 anyn = 0;
         for (int k = 0; k < 16; k++) {
@@ -254,18 +266,18 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             for (int k = 0; k < NV; k++) { u32 v = tid + 256 * k; if (v < 64u * WPR) stg[k] = __builtin_nontemporal_load(g4 + v); }
             #pragma unroll
             for (int k = 0; k < NV; k++) { u32 v = tid + 256 * k; if (v < 64u * WPR) s4[v] = stg[k]; }
-        } else {
-            const u32* g = packed + r0 * WPR;
-            for (u32 i = tid; i < 256u * WPR; i += 256) s_rows[i] = i < nr * WPR ? g[i] : 0u;
+        } else {      // last tile: whole groups of 64 rows (the buffer is padded to a full group)
+            const u32* g = packed + r0 * WPR; const u32 lim = ((nr + 63u) & ~63u) * WPR;
+            for (u32 i = tid; i < 256u * WPR; i += 256) s_rows[i] = i < lim ? g[i] : 0u;
         }
         __syncthreads();
         bool hit = false;
         {
             int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-            const uint2* row = reinterpret_cast<const uint2*>(s_rows + (u32)tid * WPR);
+            const uint2* row = reinterpret_cast<const uint2*>(s_rows) + (u32)(tid >> 6) * 32 * WPR + (tid & 63);   // group-transposed rows
             u32 w[WPR];
             #pragma unroll
-            for (int t2 = 0; t2 < WPR / 2; t2++) { uint2 x = row[t2]; w[2 * t2] = x.x; w[2 * t2 + 1] = x.y; }
+            for (int t2 = 0; t2 < WPR / 2; t2++) { uint2 x = row[t2 * 64]; w[2 * t2] = x.x; w[2 * t2 + 1] = x.y; }
             // canonical seed keys, then every probe issued before examining any (see tie_all)
             u32 klo[NT], khi[NT];
             #pragma unroll
@@ -301,8 +313,8 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
             }
             while (pending && !hit) {   // overflow chain: the key may sit in a following bucket
                 int t = __ffs(pending) - 1; pending &= pending - 1;
-                const u32* rw = s_rows + (u32)tid * WPR;
-                u32 fl; u64 c = canon40((u64)rw[t] | ((u64)(rw[t + 1] & 0xFFu) << 32), fl);
+                const u32 w0 = s_rows[packed_index((u32)tid, WPR, (u32)t)], w1 = s_rows[packed_index((u32)tid, WPR, (u32)t + 1)];
+                u32 fl; u64 c = canon40((u64)w0 | ((u64)(w1 & 0xFFu) << 32), fl);
                 u32 lo = (u32)c, hi = (u32)(c >> 32); u32 fp = sieve_fp(lo, hi);
                 u32 bi = sieve_bucket_hash(lo, hi) >> sshift;
                 for (int step = 0; step < 64; step++) {
@@ -344,6 +356,43 @@ __host__ inline u32 sieve_half_of(u64 s) {            // host restatement for th
     for (int q = 0; q < 10; q++) rcB |= (u32)(3u - (u32)((s >> (2 * (19 - q))) & 3u)) << (2 * q);
     return sieve_half_pick(A, rcB);
 }
+struct SvProbe { v4u bv; u32 fp, bi, src; bool act; };
+// read queue entry e (if any), canonical key, request its sieve bucket
+__device__ inline void sv_issue(SvProbe& P, const u64* queue, u32 e, u32 cnt, const uint4* __restrict__ sieve, u32 sshift) {
+    P.act = e < cnt;
+    const u64 ent = P.act ? queue[e] : 0ull;
+    u32 fl; const u64 c = canon40(ent & 0xFFFFFFFFFFull, fl);
+    const u32 klo = (u32)c, khi = (u32)(c >> 32);
+    P.src = (u32)(ent >> 40) & 63u;
+    P.fp = sieve_fp(klo, khi);
+    P.bi = P.act ? sieve_bucket_hash(klo, khi) >> sshift : 0u;
+    P.bv = reinterpret_cast<const v4u*>(sieve)[P.bi];
+}
+// examine a requested bucket; a hit sets the bit of the seed's read (= lane of the tile) in the wave's hit mask
+__device__ inline void sv_check(const SvProbe& P, const uint4* __restrict__ sieve, u32 smask, u32* hitw) {
+    bool full; bool hit = bucket_has(make_uint4(P.bv.x, P.bv.y, P.bv.z, P.bv.w), P.fp, full) && P.act;
+    if (P.act && !hit && full) {   // overflow chain: the key may sit in a following bucket
+        u32 bi = P.bi;
+        for (int step = 0; step < 64; step++) {
+            bi = (bi + 1) & smask; bool f2; uint4 bb = sieve[bi];
+            if (bucket_has(bb, P.fp, f2)) { hit = true; break; }
+            if (!f2) break;
+        }
+    }
+    if (hit) atomicOr(&hitw[P.src >> 5], 1u << (P.src & 31));
+}
+// append the reads of one tile whose bit is set in the wave's hit mask to the candidate list; clears the mask
+__device__ inline void sv_emit(u32* hitw, u32* __restrict__ cand, Counters* __restrict__ ctr, u64 r, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    u64 mask = uniform_u64((u64)hitw[0] | ((u64)hitw[1] << 32));
+    if (mask) {
+        if (lane < 2) hitw[lane] = 0;
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->n_cand, (u64)__popcll(mask));
+        base = __shfl(base, 0);
+        if ((mask >> lane) & 1ull) cand[base + __popcll(mask & ((1ull << lane) - 1))] = (u32)r;
+    }
+}
 template <int WPR>
 __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
                                                      const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ bitmap,
@@ -367,31 +416,76 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
     const u64 n_tiles = (n_reads + 1023) / 1024;
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     v2u xn[WPR / 2]; u16 len_raw = 0; bool live_next = false;
+    const u64 n_groups = (n_reads + 63) >> 6;      // the wave's 64 lanes own one group of the transposed layout
     {
-        u64 r = (u64)blockIdx.x * 1024 + tid;
+        u64 r = (u64)blockIdx.x * 1024 + tid; u64 grp = (u64)blockIdx.x * 16 + wave;
         live_next = blockIdx.x < n_tiles && r < n_reads;
-        const v2u* row = reinterpret_cast<const v2u*>(packed + (live_next ? r : 0) * WPR);
+        const v2u* row = reinterpret_cast<const v2u*>(packed) + (grp < n_groups ? grp : 0) * (32 * WPR) + lane;
         #pragma unroll
-        for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2);
+        for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
         len_raw = lens[live_next ? r : 0];
     }
+    // Order inside an iteration (tile k): request the rows of tile k+1, request the sieve buckets of the seeds queued by
+    // tile k-1, run the first level of tile k (pure VALU + LDS, which hides both latencies), examine the buckets and emit
+    // the candidates of tile k-1, queue the passing seeds of tile k.  The only wait for global memory is in front of
+    // the bucket examination, so nothing that was requested recently is ever waited for.
+    u32 qcnt = 0;                 // seeds queued by the previous tile (entries 0..qcnt-1 of the wave's queue)
+    u64 last_tile = blockIdx.x;
     for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const u64 r = tile * 1024 + tid;
-        const u32 n = live_next ? (u32)(len_raw & 0x7FFFu) : 0u;
-        const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-        u32 w[WPR];
+        const bool live_cur = live_next;
+        // explicit register copies: xn's registers are free again right here, so the loads below can write into them
+        // directly (left to itself the compiler copies at the loop latch instead, and that copy waits for the loads)
+        u32 w[WPR]; u32 len_cur;
         #pragma unroll
-        for (int t2 = 0; t2 < WPR / 2; t2++) { w[2 * t2] = xn[t2].x; w[2 * t2 + 1] = xn[t2].y; }
-        {   // rows of the next tile: requested now, used one iteration later.  The memory clobber keeps the compiler
-            // from sinking the loads to the end of the iteration (it would, to their first use).
+        for (int t2 = 0; t2 < WPR / 2; t2++) {
+            asm volatile("v_mov_b32 %0, %1" : "=v"(w[2 * t2]) : "v"(xn[t2].x));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(w[2 * t2 + 1]) : "v"(xn[t2].y));
+        }
+        asm volatile("v_mov_b32 %0, %1" : "=v"(len_cur) : "v"((u32)len_raw));
+        const u32 n = live_cur ? (len_cur & 0x7FFFu) : 0u;
+        const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
+#if defined(SV_EXP) && SV_EXP == 1
+        {   // rows of the next tile.  The memory clobber keeps the compiler from sinking the loads towards their first use.
             u64 tn = tile + gridDim.x; u64 rn = tn * 1024 + tid;
             live_next = tn < n_tiles && rn < n_reads;
-            const v2u* row = reinterpret_cast<const v2u*>(packed + (live_next ? rn : 0) * WPR);
+            const u64 gn = tn * 16 + wave;
+            const v2u* row = reinterpret_cast<const v2u*>(packed) + (gn < n_groups ? gn : 0) * (32 * WPR) + lane;
             #pragma unroll
-            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2);
+            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
             len_raw = lens[live_next ? rn : 0];
             asm volatile("" ::: "memory");
         }
+#endif
+#if defined(SV_EXP) && SV_EXP == 1          /* profiling build: stream the rows only */
+        { u32 acc = 0;
+          #pragma unroll
+          for (int i = 0; i < WPR; i++) acc ^= w[i];
+          if (acc == 0x12345678u && n == 77777u) cand[0] = acc; }
+        continue;
+#endif
+        // ---- buckets of the previous tile's queue: two requests stay in flight across the first level; a queue longer
+        // than 128 entries (rare) is examined on the spot
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        SvProbe PA, PB;
+        sv_issue(PA, queue, (u32)lane, qcnt, sieve, sshift);
+        sv_issue(PB, queue, 64u + (u32)lane, qcnt, sieve, sshift);
+        for (u32 base = 128; base < qcnt; base += 64) {
+            SvProbe Ps; sv_issue(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
+            sv_check(Ps, sieve, smask, hitw);
+        }
+        asm volatile("" ::: "memory");      // the bucket requests are older than the row requests below: waiting for them leaves the rows in flight
+#if !(defined(SV_EXP) && SV_EXP == 1)
+        {   // rows of the next tile.  The memory clobber keeps the compiler from sinking the loads towards their first use.
+            u64 tn = tile + gridDim.x; u64 rn = tn * 1024 + tid;
+            live_next = tn < n_tiles && rn < n_reads;
+            const u64 gn = tn * 16 + wave;
+            const v2u* row = reinterpret_cast<const v2u*>(packed) + (gn < n_groups ? gn : 0) * (32 * WPR) + lane;
+            #pragma unroll
+            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
+            len_raw = lens[live_next ? rn : 0];
+            asm volatile("" ::: "memory");
+        }
+#endif
         // ---- first level: per word the bit-reversed swapped complement (rb[i] base p = complement of w[i] base 15-p),
         // per seed the two halves, the pick and one LDS bit
         u32 rb[WPR];
@@ -414,10 +508,18 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
             #pragma unroll
             for (int t = 0; t < NT; t++) pm[t] &= __ballot(t < nseeds);
         }
-        // ---- second level: queue the passing seeds of the wave, then probe the fingerprint sieve queue-wise
-        int t0 = 0;
-        do {
-            u32 cnt = 0; int t_next = NT;
+#if defined(SV_EXP) && SV_EXP == 2          /* profiling build: rows + first level, nothing queued */
+        #pragma unroll
+        for (int t = 0; t < NT; t++) pm[t] = (pm[t] == 0x123456789ull) ? 1ull : 0ull;
+#endif
+        // ---- examine the buckets requested above; candidates of the previous tile
+        sv_check(PA, sieve, smask, hitw); sv_check(PB, sieve, smask, hitw);
+        sv_emit(hitw, cand, ctr, last_tile * 1024 + tid, lane);
+        // ---- queue the passing seeds of this tile (probed during the next iteration).  If the queue could overflow
+        // (dense on-locus data) it is drained on the spot and filling continues.
+        u32 cnt = 0; int t0 = 0;
+        for (;;) {
+            int t_next = NT;
             #pragma unroll
             for (int t = 0; t < NT; t++) {
                 if (t < t0 || t >= t_next) continue;
@@ -430,41 +532,23 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
                 cnt += (u32)__popcll(m);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (t_next == NT) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (u32 base = 0; base < cnt; base += 64) {
-                const u32 e = base + (u32)lane; const bool act = e < cnt;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const u64 ent = act ? queue[e] : 0ull;
-                u32 fl; const u64 c = canon40(ent & 0xFFFFFFFFFFull, fl);
-                const u32 klo = (u32)c, khi = (u32)(c >> 32), src = (u32)(ent >> 40) & 63u;
-                v4u bv = v4u{0u, 0u, 0u, 0u};
-                if (act) bv = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo, khi) >> sshift];
-                const u32 fp = sieve_fp(klo, khi);
-                bool full; bool hit = bucket_has(make_uint4(bv.x, bv.y, bv.z, bv.w), fp, full);
-                hit = hit && act;
-                if (act && !hit && full) {   // overflow chain: the key may sit in a following bucket
-                    u32 bi = sieve_bucket_hash(klo, khi) >> sshift;
-                    for (int step = 0; step < 64; step++) {
-                        bi = (bi + 1) & smask; bool f2; uint4 bb = sieve[bi];
-                        if (bucket_has(bb, fp, f2)) { hit = true; break; }
-                        if (!f2) break;
-                    }
-                }
-                if (hit) atomicOr(&hitw[src >> 5], 1u << (src & 31));
+                SvProbe Ps; sv_issue(Ps, queue, base + (u32)lane, cnt, sieve, sshift);
+                sv_check(Ps, sieve, smask, hitw);
             }
-            t0 = t_next;
-        } while (t0 < NT);
-        // ---- candidates of the wave
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        u64 mask = (u64)hitw[0] | ((u64)hitw[1] << 32);
-        mask = uniform_u64(mask);
-        if (mask) {
-            if (lane < 2) hitw[lane] = 0;
-            u64 base = 0;
-            if (lane == 0) base = atomicAdd(&ctr->n_cand, (u64)__popcll(mask));
-            base = __shfl(base, 0);
-            if ((mask >> lane) & 1ull) cand[base + __popcll(mask & ((1ull << lane) - 1))] = (u32)r;
+            cnt = 0; t0 = t_next;
         }
+        qcnt = cnt; last_tile = tile;
     }
+    // the last tile's queue
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (u32 base = 0; base < qcnt; base += 64) {
+        SvProbe Ps; sv_issue(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
+        sv_check(Ps, sieve, smask, hitw);
+    }
+    sv_emit(hitw, cand, ctr, last_tile * 1024 + tid, lane);
 }
 
 // ------------------------------------------------------------------ wave helpers
@@ -544,9 +628,11 @@ __global__ __launch_bounds__(256) void k_fq_records(const u8* __restrict__ text,
 __global__ __launch_bounds__(256) void k_pack_text(const u8* __restrict__ text, const u64* __restrict__ seq_off, const u64* __restrict__ qual_off,
                                                     u16* __restrict__ lens, u64 n_reads, u32* __restrict__ packed, u8* __restrict__ qrows, u32 wpr, u32 qstride) {
     u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 total = n_reads * wpr;
+    u64 total = packed_words(n_reads, wpr);
     for (; gid < total; gid += (u64)gridDim.x * blockDim.x) {
-        u64 r = gid / wpr; u32 w = (u32)(gid - r * wpr);
+        u64 grp = gid / (64ull * wpr); u32 in = (u32)(gid - grp * 64ull * wpr);
+        u64 r = grp * 64 + ((in >> 1) & 63); u32 w = ((in >> 7) << 1) | (in & 1);
+        if (r >= n_reads) { packed[gid] = 0; continue; }
         u64 so = seq_off[r], qo = qual_off[r]; u32 n = lens[r] & 0x7FFFu;
         u32 word = 0; u32 anyn = 0;
         for (int k = 0; k < 16; k++) {
@@ -596,7 +682,7 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
         if (c < n_cand) {
             r = cand[c];
             lw = lens[r]; n = lw & 0x7FFFu; bool has_n = (lw & 0x8000u) != 0;
-            const u32* row = packed + (u64)r * wpr;
+            const u32* row = packed + packed_index(r, wpr, 0);      // word c of the row: row[(c >> 1) * 128 + (c & 1)]
             const u8* qrow = qrows + (u64)r * qstride;
             Bin* bins = s_bins[tid]; int nb = 0;
             int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
@@ -607,7 +693,7 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             for (int t0 = 0; t0 < nseeds; t0 += SEED_CHUNK) {
                 u32 wv[SEED_CHUNK + 1];
                 #pragma unroll
-                for (int u = 0; u <= SEED_CHUNK; u++) { wv[u] = 0; if ((u32)(t0 + u) < wpr) wv[u] = row[t0 + u]; }
+                for (int u = 0; u <= SEED_CHUNK; u++) { wv[u] = 0; const u32 c = (u32)(t0 + u); if (c < wpr) wv[u] = row[(c >> 1) * 128 + (c & 1)]; }
                 tie_all<SEED_CHUNK + 1>(wv);
                 u32 klo[SEED_CHUNK], khi[SEED_CHUNK], slot[SEED_CHUNK], sfl[SEED_CHUNK], k0[SEED_CHUNK], k1[SEED_CHUNK]; u32 okm = 0;
                 #pragma unroll
@@ -724,7 +810,7 @@ __global__ __launch_bounds__(256) void k_retain(const EngineDev* __restrict__ Ep
     for (u64 sl = begin + (u64)blockIdx.x * 2 + (threadIdx.x >> 7); sl < end; sl += (u64)gridDim.x * 2) {
         const u64 rr = E.ret_ridx[sl] - read_base;
         const u32 nn = E.ret_len[sl] & 0x7FFFu;
-        if (sub < RW) E.ret_bases[sl * RW + sub] = sub < wpr ? packed[rr * wpr + sub] : 0u;
+        if (sub < RW) E.ret_bases[sl * RW + sub] = sub < wpr ? packed[packed_index(rr, wpr, sub)] : 0u;
         else if (sub < RW + RQ / 4) {
             const u32 w = sub - RW;
             const u32 nq = nn < qstride ? nn : qstride;        // bytes to keep; rows hold zeros beyond the read length
@@ -1963,7 +2049,7 @@ extern "C" int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, co
     if (n_reads == 0) return MLST_OK;
     Prof pf(h, 6);
     hipLaunchKernelGGL(k_pack_lens, dim3(grid_for(n_reads, 256)), dim3(256), 0, h->stream, (const u64*)d_off, (u64)n_reads, d_lens);
-    hipLaunchKernelGGL(k_pack, dim3(grid_for(n_reads * wpr, 256, 8192)), dim3(256), 0, h->stream, d_bases, d_quals, (const u64*)d_off, (u64)n_reads,
+    hipLaunchKernelGGL(k_pack, dim3(grid_for(packed_words(n_reads, wpr), 256, 8192)), dim3(256), 0, h->stream, d_bases, d_quals, (const u64*)d_off, (u64)n_reads,
                        d_packed, d_qrows, d_lens, wpr, qstride);
     HIPCHK(h, hipGetLastError());
     return MLST_OK;
@@ -2015,11 +2101,11 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
 }
 
 static int ensure_pack_buffers(mlst_handle* h, u64 n_reads, u32 wpr, u32 qstride) {
-    if (h->cap_packed_words < n_reads * wpr + 4 || h->cap_qrow_bytes < n_reads * qstride || h->cap_lens < n_reads + 2) {
+    if (h->cap_packed_words < packed_words(n_reads, wpr) + 4 || h->cap_qrow_bytes < n_reads * qstride || h->cap_lens < n_reads + 2) {
         hipStreamSynchronize(h->stream);
         hipFree(h->d_packed); hipFree(h->d_qrows); hipFree(h->d_lens); h->d_packed = nullptr; h->d_qrows = nullptr; h->d_lens = nullptr;
-        HIPCHK(h, dmalloc(&h->d_packed, n_reads * wpr + 4)); HIPCHK(h, dmalloc(&h->d_qrows, n_reads * qstride)); HIPCHK(h, dmalloc(&h->d_lens, n_reads + 2));
-        h->cap_packed_words = n_reads * wpr + 4; h->cap_qrow_bytes = n_reads * qstride; h->cap_lens = n_reads + 2;
+        HIPCHK(h, dmalloc(&h->d_packed, packed_words(n_reads, wpr) + 4)); HIPCHK(h, dmalloc(&h->d_qrows, n_reads * qstride)); HIPCHK(h, dmalloc(&h->d_lens, n_reads + 2));
+        h->cap_packed_words = packed_words(n_reads, wpr) + 4; h->cap_qrow_bytes = n_reads * qstride; h->cap_lens = n_reads + 2;
     }
     return MLST_OK;
 }
@@ -2102,13 +2188,13 @@ extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n
     u32 qstride = (max_len + 7) & ~7u; if (qstride < 8) qstride = 8;
     {   // k_fq_records wrote the lengths into d_lens; growing the pack buffers must keep them
         std::vector<u16> keep;
-        if (h->cap_packed_words < n_reads * wpr + 4 || h->cap_qrow_bytes < n_reads * qstride) {
+        if (h->cap_packed_words < packed_words(n_reads, wpr) + 4 || h->cap_qrow_bytes < n_reads * qstride) {
             keep.resize(n_reads); HIPCHK(h, hipMemcpy(keep.data(), h->d_lens, n_reads * 2, hipMemcpyDeviceToHost));
             rc = ensure_pack_buffers(h, n_reads, wpr, qstride); if (rc) return rc;
             HIPCHK(h, hipMemcpy(h->d_lens, keep.data(), n_reads * 2, hipMemcpyHostToDevice));
         }
     }
-    hipLaunchKernelGGL(k_pack_text, dim3(grid_for(n_reads * wpr, 256, 8192)), dim3(256), 0, h->stream, h->d_fq_text, h->d_fq_soff, h->d_fq_qoff,
+    hipLaunchKernelGGL(k_pack_text, dim3(grid_for(packed_words(n_reads, wpr), 256, 8192)), dim3(256), 0, h->stream, h->d_fq_text, h->d_fq_soff, h->d_fq_qoff,
                        h->d_lens, n_reads, h->d_packed, h->d_qrows, wpr, qstride);
     HIPCHK(h, hipGetLastError());
     if (n_reads_out) *n_reads_out = n_reads;
