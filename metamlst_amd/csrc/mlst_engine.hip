@@ -337,24 +337,34 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
     }
 }
 
-// Sieve with an LDS-resident first level.  One 1024-thread workgroup per CU keeps a 2^20-bit bitmap in LDS (128 KiB)
-// that is indexed DIRECTLY by one 10-base half of the seed, in an orientation that does not depend on the strand:
-//   A   = bases 0..9 of the seed,   rcB = reverse complement of bases 10..19   (the pair {A, rcB} is the same set for
-//   a seed and for its reverse complement);  L = sieve_half_pick(A, rcB) picks one of the two by a circular
-//   comparison, which keeps L uniformly distributed.
-// Indexing by half of the bases makes the alleles' SNP variants collapse: a SNP changes 20 seeds but only ~10 distinct
-// L values, so the bitmap of an MLST database is about half as full as a hashed bitmap of whole seeds (measured on
-// the 7 x 1430-allele database: 19 % against 35 %), and it needs no multiply.  The builder sets the bit of BOTH
-// orientations of every database seed, so the pick never has to be consistent across strands.
-// Seeds whose bit is set (a fifth of them) are compacted per wave into an LDS queue and only the queue is checked
-// against the fingerprint sieve -- two rounds of 64 probes per 64 reads instead of nine.  Rows are read straight from
-// global memory (lane = read, 8-byte non-temporal loads, the next tile requested a whole tile ahead).
+// Sieve with an LDS-resident first level.  One 1024-thread workgroup per CU keeps two 2^19-bit bitmaps in LDS (128 KiB),
+// each indexed DIRECTLY by one 10-base half of the seed (top bit dropped), read in an orientation that does not depend
+// on the strand:
+//   A = bases 0..9, B = bases 10..19, rcA / rcB their reverse complements.  The seed reads (A, B), its reverse
+//   complement reads (rcB, rcA); sieve_half_flip(A, rcB) chooses one of the two readings by a circular comparison
+//   (which keeps the chosen halves uniformly distributed); L = its first half, R = its second half.
+// A seed passes when bit L of the first bitmap and bit R of the second are set.  Indexing by half of the bases makes
+// the alleles' SNP variants collapse -- a SNP changes 20 seeds but only ~10 distinct halves -- so each bitmap of an
+// MLST database is far emptier than a hashed bitmap of whole seeds would be, no multiply is needed, and the two tests
+// multiply (7 x 1430-allele database: 326 k seeds, each half bitmap ~23 % full, ~5 % of random seeds pass, against
+// 27 % for one hashed 2^20-bit bitmap).  The builder sets the bits of BOTH readings of every database seed, so the
+// choice never has to be consistent across strands.
+// Seeds that pass are compacted per wave into an LDS queue and only the queue is checked against the fingerprint
+// sieve -- about half a round of 64 probes per 64 reads instead of nine.  Rows are read straight from global memory
+// (lane = read, coalesced 8-byte non-temporal loads, the next tile requested a whole tile ahead).
 #define SV_CAP 224            // queue entries per wave (8 bytes each); drained early when it could overflow
-__host__ __device__ inline u32 sieve_half_pick(u32 A, u32 rcB) { return ((A - rcB) & 0x80000u) ? rcB : A; }
-__host__ inline u32 sieve_half_of(u64 s) {            // host restatement for the builder: s = 40-bit seed, base t at bits 2t
-    u32 A = (u32)(s & 0xFFFFFu), rcB = 0;
-    for (int q = 0; q < 10; q++) rcB |= (u32)(3u - (u32)((s >> (2 * (19 - q))) & 3u)) << (2 * q);
-    return sieve_half_pick(A, rcB);
+#define SV_HALF_BITS (1u << (BITMAP_BITS - 1))      // bits per half bitmap (2^19 each: first half | second half = 128 KiB)
+__host__ __device__ inline bool sieve_half_flip(u32 A, u32 rcB) { return ((A - rcB) & 0x80000u) != 0; }
+// host restatement for the builder: s = 40-bit seed, base t at bits 2t -> the two bitmap indices of s read in the
+// orientation the pick chooses (L = chosen first half, R = the half that follows it in that orientation)
+__host__ inline void sieve_halves_of(u64 s, u32& L, u32& R) {
+    u32 A = (u32)(s & 0xFFFFFu), B = (u32)((s >> 20) & 0xFFFFFu), rcA = 0, rcB = 0;
+    for (int q = 0; q < 10; q++) {
+        rcB |= (u32)(3u - (u32)((s >> (2 * (19 - q))) & 3u)) << (2 * q);
+        rcA |= (u32)(3u - (u32)((s >> (2 * (9 - q))) & 3u)) << (2 * q);
+    }
+    const bool flip = sieve_half_flip(A, rcB);
+    L = (flip ? rcB : A) & (SV_HALF_BITS - 1u); R = (flip ? rcA : B) & (SV_HALF_BITS - 1u);
 }
 struct SvProbe { v4u bv; u32 fp, bi, src; bool act; };
 // read queue entry e (if any), canonical key, request its sieve bucket
@@ -444,37 +454,19 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
         asm volatile("v_mov_b32 %0, %1" : "=v"(len_cur) : "v"((u32)len_raw));
         const u32 n = live_cur ? (len_cur & 0x7FFFu) : 0u;
         const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-#if defined(SV_EXP) && SV_EXP == 1
-        {   // rows of the next tile.  The memory clobber keeps the compiler from sinking the loads towards their first use.
-            u64 tn = tile + gridDim.x; u64 rn = tn * 1024 + tid;
-            live_next = tn < n_tiles && rn < n_reads;
-            const u64 gn = tn * 16 + wave;
-            const v2u* row = reinterpret_cast<const v2u*>(packed) + (gn < n_groups ? gn : 0) * (32 * WPR) + lane;
-            #pragma unroll
-            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
-            len_raw = lens[live_next ? rn : 0];
-            asm volatile("" ::: "memory");
-        }
-#endif
-#if defined(SV_EXP) && SV_EXP == 1          /* profiling build: stream the rows only */
-        { u32 acc = 0;
-          #pragma unroll
-          for (int i = 0; i < WPR; i++) acc ^= w[i];
-          if (acc == 0x12345678u && n == 77777u) cand[0] = acc; }
-        continue;
-#endif
         // ---- buckets of the previous tile's queue: two requests stay in flight across the first level; a queue longer
         // than 128 entries (rare) is examined on the spot
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         SvProbe PA, PB;
         sv_issue(PA, queue, (u32)lane, qcnt, sieve, sshift);
-        sv_issue(PB, queue, 64u + (u32)lane, qcnt, sieve, sshift);
+        const bool two = qcnt > 64;              // wave-uniform: a second request only for a queue of more than 64 seeds
+        if (two) sv_issue(PB, queue, 64u + (u32)lane, qcnt, sieve, sshift);
+        else { PB.act = false; PB.bv = v4u{0u, 0u, 0u, 0u}; PB.fp = 1u; PB.bi = 0u; PB.src = 0u; }
         for (u32 base = 128; base < qcnt; base += 64) {
             SvProbe Ps; sv_issue(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
             sv_check(Ps, sieve, smask, hitw);
         }
         asm volatile("" ::: "memory");      // the bucket requests are older than the row requests below: waiting for them leaves the rows in flight
-#if !(defined(SV_EXP) && SV_EXP == 1)
         {   // rows of the next tile.  The memory clobber keeps the compiler from sinking the loads towards their first use.
             u64 tn = tile + gridDim.x; u64 rn = tn * 1024 + tid;
             live_next = tn < n_tiles && rn < n_reads;
@@ -485,7 +477,6 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
             len_raw = lens[live_next ? rn : 0];
             asm volatile("" ::: "memory");
         }
-#endif
         // ---- first level: per word the bit-reversed swapped complement (rb[i] base p = complement of w[i] base 15-p),
         // per seed the two halves, the pick and one LDS bit
         u32 rb[WPR];
@@ -498,22 +489,19 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
         u64 pm[NT];
         #pragma unroll
         for (int t = 0; t < NT; t++) {
-            u32 A = w[t] & 0xFFFFFu;
-            u32 rcB = __builtin_amdgcn_alignbit(rb[t], rb[t + 1], 24) & 0xFFFFFu;
-            u32 L = sieve_half_pick(A, rcB);
-            u32 word = s_bm[L >> 5];
-            pm[t] = __ballot(((word >> (L & 31)) & 1u) != 0);
+            const u32 A = w[t] & 0xFFFFFu, B = __builtin_amdgcn_alignbit(w[t + 1], w[t], 20) & 0xFFFFFu;
+            const u32 rcB = __builtin_amdgcn_alignbit(rb[t], rb[t + 1], 24) & 0xFFFFFu, rcA = rb[t] >> 12;
+            const bool flip = sieve_half_flip(A, rcB);
+            const u32 L = (flip ? rcB : A) & (SV_HALF_BITS - 1u), R = (flip ? rcA : B) & (SV_HALF_BITS - 1u);
+            const u32 wl = s_bm[L >> 5], wr = s_bm[SV_HALF_BITS / 32 + (R >> 5)];
+            pm[t] = __ballot((((wl >> (L & 31)) & (wr >> (R & 31))) & 1u) != 0);
         }
         if (!all_full) {
             #pragma unroll
             for (int t = 0; t < NT; t++) pm[t] &= __ballot(t < nseeds);
         }
-#if defined(SV_EXP) && SV_EXP == 2          /* profiling build: rows + first level, nothing queued */
-        #pragma unroll
-        for (int t = 0; t < NT; t++) pm[t] = (pm[t] == 0x123456789ull) ? 1ull : 0ull;
-#endif
         // ---- examine the buckets requested above; candidates of the previous tile
-        sv_check(PA, sieve, smask, hitw); sv_check(PB, sieve, smask, hitw);
+        sv_check(PA, sieve, smask, hitw); if (two) sv_check(PB, sieve, smask, hitw);
         sv_emit(hitw, cand, ctr, last_tile * 1024 + tid, lane);
         // ---- queue the passing seeds of this tile (probed during the next iteration).  If the queue could overflow
         // (dense on-locus data) it is drained on the spot and filling continues.
@@ -1934,11 +1922,14 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
             bitmap.assign(nbits / 32, 0);
             u64 set = 0;
             for (u64 i = 0; i < nk; i++) {      // both orientations of every seed (see k_sieve_lds)
-                u32 b0 = sieve_half_of(ukeys[i]), b1 = sieve_half_of(revcomp40(ukeys[i]));
-                if (!((bitmap[b0 >> 5] >> (b0 & 31)) & 1u)) { bitmap[b0 >> 5] |= 1u << (b0 & 31); set++; }
-                if (!((bitmap[b1 >> 5] >> (b1 & 31)) & 1u)) { bitmap[b1 >> 5] |= 1u << (b1 & 31); set++; }
+                for (int o = 0; o < 2; o++) {
+                    u32 L, R; sieve_halves_of(o ? revcomp40(ukeys[i]) : ukeys[i], L, R);
+                    R += SV_HALF_BITS;
+                    if (!((bitmap[L >> 5] >> (L & 31)) & 1u)) { bitmap[L >> 5] |= 1u << (L & 31); set++; }
+                    if (!((bitmap[R >> 5] >> (R & 31)) & 1u)) { bitmap[R >> 5] |= 1u << (R & 31); set++; }
+                }
             }
-            h->bitmap_fill = (double)set / (double)nbits;
+            h->bitmap_fill = (double)set / (double)nbits;       // mean fill of the two halves; a seed passes with ~fill^2
             if (set * 2 > nbits) { bitmap.clear(); h->bitmap_fill = 0.0; }   // more than half full: not selective, use the plain kernel
         }
     }
