@@ -10,6 +10,14 @@ extension against every allele -> hit accumulation -> allele choice -> pileup ->
 its own 10 M-read shard of the same isolate (weak scaling), the two all-reduces of
 metamlst_amd/dist.py run over RCCL, and rank 0 runs the host tail.
 
+By default three engines (three HIP streams, three sets of sample state) work on the same resident batch
+in turn (--pipeline 3): while the host types step k (.nfo line, ST call) the GPU already runs the passes of
+steps k+1 and k+2, and the small latency-bound kernels of one step overlap the streaming kernels of another.
+At N=1 the allele choice, pileup and consensus are queued on the device right behind pass 1
+(mlst_typing_enqueue), so a step has a single host round trip.  Every step is still one complete pass and
+the timed region holds exactly K of them; `serial_ms_per_step` reports the strictly serial step
+(--pipeline 1 times the whole run that way).
+
 Reads are synthesised on the GPU before the timed region and are resident in HBM in the packed
 format of SURVEY.md 8(d) (2-bit bases + Phred rows); the timed region contains no H2D copy of
 reads.  The JSON line also carries the roofline of the dominant kernel (HIP events on the
@@ -37,14 +45,17 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--alleles", type=int, default=1430, help="alleles per locus")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genome", type=int, default=4_600_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--st-row", type=int, default=11)
+    ap.add_argument("--pipeline", type=int, default=3,
+                    help="engines per GPU: with more than one, the GPU already works on the next steps while the host types "
+                         "step k (multiple buffering; every step is still a complete pass); 1 = strictly serial steps")
     ap.add_argument("--calibrate", action="store_true",
                     help="before the timed region copy the Phred rows 3x with torch (a known-size wide coalesced stream) "
                          "so a rocprofv3 --pmc FETCH_SIZE pass of this command can be calibrated")
@@ -154,12 +165,15 @@ def main():
     database = mdb.metaMLST_db(db_path)
     st_tuple = sdb.profiles["ecoli"][args.st_row]
     genome, _ = synth.make_genome(sdb, "ecoli", st_tuple, size=args.genome)
-    eng = Engine(local_rank)
-    eng.load_reference(idx)
+    depth = max(1, min(4, args.pipeline))
+    engines = [Engine(local_rank) for _ in range(depth)]       # one HIP stream and one set of sample state each
+    for e in engines:
+        e.load_reference(idx)
+    eng = engines[0]
     t_setup = time.time() - t0
     packed, qrows, lens, wpr, qstride = synth_reads_gpu(eng, torch, device, genome, args.reads, args.read_len,
                                                         seed=synth.SEED + 1000 * rank)
-    port = DeviceStatsPort(eng, device)
+    ports = [DeviceStatsPort(e, device) for e in engines]
     matcher = EngineMatcher(eng, idx)
     true_st = args.st_row + 1
     # merge-run prologue (metamlst-merge.py:119-142) happens once per run of many samples: untimed setup
@@ -173,30 +187,43 @@ def main():
         del _c
     host_ms = {"submit": 0.0, "stats": 0.0, "typing+pileup": 0.0, "st_call": 0.0}
 
-    def step():
+    def submit(k):
+        """Pass 1 of step k: asynchronous (sieve -> seeds -> extension -> accumulation on engine k % depth)."""
         t_a = time.perf_counter()
-        eng.reset_sample()
-        eng.set_read_index_base(rank * args.reads)
-        eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), args.reads, wpr, qstride)
+        e = engines[k % depth]
+        e.reset_sample()
+        e.set_read_index_base(rank * args.reads)
+        e.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), args.reads, wpr, qstride)
+        if world == 1:      # allele choice + pileup + consensus queued behind pass 1: no host round trip between the passes
+            e.typing_enqueue(penalty=100)
+        host_ms["submit"] += (time.perf_counter() - t_a) * 1e3
+
+    def finish(k):
+        """The rest of step k: (all-reduce,) statistics, allele choice, pileup, consensus, .nfo line, ST call."""
+        e, port = engines[k % depth], ports[k % depth]
+        t_b = time.perf_counter()
+        typed = None
         if world > 1:
             allreduce_stats(port, device)
-        t_b = time.perf_counter()
-        st = eng.stats()
+            st = e.stats()
+        else:
+            st, chosen_dev, letters_dev = e.typing_fetch()
+            typed = (chosen_dev, letters_dev)
         t_c = time.perf_counter()
 
         def pileup_fn(chosen):
             if world > 1:
                 n_cols = sum(int(idx.off[a + 1] - idx.off[a]) for a in chosen)
                 return split_counts(idx, chosen, allreduce_pileup(port, chosen, n_cols, device))
-            return eng.pileup(chosen)
+            return e.pileup(chosen)
 
         def consensus_fn(chosen):
             if world > 1:
                 n_cols = sum(int(idx.off[a + 1] - idx.off[a]) for a in chosen)
                 return allreduce_consensus(port, idx, chosen, n_cols, device)
-            return eng.consensus(chosen)
+            return e.consensus(chosen)
 
-        res = type_sample(idx, st, pileup_fn, database, "sample", fast=True, cache=cache, consensus_fn=consensus_fn)
+        res = type_sample(idx, st, pileup_fn, database, "sample", fast=True, cache=cache, consensus_fn=consensus_fn, typed=typed)
         t_d = time.perf_counter()
         out = {}
         if rank == 0:
@@ -205,29 +232,48 @@ def main():
                     organism, (bacteriumLine, sampleRecord) = parse_nfo_line(r.nfo_line)
                     out[organism] = sessions[organism].add_sample(bacteriumLine, sampleRecord)
         t_e = time.perf_counter()
-        host_ms["submit"] += (t_b - t_a) * 1e3
         host_ms["stats"] += (t_c - t_b) * 1e3        # includes waiting for the pass-1 kernels
         host_ms["typing+pileup"] += (t_d - t_c) * 1e3
         host_ms["st_call"] += (t_e - t_d) * 1e3
         return out, st
 
+    def run(n_steps):
+        """n_steps complete steps; with depth > 1 the GPU works on step k+1 while the host finishes step k."""
+        last = None
+        for k in range(min(depth - 1, n_steps)):
+            submit(k)
+        for k in range(n_steps):
+            if k + depth - 1 < n_steps:
+                submit(k + depth - 1)
+            last = finish(k)
+        return last
+
     def fence():
-        eng.synchronize()
+        for e in engines:
+            e.synchronize()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    eng.set_profiling(True)
-    eng.reset_kernel_time()
+    run(args.warmup)
+    # strictly serial steps (one engine), a few of them: the latency of one step, reported beside the throughput
+    fence()
+    t0 = time.perf_counter()
+    n_serial = min(5, args.steps)
+    for k in range(n_serial):
+        submit(0)
+        finish(0)
+    fence()
+    serial_ms = (time.perf_counter() - t0) / max(1, n_serial) * 1e3
+    for e in engines:
+        e.set_profiling(True)
+        e.reset_kernel_time()
     for k in host_ms:
         host_ms[k] = 0.0
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st_call, stats = step()
+    st_call, stats = run(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -235,8 +281,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    kernels = {k: eng.kernel_time(k) for k in ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup")}
-    eng.set_profiling(False)
+    kernels = {}
+    for k in ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup"):
+        parts = [e.kernel_time(k) for e in engines]
+        kernels[k] = (sum(p_[0] for p_ in parts), sum(p_[1] for p_ in parts))
+    for e in engines:
+        e.set_profiling(False)
 
     if rank != 0:
         if world > 1:
@@ -312,11 +362,12 @@ def main():
            "dtype": "int32", "data": "synthetic",
            "config": {"workload": "cfg2: %d x %d bp SE reads per GPU, one E. coli-like isolate (%.1f Mb), synthetic DB 7 loci x %d alleles "
                                   "(metamlstDB_2022 is not available offline)" % (args.reads, args.read_len, args.genome / 1e6, args.alleles),
-                      "reads_per_gpu": args.reads, "n_alleles": int(idx.n_alleles), "parallelism": "reads sharded x%d" % world,
+                      "reads_per_gpu": args.reads, "n_alleles": int(idx.n_alleles), "parallelism": "reads sharded x%d" % world, "pipeline_depth": depth,
                       "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (wpr * 4, qstride)},
            "roofline": roofline, "cpu_baseline": cpu, "concordance": conc,
            "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
            "host_ms_per_step": {k: round(v / args.steps, 4) for k, v in host_ms.items()},
+           "serial_ms_per_step": round(serial_ms, 4),
            "counters": {"records": int(stats.counters[0]), "ignored": int(stats.counters[1]), "candidates": int(stats.counters[3]),
                         "retained": int(stats.counters[4]), "items": int(stats.counters[5]), "banded_sw_pairs": int(stats.counters[6])},
            "index_bytes": dict(zip(("allele_arena", "sieve", "seed_table"), eng.index_bytes()[:3])),

@@ -167,6 +167,26 @@ int mlst_consensus(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n
 int mlst_consensus_from_counts_device(mlst_handle* h, const uint32_t* d_counts, uint64_t n_cols, uint32_t mincov,
                                       char none_char, uint8_t* out_seq);
 
+/* ---- whole typing tail on the device, without a host round trip between the passes ----------------------
+ * mlst_typing_enqueue queues, behind the pass-1 work already submitted on the engine's stream:
+ *   the allele choice of metamlst.py:133-151 + :244 (per locus the allele with the highest
+ *   round((sum AS - (maxHits - hits) * penalty) / hits, 1), ties to the lowest allele number, computed exactly
+ *   as Python's round() does -- see mlst_round_tenths), pass 2 against the chosen alleles, the majority
+ *   consensus of mlst_consensus, and the copies to the host.  It returns at once.
+ * mlst_typing_fetch waits for it and returns the statistics of mlst_get_allele_stats, chosen[n_loci] (allele
+ *   index, -1 = locus without an accepted record) and the consensus letters; the letters of locus l start at
+ *   colbase[l] of mlst_typing_layout (one slot of the locus' longest allele per locus; only the first
+ *   len(chosen allele) bytes of a slot are meaningful).
+ * The choice is part of the host logic of the reference (float round + tie-break); the Python host keeps its
+ * own statement of it (typing.pick_alleles_fast) and the tests compare the two. */
+int mlst_typing_layout(mlst_handle* h, uint64_t* colbase /* n_loci + 1 */, uint64_t* total_cols);
+int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char);
+int mlst_typing_fetch(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_read_len_sum,
+                      uint64_t* locus_first_read, uint64_t* counters, int32_t* chosen, uint8_t* letters);
+/* round(float(p) / float(q), 1) of Python as an exact integer number of tenths (host function, the same code
+ * the device uses); 0 when q == 0. */
+long long mlst_round_tenths(long long p, uint32_t q);
+
 /* Allele match: Hamming distance of `query` against every allele of `locus`, semantics of
  * stringDiff (metaMLST_functions.py:230-234: zip truncates, length difference not counted),
  * as used by metamlst-merge.py:177-181.  Outputs the first allele (load order) within z,

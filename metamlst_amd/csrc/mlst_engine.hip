@@ -1592,6 +1592,58 @@ __global__ __launch_bounds__(256) void k_consensus(const u32* __restrict__ count
     }
 }
 
+// ------------------------------------------------------------------ allele choice on the device (metamlst.py:133-151, 244)
+// Python's round(float(p) / float(q), 1) as an exact integer number of tenths.  round() of a float is the correctly
+// rounded decimal of the binary double (ties of the DOUBLE go to the even digit).  The double d = fl(p/q) lies within
+// one ulp of p/q, and p/q is at least 1/(20q) away from every rounding boundary (2m+1)/20 it does not hit exactly, so
+// away from rational ties the exact integer arithmetic decides; on a rational tie the sign of 20*d - (2m+1), which one
+// fma gives exactly, says on which side of the boundary the double fell.
+__host__ __device__ inline long long round_tenths(long long p, u32 q) {
+    const long long p10 = 10 * p, qq = (long long)q;
+    long long m = p10 / qq; if ((p10 % qq) < 0) m -= 1;                 // floor division
+    const long long rem = p10 - m * qq;                                  // 0 <= rem < q
+    if (2 * rem < qq) return m;
+    if (2 * rem > qq) return m + 1;
+    const double d = (double)p / (double)q;
+    const double sgn = fma(d, 20.0, -(double)(2 * m + 1));
+    if (sgn > 0.0) return m + 1;
+    if (sgn < 0.0) return m;
+    return (m & 1) ? m + 1 : m;                                          // the double IS the tie: even digit
+}
+// One block per locus: chosen[l] = the allele with the highest rounded penalised average, ties to the lowest allele
+// number (Q5), or -1 when the locus has no accepted record.
+__global__ __launch_bounds__(256) void k_choose(const EngineDev* __restrict__ Ep, const int* __restrict__ allele_no, int penalty,
+                                                int* __restrict__ chosen) {
+    const EngineDev& E = *Ep;
+    __shared__ u32 s_max[4]; __shared__ long long s_r[4]; __shared__ int s_no[4]; __shared__ int s_a[4];
+    const u32 l = blockIdx.x; const LocusDev L = E.loci[l];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 mx = 0;
+    for (u32 k = threadIdx.x; k < L.n_alleles; k += 256) { u32 v = E.n_hits[L.a_begin + k]; mx = v > mx ? v : mx; }
+    for (int o = 32; o > 0; o >>= 1) { u32 y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+    if (lane == 0) s_max[wv] = mx;
+    __syncthreads();
+    mx = s_max[0]; for (int k = 1; k < 4; k++) mx = s_max[k] > mx ? s_max[k] : mx;
+    long long br = 0; int bno = 0x7FFFFFFF, ba = -1;
+    for (u32 k = threadIdx.x; k < L.n_alleles; k += 256) {
+        const u32 a = L.a_begin + k; const u32 nh = E.n_hits[a];
+        if (!nh) continue;
+        const long long local = E.sum_score[a] - (long long)(mx - nh) * (long long)penalty;     // metamlst.py:146-147
+        const long long r = round_tenths(local, nh); const int no = allele_no[a];
+        if (ba < 0 || r > br || (r == br && no < bno)) { br = r; bno = no; ba = (int)a; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        long long r2 = __shfl_xor(br, o); int no2 = __shfl_xor(bno, o); int a2 = __shfl_xor(ba, o);
+        if (a2 >= 0 && (ba < 0 || r2 > br || (r2 == br && no2 < bno))) { br = r2; bno = no2; ba = a2; }
+    }
+    if (lane == 0) { s_r[wv] = br; s_no[wv] = bno; s_a[wv] = ba; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) if (s_a[k] >= 0 && (ba < 0 || s_r[k] > br || (s_r[k] == br && s_no[k] < bno))) { br = s_r[k]; bno = s_no[k]; ba = s_a[k]; }
+        chosen[l] = ba;
+    }
+}
+
 // ------------------------------------------------------------------ K7: stringDiff over the alleles of one locus
 __global__ __launch_bounds__(256) void k_hamming(const u8* __restrict__ ascii, const u64* __restrict__ aoff, u32 a_begin,
                                                  u32 n_alleles, const u8* __restrict__ query, u32 qlen, u32* __restrict__ dist) {
@@ -1667,6 +1719,9 @@ struct mlst_handle {
     // pileup scratch
     int* d_locus_chosen = nullptr; u64* d_locus_colbase = nullptr; u64* d_pl_list = nullptr; u8* d_tb = nullptr;
     u32* d_counts = nullptr; u64 cap_counts = 0;
+    // device-side typing (mlst_typing_enqueue / mlst_typing_fetch): fixed column layout, one slot of loc_maxlen columns per locus
+    int* d_allele_no = nullptr; int* d_auto_chosen = nullptr; u64* d_fixed_colbase = nullptr; std::vector<u64> fixed_colbase; u64 fixed_cols = 0;
+    u32* d_auto_counts = nullptr; u8* d_auto_letters = nullptr; u8* h_auto = nullptr; bool auto_pending = false;
     u32* d_dist = nullptr; u8* d_query = nullptr; u64 cap_dist = 0, cap_query = 0;
     // one contiguous device block [sum_score | locus_len | Counters | n_hits | pad][locus_first] with a pinned mirror
     u8* d_stats = nullptr; u8* h_stats = nullptr; u64 stats_bytes = 0, stats_zero_bytes = 0;
@@ -1751,6 +1806,9 @@ static void free_ref(mlst_handle* h) {
     hipFree(h->d_arena); hipFree(h->d_planes); hipFree(h->d_nmask); hipFree(h->d_allele_len); hipFree(h->d_allele_locus); hipFree(h->d_loci);
     hipFree(h->d_sieve); hipFree(h->d_bitmap); h->d_bitmap = nullptr; hipFree(h->d_gbitmap); h->d_gbitmap = nullptr; hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
     hipFree(h->d_ascii); hipFree(h->d_aoff);
+    hipFree(h->d_allele_no); hipFree(h->d_auto_chosen); hipFree(h->d_fixed_colbase); hipFree(h->d_auto_counts); hipFree(h->d_auto_letters);
+    if (h->h_auto) { hipHostFree(h->h_auto); h->h_auto = nullptr; }
+    h->d_allele_no = h->d_auto_chosen = nullptr; h->d_fixed_colbase = nullptr; h->d_auto_counts = nullptr; h->d_auto_letters = nullptr; h->auto_pending = false;
     h->d_arena = h->d_planes = h->d_nmask = nullptr; h->d_allele_len = nullptr; h->d_allele_locus = nullptr; h->d_loci = nullptr; h->d_sieve = nullptr;
     h->d_keys = nullptr; h->d_vals = h->d_posts = nullptr; h->d_floor = nullptr; h->d_pen = nullptr; h->d_ascii = nullptr; h->d_aoff = nullptr;
     h->have_ref = false;
@@ -1971,6 +2029,16 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_aoff, (u64)n_alleles + 1)); HIPCHK(h, hipMemcpy(h->d_aoff, off, ((u64)n_alleles + 1) * 8, hipMemcpyHostToDevice));
     h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
     h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
+    {   // device-side typing: allele numbers, one slot of max_len columns per locus
+        HIPCHK(h, dmalloc(&h->d_allele_no, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_no, allele_no, (u64)n_alleles * 4, hipMemcpyHostToDevice));
+        h->fixed_colbase.assign(n_loci + 1, 0);
+        for (u32 l = 0; l < n_loci; l++) h->fixed_colbase[l + 1] = h->fixed_colbase[l] + loci[l].max_len;
+        h->fixed_cols = h->fixed_colbase[n_loci];
+        HIPCHK(h, dmalloc(&h->d_fixed_colbase, (u64)n_loci + 1)); HIPCHK(h, hipMemcpy(h->d_fixed_colbase, h->fixed_colbase.data(), ((u64)n_loci + 1) * 8, hipMemcpyHostToDevice));
+        HIPCHK(h, dmalloc(&h->d_auto_chosen, (u64)n_loci));
+        HIPCHK(h, dmalloc(&h->d_auto_counts, h->fixed_cols * 4 + 4)); HIPCHK(h, dmalloc(&h->d_auto_letters, h->fixed_cols + 16));
+        HIPCHK(h, hipHostMalloc((void**)&h->h_auto, (u64)n_loci * 4 + h->fixed_cols + 64, hipHostMallocDefault));
+    }
     // ---- sample state
     EngineDev& E = h->E;
     E.arena = h->d_arena; E.planes = h->d_planes; E.nmask = h->d_nmask; E.allele_len = h->d_allele_len; E.allele_locus = h->d_allele_locus; E.loci = h->d_loci;
@@ -2335,6 +2403,58 @@ extern "C" int mlst_consensus_from_counts_device(mlst_handle* h, const uint32_t*
     HIPCHK(h, hipMemcpyAsync(stage, d_letters, n_cols, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     memcpy(out_seq, stage, n_cols);
+    return MLST_OK;
+}
+
+extern "C" long long mlst_round_tenths(long long p, uint32_t q) { return q ? round_tenths(p, q) : 0; }
+
+extern "C" int mlst_typing_layout(mlst_handle* h, uint64_t* colbase, uint64_t* total_cols) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (colbase) memcpy(colbase, h->fixed_colbase.data(), ((u64)h->n_loci + 1) * 8);
+    if (total_cols) *total_cols = h->fixed_cols;
+    return MLST_OK;
+}
+
+// Asynchronous: on the engine's stream, behind whatever pass 1 has been submitted -- allele choice, pileup against
+// the chosen alleles, majority consensus, and the copies of statistics, choice and consensus into pinned memory.
+extern "C" int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    hipSetDevice(h->device);
+    const u64 nl = h->n_loci, ncols = h->fixed_cols;
+    if (nl) hipLaunchKernelGGL(k_choose, dim3((unsigned)nl), dim3(256), 0, h->stream, h->d_E, h->d_allele_no, (int)penalty, h->d_auto_chosen);
+    HIPCHK(h, hipMemsetAsync(h->d_auto_counts, 0, (ncols ? ncols : 1) * 16, h->stream));
+    HIPCHK(h, hipMemsetAsync(&h->E.ctr.p->n_pl_dp, 0, 8, h->stream));
+    { Prof pf(h, 5);
+      hipLaunchKernelGGL(k_pileup, dim3(4096), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, h->d_auto_counts, h->d_pl_list);
+      hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, h->d_auto_counts, h->d_pl_list, h->d_tb);
+      if (ncols) hipLaunchKernelGGL(k_consensus, dim3(grid_for(ncols, 256, 256)), dim3(256), 0, h->stream, h->d_auto_counts, (u64)ncols, mincov, (u8)none_char, h->d_auto_letters); }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, h->stats_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (nl) HIPCHK(h, hipMemcpyAsync(h->h_auto, h->d_auto_chosen, nl * 4, hipMemcpyDeviceToHost, h->stream));
+    if (ncols) HIPCHK(h, hipMemcpyAsync(h->h_auto + ((nl * 4 + 15) & ~15ull), h->d_auto_letters, ncols, hipMemcpyDeviceToHost, h->stream));
+    h->auto_pending = true;
+    return MLST_OK;
+}
+
+// Waits for mlst_typing_enqueue and hands everything over: the statistics of mlst_get_allele_stats, chosen[n_loci]
+// (allele index or -1) and the consensus letters in the fixed layout of mlst_typing_layout.
+extern "C" int mlst_typing_fetch(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_len, uint64_t* locus_first,
+                                 uint64_t* counters, int32_t* chosen, uint8_t* letters) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (!h->auto_pending) return fail(h, MLST_E_INVALID, "mlst_typing_fetch without mlst_typing_enqueue");
+    hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->auto_pending = false;
+    Counters* c = (Counters*)(h->h_stats + h->off_ctr);
+    if (c->err) return fail(h, MLST_E_CAPACITY, "capacity exceeded (flags 0x%llx); raise mlst_params.max_*", (unsigned long long)c->err);
+    const u64 nl = h->n_loci;
+    if (sum_score) memcpy(sum_score, h->h_stats + h->off_sum, (u64)h->n_alleles * 8);
+    if (n_hits) memcpy(n_hits, h->h_stats + h->off_hits, (u64)h->n_alleles * 4);
+    if (locus_len) memcpy(locus_len, h->h_stats + h->off_len, nl * 8);
+    if (locus_first) memcpy(locus_first, h->h_stats + h->off_first, nl * 8);
+    if (counters) { for (int i = 0; i < MLST_CNT_N; i++) counters[i] = c->cnt[i]; counters[MLST_CNT_RETAINED] = c->n_ret; counters[MLST_CNT_ITEMS] = c->n_items; }
+    if (chosen) memcpy(chosen, h->h_auto, nl * 4);
+    if (letters) memcpy(letters, h->h_auto + ((nl * 4 + 15) & ~15ull), h->fixed_cols);
     return MLST_OK;
 }
 

@@ -133,11 +133,20 @@ class DbCache:
         self.seq_first: dict = {}       # (bacterium, sequence) -> (gene, alleleVariant) of the first row
         self.label_rec: dict = {}       # 'bacterium_gene_alleleVariant' -> recID of the first row
         self.prof_by_allele: dict = {}  # alleleCode -> [profileCode, ...] (one per profiles row)
+        self._genes: dict = {}          # bacterium -> [geneName, ...]
         for row in conn.execute("SELECT recID,bacterium,gene,sequence,alleleVariant FROM alleles ORDER BY recID"):
             self.seq_first.setdefault((row["bacterium"], row["sequence"]), (row["gene"], row["alleleVariant"]))
             self.label_rec.setdefault("%s_%s_%s" % (row["bacterium"], row["gene"], row["alleleVariant"]), row["recID"])
         for row in conn.execute("SELECT profileCode,alleleCode FROM profiles ORDER BY recID"):
             self.prof_by_allele.setdefault(row["alleleCode"], []).append(row["profileCode"])
+
+    def genes(self, bacterium) -> list:
+        """geneName rows of `SELECT geneName FROM genes WHERE bacterium = ?` (metamlst.py:185), in rowid order."""
+        g = self._genes.get(bacterium)
+        if g is None:
+            g = [row["geneName"] for row in self.conn.execute("SELECT geneName FROM genes WHERE bacterium = ?", (bacterium,))]
+            self._genes[bacterium] = g
+        return g
 
     def sequenceExists(self, bacterium, sequence) -> bool:
         return (bacterium, str(sequence)) in self.seq_first

@@ -96,6 +96,10 @@ def load_library(path: str | None = None):
         "mlst_pileup_device": (C.c_int, [H, u32p, C.c_uint32, u32p, C.POINTER(C.c_uint64)]),
         "mlst_consensus": (C.c_int, [H, u32p, C.c_uint32, C.c_uint32, C.c_char, u8p, u32p]),
         "mlst_consensus_from_counts_device": (C.c_int, [H, u32p, C.c_uint64, C.c_uint32, C.c_char, u8p]),
+        "mlst_typing_layout": (C.c_int, [H, u64p, C.POINTER(C.c_uint64)]),
+        "mlst_typing_enqueue": (C.c_int, [H, C.c_int32, C.c_uint32, C.c_char]),
+        "mlst_typing_fetch": (C.c_int, [H, i64p, u32p, u64p, u64p, u64p, i32p, u8p]),
+        "mlst_round_tenths": (C.c_longlong, [C.c_longlong, C.c_uint32]),
         "mlst_hamming_le": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
         "mlst_hamming_all": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, u32p]),
         "mlst_reset_sample": (C.c_int, [H]),
@@ -195,6 +199,34 @@ class Engine:
         self._check(self.lib.mlst_get_allele_stats(self._h, _ptr(s.sum_score), _ptr(s.n_hits), _ptr(s.locus_len_sum),
                                                    _ptr(s.locus_first), _ptr(s.counters)), "mlst_get_allele_stats")
         return s
+
+    # ---- typing tail on the device ----
+    def typing_enqueue(self, penalty: int = 100, mincov: int = 1, none_char: str = "N"):
+        """Queue allele choice + pileup + consensus + host copies behind the submitted pass 1 (returns at once)."""
+        self._check(self.lib.mlst_typing_enqueue(self._h, int(penalty), int(mincov), none_char.encode()), "mlst_typing_enqueue")
+
+    def typing_fetch(self):
+        """-> (SampleStats, {locus: chosen allele idx}, {allele idx: consensus bytes}) of the last typing_enqueue."""
+        nA, nL = self.index.n_alleles, self.index.n_loci
+        if getattr(self, "_colbase", None) is None or len(self._colbase) != nL + 1:
+            self._colbase = np.zeros(nL + 1, np.uint64)
+            tot = C.c_uint64()
+            self._check(self.lib.mlst_typing_layout(self._h, _ptr(self._colbase), C.byref(tot)), "mlst_typing_layout")
+            self._cb_list = [int(x) for x in self._colbase]
+        s = SampleStats(np.empty(nA, np.int64), np.empty(nA, np.uint32), np.empty(nL, np.uint64),
+                        np.empty(nL, np.uint64), np.empty(MLST_CNT_N, np.uint64))
+        chosen = np.empty(nL, np.int32)
+        letters = np.empty(self._cb_list[-1], np.uint8)
+        self._check(self.lib.mlst_typing_fetch(self._h, _ptr(s.sum_score), _ptr(s.n_hits), _ptr(s.locus_len_sum), _ptr(s.locus_first),
+                                               _ptr(s.counters), _ptr(chosen), _ptr(letters)), "mlst_typing_fetch")
+        raw = letters.tobytes()
+        ch, let = {}, {}
+        off = self.index.off
+        for l in np.nonzero(chosen >= 0)[0].tolist():
+            a = int(chosen[l]); ch[l] = a
+            b = self._cb_list[l]
+            let[a] = raw[b:b + int(off[a + 1] - off[a])]
+        return s, ch, let
 
     def flat_sizes(self) -> tuple[int, int]:
         a, b = C.c_uint64(), C.c_uint64()

@@ -265,7 +265,7 @@ def _detected_loci(index: AlleleIndex, st: SampleStats) -> dict:
 
 def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.metaMLST_db, fileName: str,
                 args: TypingArgs | None = None, out_dir: str | None = None, fast: bool = False,
-                cache: mdb.DbCache | None = None, consensus_fn=None) -> list[SpeciesResult]:
+                cache: mdb.DbCache | None = None, consensus_fn=None, typed=None) -> list[SpeciesResult]:
     """metamlst.py:133-289 for one sample.
 
     pileup_fn(list of allele indices) -> {allele idx: uint32[len, 4]} is pass 2 of the engine
@@ -276,12 +276,15 @@ def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.me
     args = args or TypingArgs()
     cursor = database.cursor
     cel = _detected_loci(index, st) if fast else compile_cel(index, st, args.penalty)
-    fast_choice = pick_alleles_fast(index, st, args.penalty) if fast else None
+    # typed = (chosen {locus: allele idx}, letters {allele idx: bytes}) from Engine.typing_fetch: choice and consensus
+    # were made on the device (mlst_typing_enqueue, penalty = args.penalty); implies the fast path
+    fast_choice = (typed[0] if typed is not None else pick_alleles_fast(index, st, args.penalty)) if fast else None
     results: list[SpeciesResult] = []
     plan = []
     for speciesKey, species in cel.items():
         # metamlst.py:184-206 locus presence gate
-        tVar = dict([(row["geneName"], 0) for row in cursor.execute("SELECT geneName FROM genes WHERE bacterium = ?", (speciesKey,))])
+        tVar = (dict.fromkeys(cache.genes(speciesKey), 0) if cache is not None else
+                dict([(row["geneName"], 0) for row in cursor.execute("SELECT geneName FROM genes WHERE bacterium = ?", (speciesKey,))]))
         if len(tVar) < len(species.keys()):
             raise SystemExit("Database is broken for " + speciesKey)      # metamlst.py:188-190 exits
         for sk in species.keys():
@@ -319,7 +322,8 @@ def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.me
             plan.append((res, a))
     # pass 2 once for every species that passed (identical to one buildConsensus per species)
     # consensus_fn(list of allele indices) -> {allele idx: consensus bytes} (mlst_consensus) replaces counts + majority
-    letters = consensus_fn([a for _, a in plan]) if (plan and consensus_fn is not None) else None
+    letters = (typed[1] if (typed is not None and fast) else
+               consensus_fn([a for _, a in plan]) if (plan and consensus_fn is not None) else None)
     counts = pileup_fn([a for _, a in plan]) if (plan and letters is None) else {}
     for res in results:
         if not res.passed_nloci:

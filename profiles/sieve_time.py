@@ -1,5 +1,5 @@
 import sys, os, tempfile
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from metamlst_amd import synth

@@ -348,3 +348,68 @@ def test_plain_sieve_with_global_bitmap_and_without(monkeypatch):
         eng, orc = both(idx)
         s, _ = run_both(eng, orc, fb, fq, off)
         check_pileup(eng, orc, idx, s)
+
+
+def test_device_typing_tail_equals_host_choice_and_consensus():
+    """mlst_typing_enqueue / mlst_typing_fetch (allele choice + pileup + consensus queued behind pass 1) against the
+    host's own allele choice (metamlst.py:133-151, 244 restated in typing.pick_alleles_fast) and mlst_consensus."""
+    for db, idx, sp, row in ((*fx.ecoli_small(80), "ecoli", 4), (*fx.ecoli_small(60, indel_every=5), "ecoli", 2),
+                             (*fx.multi_species(3, 25), None, 1)):
+        sp = sp or db.species[1]
+        fb, fq, off, _, _ = fx.isolate_reads(db, sp, row, n_reads=12000)
+        eng = Engine(0)
+        eng.load_reference(idx)
+        for penalty in (100, 0, 7):
+            eng.reset_sample()
+            eng.submit_reads(fb, fq, off)
+            eng.typing_enqueue(penalty=penalty)
+            st, chosen, letters = eng.typing_fetch()
+            fx.assert_stats_equal(st, eng.stats())
+            want = pick_alleles_fast(idx, st, penalty)
+            assert chosen == want
+            cons = eng.consensus(sorted(want.values()))
+            assert {a: bytes(v) for a, v in letters.items()} == {a: bytes(v) for a, v in cons.items()}
+
+
+def test_device_allele_choice_on_crafted_ties():
+    """Statistics built to tie: equal rounded averages with different allele numbers, averages on x.x5 boundaries (where
+    the binary double falls on either side), exact quarters, negative penalised scores, loci without records."""
+    import torch
+    from metamlst_amd.typing import SampleStats
+    db, idx = fx.ecoli_small(80)
+    eng = Engine(0)
+    eng.load_reference(idx)
+    dev = torch.device("cuda", 0)
+    nA, nL = idx.n_alleles, idx.n_loci
+    n_sum, n_min = eng.flat_sizes()
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        nh = np.zeros(nA, np.int64); ss = np.zeros(nA, np.int64)
+        first = np.full(nL, np.iinfo(np.int64).max, np.int64)
+        for l in range(nL):
+            b, c = int(idx.locus_begin[l]), int(idx.locus_count[l])
+            if trial % 4 == 3 and l % 3 == 0:
+                continue                                  # locus without any record
+            first[l] = 1000 * l + trial
+            k = rng.choice(c, size=min(c, 30), replace=False)
+            if trial % 3 == 0:                            # all on twentieths: p/q = (2m+1)/20
+                q = rng.choice([20, 40, 100, 4, 8], size=k.size)
+                m = rng.integers(1000, 1010, size=k.size)
+                nh[b + k] = q
+                ss[b + k] = np.where(q % 20 == 0, (2 * m + 1) * (q // 20), (2 * (m // 5) + 1) * (q // 4) + 100 * q)
+            elif trial % 3 == 1:                          # identical averages: the lowest allele number must win
+                q = rng.integers(1, 50, size=k.size)
+                nh[b + k] = q; ss[b + k] = 250 * q
+            else:                                         # unequal depths: the penalty makes scores negative
+                q = rng.integers(1, 400, size=k.size)
+                nh[b + k] = q; ss[b + k] = q * rng.integers(80, 300, size=k.size) + rng.integers(0, 20, size=k.size)
+        flat = np.concatenate([ss, nh, np.zeros(nL, np.int64), np.zeros(n_sum - 2 * nA - nL, np.int64)])
+        eng.reset_sample()
+        t_flat, t_first = torch.from_numpy(flat).to(dev), torch.from_numpy(first).to(dev)
+        torch.cuda.synchronize(dev)
+        eng.import_stats_device(t_flat.data_ptr(), t_first.data_ptr())
+        for penalty in (100, 3):
+            eng.typing_enqueue(penalty=penalty)
+            st, chosen, _ = eng.typing_fetch()
+            assert np.array_equal(st.sum_score, ss) and np.array_equal(st.n_hits.astype(np.int64), nh)
+            assert chosen == pick_alleles_fast(idx, st, penalty), (trial, penalty)
