@@ -150,7 +150,7 @@ def main():
         dist.barrier()
     from metamlst_amd import db as mdb
     from metamlst_amd import synth
-    from metamlst_amd.dist import DeviceStatsPort, allreduce_consensus, allreduce_pileup, allreduce_stats, split_counts
+    from metamlst_amd.dist import StreamedShard
     from metamlst_amd.engine import Engine
     from metamlst_amd.index import load_index
     from metamlst_amd.merge import EngineMatcher, SpeciesSession, parse_nfo_line
@@ -173,7 +173,9 @@ def main():
     t_setup = time.time() - t0
     packed, qrows, lens, wpr, qstride = synth_reads_gpu(eng, torch, device, genome, args.reads, args.read_len,
                                                         seed=synth.SEED + 1000 * rank)
-    ports = [DeviceStatsPort(e, device) for e in engines]
+    # N > 1: every engine runs on its own torch stream, so that its kernels and the RCCL all-reduces of its step are
+    # ordered on the device and the host synchronises once per step (metamlst_amd.dist.StreamedShard)
+    shards = [StreamedShard(e, device) for e in engines] if world > 1 else None
     matcher = EngineMatcher(eng, idx)
     true_st = args.st_row + 1
     # merge-run prologue (metamlst-merge.py:119-142) happens once per run of many samples: untimed setup
@@ -188,42 +190,31 @@ def main():
     host_ms = {"submit": 0.0, "stats": 0.0, "typing+pileup": 0.0, "st_call": 0.0}
 
     def submit(k):
-        """Pass 1 of step k: asynchronous (sieve -> seeds -> extension -> accumulation on engine k % depth)."""
+        """Everything of step k that runs on the GPU, queued without waiting: pass 1 (sieve -> seeds -> extension ->
+        accumulation), at N > 1 the all-reduce of the statistics, allele choice, pileup, at N > 1 the all-reduce of the
+        pileup counts, consensus, copies to the host -- on engine k % depth."""
         t_a = time.perf_counter()
         e = engines[k % depth]
-        e.reset_sample()
-        e.set_read_index_base(rank * args.reads)
-        e.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), args.reads, wpr, qstride)
-        if world == 1:      # allele choice + pileup + consensus queued behind pass 1: no host round trip between the passes
+
+        def pass1():
+            e.reset_sample()
+            e.set_read_index_base(rank * args.reads)
+            e.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), args.reads, wpr, qstride)
+
+        if world > 1:
+            shards[k % depth].enqueue(pass1, penalty=100)
+        else:
+            pass1()
             e.typing_enqueue(penalty=100)
         host_ms["submit"] += (time.perf_counter() - t_a) * 1e3
 
     def finish(k):
-        """The rest of step k: (all-reduce,) statistics, allele choice, pileup, consensus, .nfo line, ST call."""
-        e, port = engines[k % depth], ports[k % depth]
+        """The host part of step k: wait for its device work, then .nfo line (gap-fill, accuracy gate) and ST call."""
+        e = engines[k % depth]
         t_b = time.perf_counter()
-        typed = None
-        if world > 1:
-            allreduce_stats(port, device)
-            st = e.stats()
-        else:
-            st, chosen_dev, letters_dev = e.typing_fetch()
-            typed = (chosen_dev, letters_dev)
+        st, chosen_dev, letters_dev = e.typing_fetch()
         t_c = time.perf_counter()
-
-        def pileup_fn(chosen):
-            if world > 1:
-                n_cols = sum(int(idx.off[a + 1] - idx.off[a]) for a in chosen)
-                return split_counts(idx, chosen, allreduce_pileup(port, chosen, n_cols, device))
-            return e.pileup(chosen)
-
-        def consensus_fn(chosen):
-            if world > 1:
-                n_cols = sum(int(idx.off[a + 1] - idx.off[a]) for a in chosen)
-                return allreduce_consensus(port, idx, chosen, n_cols, device)
-            return e.consensus(chosen)
-
-        res = type_sample(idx, st, pileup_fn, database, "sample", fast=True, cache=cache, consensus_fn=consensus_fn, typed=typed)
+        res = type_sample(idx, st, None, database, "sample", fast=True, cache=cache, typed=(chosen_dev, letters_dev))
         t_d = time.perf_counter()
         out = {}
         if rank == 0:
@@ -232,7 +223,7 @@ def main():
                     organism, (bacteriumLine, sampleRecord) = parse_nfo_line(r.nfo_line)
                     out[organism] = sessions[organism].add_sample(bacteriumLine, sampleRecord)
         t_e = time.perf_counter()
-        host_ms["stats"] += (t_c - t_b) * 1e3        # includes waiting for the pass-1 kernels
+        host_ms["stats"] += (t_c - t_b) * 1e3        # waiting for the device work of the step
         host_ms["typing+pileup"] += (t_d - t_c) * 1e3
         host_ms["st_call"] += (t_e - t_d) * 1e3
         return out, st

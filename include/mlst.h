@@ -181,6 +181,11 @@ int mlst_consensus_from_counts_device(mlst_handle* h, const uint32_t* d_counts, 
  * own statement of it (typing.pick_alleles_fast) and the tests compare the two. */
 int mlst_typing_layout(mlst_handle* h, uint64_t* colbase /* n_loci + 1 */, uint64_t* total_cols);
 int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char);
+/* The two halves of mlst_typing_enqueue, for a multi-GPU caller that all-reduces the pileup counts in between:
+ * choice + pileup into d_counts (device, total_cols * 4 uint32, zeroed by the call; NULL = internal buffer), then
+ * consensus over d_counts + the copies to the host. */
+int mlst_typing_choose_pileup(mlst_handle* h, int32_t penalty, uint32_t* d_counts);
+int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_char, const uint32_t* d_counts);
 int mlst_typing_fetch(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_read_len_sum,
                       uint64_t* locus_first_read, uint64_t* counters, int32_t* chosen, uint8_t* letters);
 /* round(float(p) / float(q), 1) of Python as an exact integer number of tenths (host function, the same code
@@ -217,6 +222,14 @@ int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint64_t* n);
 
 /* Per-kernel device time measured with HIP events on the engine's stream.
  * which: 0=sieve 1=seed 2=extend 3=banded-SW 4=accumulate 5=pileup 6=pack */
+/* Run the engine on the caller's HIP stream (hipStream_t; NULL = back on the engine's own stream).  Work queued so
+ * far is waited for.  With the engine on the stream a torch.distributed collective is ordered against, a multi-GPU
+ * step needs no host synchronisation between its kernels and its collectives (metamlst_amd/dist.py). */
+int mlst_set_stream(mlst_handle* h, void* stream);
+/* mlst_export_stats_device / mlst_import_stats_device without the host synchronisation. */
+int mlst_export_stats_device_async(mlst_handle* h, int64_t* d_sum, int64_t* d_min);
+int mlst_import_stats_device_async(mlst_handle* h, const int64_t* d_sum, const int64_t* d_min);
+
 int mlst_set_profiling(mlst_handle* h, int on);
 int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms, uint64_t* launches);
 int mlst_reset_kernel_time(mlst_handle* h);

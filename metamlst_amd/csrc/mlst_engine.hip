@@ -1722,6 +1722,7 @@ struct mlst_handle {
     // device-side typing (mlst_typing_enqueue / mlst_typing_fetch): fixed column layout, one slot of loc_maxlen columns per locus
     int* d_allele_no = nullptr; int* d_auto_chosen = nullptr; u64* d_fixed_colbase = nullptr; std::vector<u64> fixed_colbase; u64 fixed_cols = 0;
     u32* d_auto_counts = nullptr; u8* d_auto_letters = nullptr; u8* h_auto = nullptr; bool auto_pending = false;
+    hipStream_t own_stream = nullptr;           // the stream created by mlst_create (h->stream may be a caller's stream: mlst_set_stream)
     u32* d_dist = nullptr; u8* d_query = nullptr; u64 cap_dist = 0, cap_query = 0;
     // one contiguous device block [sum_score | locus_len | Counters | n_hits | pad][locus_first] with a pinned mirror
     u8* d_stats = nullptr; u8* h_stats = nullptr; u64 stats_bytes = 0, stats_zero_bytes = 0;
@@ -1792,6 +1793,7 @@ extern "C" int mlst_create(int device, const mlst_params* p, mlst_handle** out) 
     mlst_handle* h = new mlst_handle();
     h->device = device; h->prm = prm;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, MLST_E_HIP, "cannot initialise device %d", device); }
+    h->own_stream = h->stream;
     KParams& k = h->kp;
     k.minscore = prm.minscore; k.max_xm = prm.max_xm; k.min_read_len = prm.min_read_len; k.minqual = prm.minqual;
     k.match_bonus = prm.match_bonus; k.n_penalty = prm.n_penalty;
@@ -1837,7 +1839,7 @@ extern "C" void mlst_destroy(mlst_handle* h) {
     hipFree(h->d_cand); hipFree(h->d_in_bases); hipFree(h->d_in_quals); hipFree(h->d_in_off);
     hipFree(h->d_fq_text); hipFree(h->d_fq_blk); hipFree(h->d_fq_lines); hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); hipFree(h->d_fq_meta);
     hipFree(h->d_packed); hipFree(h->d_qrows); hipFree(h->d_lens); hipFree(h->d_counts); hipFree(h->d_dist); hipFree(h->d_query);
-    if (h->stream) hipStreamDestroy(h->stream);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -2415,24 +2417,66 @@ extern "C" int mlst_typing_layout(mlst_handle* h, uint64_t* colbase, uint64_t* t
     return MLST_OK;
 }
 
-// Asynchronous: on the engine's stream, behind whatever pass 1 has been submitted -- allele choice, pileup against
-// the chosen alleles, majority consensus, and the copies of statistics, choice and consensus into pinned memory.
-extern "C" int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char) {
+// Asynchronous, on the engine's stream, behind whatever pass 1 has been submitted.  Phase 1: allele choice and pileup
+// against the chosen alleles into d_counts (NULL = the engine's own buffer; a caller's buffer of total_cols*4 uint32 lets
+// a multi-GPU caller all-reduce the counts between the phases).  Phase 2: majority consensus over those counts and the
+// copies of statistics, choice and consensus into pinned memory.
+extern "C" int mlst_typing_choose_pileup(mlst_handle* h, int32_t penalty, uint32_t* d_counts) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);
     const u64 nl = h->n_loci, ncols = h->fixed_cols;
+    u32* cnt = d_counts ? d_counts : h->d_auto_counts;
     if (nl) hipLaunchKernelGGL(k_choose, dim3((unsigned)nl), dim3(256), 0, h->stream, h->d_E, h->d_allele_no, (int)penalty, h->d_auto_chosen);
-    HIPCHK(h, hipMemsetAsync(h->d_auto_counts, 0, (ncols ? ncols : 1) * 16, h->stream));
+    HIPCHK(h, hipMemsetAsync(cnt, 0, (ncols ? ncols : 1) * 16, h->stream));
     HIPCHK(h, hipMemsetAsync(&h->E.ctr.p->n_pl_dp, 0, 8, h->stream));
     { Prof pf(h, 5);
-      hipLaunchKernelGGL(k_pileup, dim3(4096), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, h->d_auto_counts, h->d_pl_list);
-      hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, h->d_auto_counts, h->d_pl_list, h->d_tb);
-      if (ncols) hipLaunchKernelGGL(k_consensus, dim3(grid_for(ncols, 256, 256)), dim3(256), 0, h->stream, h->d_auto_counts, (u64)ncols, mincov, (u8)none_char, h->d_auto_letters); }
+      hipLaunchKernelGGL(k_pileup, dim3(4096), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list);
+      hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list, h->d_tb); }
+    HIPCHK(h, hipGetLastError());
+    return MLST_OK;
+}
+extern "C" int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_char, const uint32_t* d_counts) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    hipSetDevice(h->device);
+    const u64 nl = h->n_loci, ncols = h->fixed_cols;
+    const u32* cnt = d_counts ? d_counts : h->d_auto_counts;
+    if (ncols) hipLaunchKernelGGL(k_consensus, dim3(grid_for(ncols, 256, 256)), dim3(256), 0, h->stream, cnt, (u64)ncols, mincov, (u8)none_char, h->d_auto_letters);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, h->stats_bytes, hipMemcpyDeviceToHost, h->stream));
     if (nl) HIPCHK(h, hipMemcpyAsync(h->h_auto, h->d_auto_chosen, nl * 4, hipMemcpyDeviceToHost, h->stream));
     if (ncols) HIPCHK(h, hipMemcpyAsync(h->h_auto + ((nl * 4 + 15) & ~15ull), h->d_auto_letters, ncols, hipMemcpyDeviceToHost, h->stream));
     h->auto_pending = true;
+    return MLST_OK;
+}
+extern "C" int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char) {
+    int rc = mlst_typing_choose_pileup(h, penalty, nullptr); if (rc) return rc;
+    return mlst_typing_finish(h, mincov, none_char, nullptr);
+}
+
+// Run the engine on a caller's HIP stream (e.g. the stream a torch.distributed collective is ordered against), or
+// back on its own (stream = NULL).  Everything queued so far is waited for first.
+extern "C" int mlst_set_stream(mlst_handle* h, void* stream) {
+    if (!h) return MLST_E_INVALID;
+    hipSetDevice(h->device);
+    drain_events(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = stream ? (hipStream_t)stream : h->own_stream;
+    return MLST_OK;
+}
+// mlst_export_stats_device / mlst_import_stats_device without the host synchronisation (capacity errors surface in
+// mlst_typing_fetch / mlst_get_allele_stats)
+extern "C" int mlst_export_stats_device_async(mlst_handle* h, int64_t* d_sum, int64_t* d_min) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    hipSetDevice(h->device);
+    hipLaunchKernelGGL(k_export, dim3(256), dim3(256), 0, h->stream, h->d_E, (long long*)d_sum, (long long*)d_min);
+    HIPCHK(h, hipGetLastError());
+    return MLST_OK;
+}
+extern "C" int mlst_import_stats_device_async(mlst_handle* h, const int64_t* d_sum, const int64_t* d_min) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    hipSetDevice(h->device);
+    hipLaunchKernelGGL(k_import, dim3(256), dim3(256), 0, h->stream, h->d_E, (const long long*)d_sum, (const long long*)d_min);
+    HIPCHK(h, hipGetLastError());
     return MLST_OK;
 }
 

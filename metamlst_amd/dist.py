@@ -108,3 +108,45 @@ def split_counts(index, chosen: list[int], counts: np.ndarray) -> dict[int, np.n
         out[int(a)] = counts[at:at + L]
         at += L
     return out
+
+
+class StreamedShard:
+    """One engine of a rank with everything of a step queued on ONE torch stream: pass 1, export of the statistics,
+    the two all-reduces (RCCL orders a collective against the current stream), import, allele choice + pileup, the
+    all-reduce of the pileup counts, consensus and the copies to the host.  The host synchronises once per step, in
+    fetch().  The engine library and torch share one HIP runtime in the process (the library binds to the
+    libamdhip64.so.7 torch has already loaded), so the engine can run on a torch stream (mlst_set_stream)."""
+
+    def __init__(self, engine, device: torch.device, group=None, force_collectives: bool = False):
+        self.engine, self.device, self.group = engine, device, group
+        self.force = force_collectives           # tests: issue the collectives even in a group of one
+        self.stream = torch.cuda.Stream(device=device)
+        n_sum, n_min = engine.flat_sizes()
+        self.t_sum = torch.zeros(max(1, n_sum), dtype=torch.int64, device=device)
+        self.t_min = torch.zeros(max(1, n_min), dtype=torch.int64, device=device)
+        self.t_counts = torch.zeros(max(1, engine.typing_total_cols()) * 4, dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)
+        engine.set_stream(self.stream.cuda_stream)
+
+    def enqueue(self, submit_fn, penalty: int = 100, mincov: int = 1):
+        """submit_fn() queues pass 1 on the engine (reset_sample + submit_*); everything else follows here."""
+        e = self.engine
+        multi = dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
+        with torch.cuda.stream(self.stream):
+            submit_fn()
+            if multi:
+                e.export_stats_device_async(self.t_sum.data_ptr(), self.t_min.data_ptr())
+                dist.all_reduce(self.t_sum, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self.t_min, op=dist.ReduceOp.MIN, group=self.group)
+                e.import_stats_device_async(self.t_sum.data_ptr(), self.t_min.data_ptr())
+            e.typing_choose_pileup(penalty, self.t_counts.data_ptr())
+            if multi:
+                dist.all_reduce(self.t_counts, op=dist.ReduceOp.SUM, group=self.group)
+            e.typing_finish(mincov, "N", self.t_counts.data_ptr())
+
+    def fetch(self):
+        """-> (SampleStats, {locus: chosen allele idx}, {allele idx: consensus bytes}); whole-job values on every rank."""
+        return self.engine.typing_fetch()
+
+    def close(self):
+        self.engine.set_stream(0)

@@ -98,6 +98,11 @@ def load_library(path: str | None = None):
         "mlst_consensus_from_counts_device": (C.c_int, [H, u32p, C.c_uint64, C.c_uint32, C.c_char, u8p]),
         "mlst_typing_layout": (C.c_int, [H, u64p, C.POINTER(C.c_uint64)]),
         "mlst_typing_enqueue": (C.c_int, [H, C.c_int32, C.c_uint32, C.c_char]),
+        "mlst_typing_choose_pileup": (C.c_int, [H, C.c_int32, u32p]),
+        "mlst_typing_finish": (C.c_int, [H, C.c_uint32, C.c_char, u32p]),
+        "mlst_set_stream": (C.c_int, [H, C.c_void_p]),
+        "mlst_export_stats_device_async": (C.c_int, [H, i64p, i64p]),
+        "mlst_import_stats_device_async": (C.c_int, [H, i64p, i64p]),
         "mlst_typing_fetch": (C.c_int, [H, i64p, u32p, u64p, u64p, u64p, i32p, u8p]),
         "mlst_round_tenths": (C.c_longlong, [C.c_longlong, C.c_uint32]),
         "mlst_hamming_le": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
@@ -204,6 +209,27 @@ class Engine:
     def typing_enqueue(self, penalty: int = 100, mincov: int = 1, none_char: str = "N"):
         """Queue allele choice + pileup + consensus + host copies behind the submitted pass 1 (returns at once)."""
         self._check(self.lib.mlst_typing_enqueue(self._h, int(penalty), int(mincov), none_char.encode()), "mlst_typing_enqueue")
+
+    def typing_choose_pileup(self, penalty: int = 100, d_counts: int = 0):
+        self._check(self.lib.mlst_typing_choose_pileup(self._h, int(penalty), d_counts or None), "mlst_typing_choose_pileup")
+
+    def typing_finish(self, mincov: int = 1, none_char: str = "N", d_counts: int = 0):
+        self._check(self.lib.mlst_typing_finish(self._h, int(mincov), none_char.encode(), d_counts or None), "mlst_typing_finish")
+
+    def typing_total_cols(self) -> int:
+        tot = C.c_uint64()
+        self._check(self.lib.mlst_typing_layout(self._h, None, C.byref(tot)), "mlst_typing_layout")
+        return int(tot.value)
+
+    def set_stream(self, stream: int = 0):
+        """Run the engine on a caller's HIP stream (e.g. torch.cuda.Stream.cuda_stream); 0 = its own stream again."""
+        self._check(self.lib.mlst_set_stream(self._h, stream or None), "mlst_set_stream")
+
+    def export_stats_device_async(self, d_sum: int, d_min: int):
+        self._check(self.lib.mlst_export_stats_device_async(self._h, d_sum, d_min), "mlst_export_stats_device_async")
+
+    def import_stats_device_async(self, d_sum: int, d_min: int):
+        self._check(self.lib.mlst_import_stats_device_async(self._h, d_sum, d_min), "mlst_import_stats_device_async")
 
     def typing_fetch(self):
         """-> (SampleStats, {locus: chosen allele idx}, {allele idx: consensus bytes}) of the last typing_enqueue."""

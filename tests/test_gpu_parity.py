@@ -413,3 +413,39 @@ def test_device_allele_choice_on_crafted_ties():
             st, chosen, _ = eng.typing_fetch()
             assert np.array_equal(st.sum_score, ss) and np.array_equal(st.n_hits.astype(np.int64), nh)
             assert chosen == pick_alleles_fast(idx, st, penalty), (trial, penalty)
+
+
+def test_streamed_shard_step_on_a_torch_stream():
+    """The multi-GPU step of metamlst_amd.dist.StreamedShard -- engine on a torch stream, RCCL all-reduces queued
+    between its kernels, one host synchronisation -- in a process group of one (the collectives are issued and are
+    identities): same statistics, choice and consensus as the plain calls."""
+    import torch
+    import torch.distributed as dist
+    from metamlst_amd.dist import StreamedShard
+    db, idx = fx.ecoli_small(80)
+    fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 4, n_reads=9000)
+    plain = Engine(0)
+    plain.load_reference(idx)
+    plain.submit_reads(fb, fq, off)
+    s0 = plain.stats()
+    want = pick_alleles_fast(idx, s0, 100)
+    cons = plain.consensus(sorted(want.values()))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        eng = Engine(0)
+        eng.load_reference(idx)
+        sh = StreamedShard(eng, torch.device("cuda", 0), force_collectives=True)
+        for _ in range(3):                       # reuse across samples, as the bench loop does
+            sh.enqueue(lambda: (eng.reset_sample(), eng.submit_reads(fb, fq, off)))
+            st, chosen, letters = sh.fetch()
+            fx.assert_stats_equal(st, s0)
+            assert chosen == want
+            assert {a: bytes(v) for a, v in letters.items()} == {a: bytes(v) for a, v in cons.items()}
+        sh.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
