@@ -249,14 +249,18 @@ def main():
 
     run(args.warmup)
     # strictly serial steps (one engine), a few of them: the latency of one step, reported beside the throughput
+    engines[0].set_profiling(True)
+    engines[0].reset_kernel_time()
     fence()
     t0 = time.perf_counter()
-    n_serial = min(5, args.steps)
+    n_serial = min(20, args.steps)
     for k in range(n_serial):
         submit(0)
         finish(0)
     fence()
     serial_ms = (time.perf_counter() - t0) / max(1, n_serial) * 1e3
+    KNAMES = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup")
+    isolated = {k: engines[0].kernel_time(k) for k in KNAMES}       # no other stream is busy during these steps
     for e in engines:
         e.set_profiling(True)
         e.reset_kernel_time()
@@ -273,7 +277,7 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     kernels = {}
-    for k in ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup"):
+    for k in KNAMES:
         parts = [e.kernel_time(k) for e in engines]
         kernels[k] = (sum(p_[0] for p_ in parts), sum(p_[1] for p_ in parts))
     for e in engines:
@@ -305,6 +309,13 @@ def main():
                 "alg_bytes_per_read": ALG_BYTES_BASES, "reads_per_launch": args.reads, "avg_launch_ms": round(sieve_ms, 4),
                 "achieved_at_188B_per_read": round(args.reads * ALG_BYTES_SURVEY / (sieve_ms * 1e-3) / 1e9, 1) if sieve_ms > 0 else 0.0,
                 "dominant_by_time": dom}
+    # the same kernel with the GPU to itself (the strictly serial steps before the timed region): in the timed region
+    # the kernels of up to `depth` steps share the GPU, which lengthens each launch
+    iso_ms = isolated["sieve"][0] / max(1, isolated["sieve"][1])
+    if iso_ms > 0:
+        roofline["avg_launch_ms_isolated"] = round(iso_ms, 4)
+        roofline["achieved_isolated"] = round(args.reads * ALG_BYTES_BASES / (iso_ms * 1e-3) / 1e9, 1)
+        roofline["frac_isolated"] = round(roofline["achieved_isolated"] / HBM_PEAK_GBS, 4)
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, all host cores
     cpu = None
@@ -357,6 +368,7 @@ def main():
                       "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (wpr * 4, qstride)},
            "roofline": roofline, "cpu_baseline": cpu, "concordance": conc,
            "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
+           "kernel_ms_per_launch_isolated": {k: round(v[0] / max(1, v[1]), 4) for k, v in isolated.items()},
            "host_ms_per_step": {k: round(v / args.steps, 4) for k, v in host_ms.items()},
            "serial_ms_per_step": round(serial_ms, 4),
            "counters": {"records": int(stats.counters[0]), "ignored": int(stats.counters[1]), "candidates": int(stats.counters[3]),
