@@ -320,7 +320,7 @@ def main():
     # ---- CPU baseline: the oracle on a bounded sample of the same workload, all host cores
     cpu = None
     conc = {"st_called": st_call.get("ecoli"), "st_planted": true_st, "st_match": st_call.get("ecoli") == true_st}
-    if args.cpu_seconds > 0:
+    if args.cpu_seconds > 0 and world == 1:      # the CPU baseline is timed at N=1 only
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         cores = os.cpu_count() or 1

@@ -86,8 +86,9 @@ def main():
         t0 = time.perf_counter()
         eng.reset_sample()
         eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), n_total, wpr, qstride)
-        st = eng.stats()
-        res = type_sample(idx, st, eng.pileup, database, "meta", fast=True, cache=cache)
+        eng.typing_enqueue(penalty=100)                 # allele choice + pileup + consensus queued behind pass 1
+        st, chosen_dev, letters_dev = eng.typing_fetch()
+        res = type_sample(idx, st, None, database, "meta", fast=True, cache=cache, typed=(chosen_dev, letters_dev))
         calls = {}
         for r in res:
             if r.written:
