@@ -117,6 +117,7 @@ struct Counters {
     // sit in separate 128-byte lines.
     u64 ext_q[EXT_Q][16];
     u64 err;             // bit0 retained overflow, bit1 item overflow, bit2 result overflow, bit3 dp overflow
+    u64 sv_t0n, sv_t1;   // sieve execution window in wall-clock ticks: max over workgroups of ~start and of end (profiling)
     u64 cnt[MLST_CNT_N];
 };
 // item_state bits
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
                                                 const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ gbm, u32 gbm_bits,
                                                 u32* __restrict__ cand, Counters* __restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) u32 s_rows[256 * WPR];
+    if (threadIdx.x == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());      // execution window (excludes queueing behind other streams)
     const u32 sshift = (u32)__clz((int)smask);       // buckets = smask + 1 = 2^(32 - sshift)
     constexpr int NT = WPR - 1;                 // seed slots
     constexpr int NV = (64 * WPR + 255) / 256;  // 16-byte vectors staged per thread
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, c
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
 }
 
 // Sieve with an LDS-resident first level.  One 1024-thread workgroup per CU keeps two 2^19-bit bitmaps in LDS (128 KiB),
@@ -416,6 +419,7 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u64* const queue = reinterpret_cast<u64*>(s_all) + wave * SV_CAP;
     u32* const hitw = s_all + Q_WORDS + wave * 2;
+    if (tid == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());      // execution window (excludes queueing behind other streams)
     {   // 32768 words, 16-byte vectors
         const v4u* g4 = reinterpret_cast<const v4u*>(bitmap); v4u* s4 = reinterpret_cast<v4u*>(s_bm);
         #pragma unroll
@@ -537,6 +541,8 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
         sv_check(Ps, sieve, smask, hitw);
     }
     sv_emit(hitw, cand, ctr, last_tile * 1024 + tid, lane);
+    __syncthreads();
+    if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
 }
 
 // ------------------------------------------------------------------ wave helpers
@@ -1733,6 +1739,7 @@ struct mlst_handle {
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool;
     double k_ms[8] = {0}; u64 k_n[8] = {0};
+    double wall_khz = 100000.0;                  // wall_clock64 rate (hipDeviceAttributeWallClockRate)
 };
 
 static std::string g_create_err;
@@ -1794,6 +1801,7 @@ extern "C" int mlst_create(int device, const mlst_params* p, mlst_handle** out) 
     h->device = device; h->prm = prm;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, MLST_E_HIP, "cannot initialise device %d", device); }
     h->own_stream = h->stream;
+    { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) h->wall_khz = (double)khz; }
     KParams& k = h->kp;
     k.minscore = prm.minscore; k.max_xm = prm.max_xm; k.min_read_len = prm.min_read_len; k.minqual = prm.minqual;
     k.match_bonus = prm.match_bonus; k.n_penalty = prm.n_penalty;
@@ -2274,6 +2282,12 @@ static int fetch_stats(mlst_handle* h, Counters** c_out) {
     return MLST_OK;
 }
 static int check_overflow(mlst_handle* h) { return fetch_stats(h, nullptr); }
+// in-kernel execution window of the sample's sieve launch (one submission per sample), slot 7 of the kernel times
+static void note_sieve_window(mlst_handle* h, const Counters* c) {
+    if (!h->profiling || !c->sv_t1 || !c->sv_t0n) return;
+    const u64 t0 = ~c->sv_t0n;
+    if (c->sv_t1 > t0) { h->k_ms[7] += (double)(c->sv_t1 - t0) / h->wall_khz; h->k_n[7]++; }
+}
 
 extern "C" int mlst_get_allele_stats(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_len,
                                      uint64_t* locus_first, uint64_t* counters) {
@@ -2281,6 +2295,7 @@ extern "C" int mlst_get_allele_stats(mlst_handle* h, int64_t* sum_score, uint32_
     hipSetDevice(h->device);
     Counters* c = nullptr;
     int rc = fetch_stats(h, &c); if (rc) return rc;
+    note_sieve_window(h, c);
     if (sum_score) memcpy(sum_score, h->h_stats + h->off_sum, (u64)h->n_alleles * 8);
     if (n_hits) memcpy(n_hits, h->h_stats + h->off_hits, (u64)h->n_alleles * 4);
     if (locus_len) memcpy(locus_len, h->h_stats + h->off_len, (u64)h->n_loci * 8);
@@ -2496,6 +2511,7 @@ extern "C" int mlst_typing_fetch(mlst_handle* h, int64_t* sum_score, uint32_t* n
     if (n_hits) memcpy(n_hits, h->h_stats + h->off_hits, (u64)h->n_alleles * 4);
     if (locus_len) memcpy(locus_len, h->h_stats + h->off_len, nl * 8);
     if (locus_first) memcpy(locus_first, h->h_stats + h->off_first, nl * 8);
+    note_sieve_window(h, c);
     if (counters) { for (int i = 0; i < MLST_CNT_N; i++) counters[i] = c->cnt[i]; counters[MLST_CNT_RETAINED] = c->n_ret; counters[MLST_CNT_ITEMS] = c->n_items; }
     if (chosen) memcpy(chosen, h->h_auto, nl * 4);
     if (letters) memcpy(letters, h->h_auto + ((nl * 4 + 15) & ~15ull), h->fixed_cols);
