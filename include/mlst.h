@@ -167,6 +167,21 @@ int mlst_consensus(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n
 int mlst_consensus_from_counts_device(mlst_handle* h, const uint32_t* d_counts, uint64_t n_cols, uint32_t mincov,
                                       char none_char, uint8_t* out_seq);
 
+/* Pass 2 for ready-made alignments (a SAM / BAM produced by the documented bowtie2 command):
+ * counts as mlst_pileup, over the records given.  Replaces the cmseq / pysam pileup of the BAM
+ * (metaMLST_functions.py:255-259 [cmseq NOT IN TREE]): a base counts when its record's AS >= minscore and
+ * XM <= max_xm (true tags), its Phred >= minqual and it is A/C/G/T; secondary records count (stepper 'nofilter').
+ *   rec_allele  : allele index of the record's contig      rec_pos0 : leftmost reference position, 0-based
+ *   cigar       : len << 4 | op with the BAM operation codes (M I D N S H P = X), cigar_off[n_rec+1] delimits records
+ *   seq / qual  : ASCII bases and raw Phred (not +33), seq_off[n_rec+1] delimits records (SEQ as stored in SAM,
+ *                 i.e. already on the reference strand)
+ *   counts      : host, sum(len(chosen)) * 4 uint32. */
+int mlst_pileup_alignments(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n_chosen, uint64_t n_rec,
+                           const uint32_t* rec_allele, const int32_t* rec_pos0, const int32_t* rec_as, const int32_t* rec_xm,
+                           const uint64_t* cigar_off, const uint32_t* cigar, const uint64_t* seq_off,
+                           const uint8_t* seq, const uint8_t* qual, int32_t minscore, int32_t max_xm, int32_t minqual,
+                           uint32_t* counts);
+
 /* ---- whole typing tail on the device, without a host round trip between the passes ----------------------
  * mlst_typing_enqueue queues, behind the pass-1 work already submitted on the engine's stream:
  *   the allele choice of metamlst.py:133-151 + :244 (per locus the allele with the highest

@@ -25,7 +25,10 @@ from .typing import TypingArgs, log_table, sample_name, type_sample
 
 def _type_parser(sub):
     p = sub.add_parser("type", help="reconstruct the MLST loci of one sample from its reads (counterpart of metamlst.py)")
-    p.add_argument("READS", help="FASTQ file (plain or .gz)")
+    p.add_argument("READS", help="FASTQ file (plain or .gz); with --alignments: a SAM (plain or .gz) or BAM file")
+    p.add_argument("--alignments", action="store_true",
+                   help="READS is a SAM / BAM made by `bowtie2 --very-sensitive-local -a --no-unal` against the database's "
+                        "alleles (the reference's own input): hit accumulation as metamlst.py:101-130, pileup on the GPU")
     p.add_argument("-2", dest="mates", help="second FASTQ of a paired-end sample")
     p.add_argument("-o", metavar="OUTPUT FOLDER", default="./out")
     p.add_argument("-d", "--database", metavar="DB PATH", required=True)
@@ -100,21 +103,28 @@ def run_type(a) -> int:
     prm.minscore, prm.max_xm, prm.min_read_len = a.minscore, a.max_xM, a.min_read_len
     eng = Engine(a.device, prm)
     eng.load_reference(idx)
+    targs = TypingArgs(penalty=a.penalty, minscore=a.minscore, max_xM=a.max_xM, min_read_len=a.min_read_len,
+                       min_accuracy=a.min_accuracy, nloci=a.nloci, a=a.a, quiet=a.quiet, filter=a.filter, log=a.log)
+    if a.alignments:
+        from .samin import AlignmentSample
+        smp = AlignmentSample(idx, targs).add_file(a.READS)
+        return _finish_type(a, idx, database, targs, smp.stats(), lambda chosen: smp.pileup(eng, chosen))
     # FASTQ text goes to the GPU as is and is parsed there (mlst_submit_fastq).  Mates are unpaired reads for this
     # pipeline (bowtie2 -U), so a second file is simply submitted after the first.
     for path in [a.READS] + ([a.mates] if a.mates else []):
         for chunk in text_chunks(path):
             eng.submit_fastq(chunk, paired=False)
-    st = eng.stats()
-    targs = TypingArgs(penalty=a.penalty, minscore=a.minscore, max_xM=a.max_xM, min_read_len=a.min_read_len,
-                       min_accuracy=a.min_accuracy, nloci=a.nloci, a=a.a, quiet=a.quiet, filter=a.filter, log=a.log)
+    return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)
+
+
+def _finish_type(a, idx, database, targs, st, pileup_fn) -> int:
     fileName = sample_name(a.READS)
     if not os.path.isdir(a.o):
         os.mkdir(a.o)
     if a.log:   # metamlst.py:159-172
         with open(a.o + "/" + fileName + "_" + str(int(time.time())) + ".out", "w", newline="") as f:
             f.write(log_table(idx, st, targs, a.READS))
-    results = type_sample(idx, st, eng.pileup, database, fileName, targs, out_dir=a.o)
+    results = type_sample(idx, st, pileup_fn, database, fileName, targs, out_dir=a.o)
     if not a.quiet:
         for r in results:
             print(" %-18s Detected Loci: %s" % (r.species, ", ".join(r.detected)))

@@ -1598,6 +1598,41 @@ __global__ __launch_bounds__(256) void k_consensus(const u32* __restrict__ count
     }
 }
 
+// ------------------------------------------------------------------ pileup of ready-made alignments (SAM / BAM input)
+// One thread per record: CIGAR walk over the chosen contig's columns.  A base counts when the record's true tags pass
+// AS >= minscore and XM <= max_xm (cmseq BAM_tagFilter), its Phred is >= minqual and it is A/C/G/T
+// (metaMLST_functions.py:255-259 -> cmseq get_base_stats [NOT IN TREE]; policy constants as in k_pileup).
+__global__ __launch_bounds__(256) void k_pileup_aln(u64 n_rec, const u32* __restrict__ rec_allele, const int* __restrict__ rec_pos,
+                                                    const int* __restrict__ rec_as, const int* __restrict__ rec_xm,
+                                                    const u64* __restrict__ cig_off, const u32* __restrict__ cig,
+                                                    const u64* __restrict__ seq_off, const u8* __restrict__ seq, const u8* __restrict__ qual,
+                                                    const int* __restrict__ allele_slot /* n_alleles: column base or -1 */,
+                                                    const u64* __restrict__ aoff, int minscore, int max_xm, int minqual,
+                                                    u32* __restrict__ counts) {
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < n_rec; k += (u64)gridDim.x * blockDim.x) {
+        const u32 a = rec_allele[k];
+        const int base = allele_slot[a];
+        if (base < 0 || rec_as[k] < minscore || rec_xm[k] > max_xm) continue;
+        const long long alen = (long long)(aoff[a + 1] - aoff[a]);
+        const u64 s0 = seq_off[k], sn = seq_off[k + 1] - s0;
+        long long r = rec_pos[k]; u64 q = 0;
+        for (u64 c = cig_off[k]; c < cig_off[k + 1]; c++) {
+            const u32 ln = cig[c] >> 4, op = cig[c] & 15u;
+            if (op == 0 || op == 7 || op == 8) {                       // M = X
+                for (u32 t = 0; t < ln && q + t < sn; t++) {
+                    const u8 ch = seq[s0 + q + t] & 0xDF;              // upper case
+                    const int b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1;
+                    const long long col = r + t;
+                    if (b >= 0 && (int)qual[s0 + q + t] >= minqual && col >= 0 && col < alen)
+                        atomicAdd(&counts[((u64)base + (u64)col) * 4 + b], 1u);
+                }
+                r += ln; q += ln;
+            } else if (op == 1 || op == 4) q += ln;                    // I S
+            else if (op == 2 || op == 3) r += ln;                      // D N
+        }
+    }
+}
+
 // ------------------------------------------------------------------ allele choice on the device (metamlst.py:133-151, 244)
 // Python's round(float(p) / float(q), 1) as an exact integer number of tenths.  round() of a float is the correctly
 // rounded decimal of the binary double (ties of the DOUBLE go to the even digit).  The double d = fl(p/q) lies within
@@ -2420,6 +2455,45 @@ extern "C" int mlst_consensus_from_counts_device(mlst_handle* h, const uint32_t*
     HIPCHK(h, hipMemcpyAsync(stage, d_letters, n_cols, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     memcpy(out_seq, stage, n_cols);
+    return MLST_OK;
+}
+
+extern "C" int mlst_pileup_alignments(mlst_handle* h, const uint32_t* chosen, uint32_t n_chosen, uint64_t n_rec,
+                                      const uint32_t* rec_allele, const int32_t* rec_pos0, const int32_t* rec_as, const int32_t* rec_xm,
+                                      const uint64_t* cigar_off, const uint32_t* cigar, const uint64_t* seq_off,
+                                      const uint8_t* seq, const uint8_t* qual, int32_t minscore, int32_t max_xm, int32_t minqual,
+                                      uint32_t* counts) {
+    if (!h || !h->have_ref) return fail(h, MLST_E_INVALID, "no reference loaded");
+    hipSetDevice(h->device);
+    std::vector<int> slot(h->n_alleles, -1); u64 ncols = 0;
+    for (u32 k = 0; k < n_chosen; k++) {
+        if (chosen[k] >= h->n_alleles) return fail(h, MLST_E_INVALID, "chosen allele %u out of range", chosen[k]);
+        if (slot[chosen[k]] >= 0) return fail(h, MLST_E_INVALID, "allele %u chosen twice", chosen[k]);
+        if (ncols > 0x7FFFFFFFull) return fail(h, MLST_E_LIMIT, "more than 2^31 pileup columns");
+        slot[chosen[k]] = (int)ncols; ncols += h->aoff[chosen[k] + 1] - h->aoff[chosen[k]];
+    }
+    for (u64 k = 0; k < n_rec; k++) if (rec_allele[k] >= h->n_alleles) return fail(h, MLST_E_INVALID, "record %llu: allele out of range", (unsigned long long)k);
+    const u64 n_cig = n_rec ? cigar_off[n_rec] : 0, n_seq = n_rec ? seq_off[n_rec] : 0;
+    u32 *d_ra = nullptr, *d_cig = nullptr, *d_cnt = nullptr; int *d_pos = nullptr, *d_as = nullptr, *d_xm = nullptr, *d_slot = nullptr;
+    u64 *d_co = nullptr, *d_so = nullptr; u8 *d_seq = nullptr, *d_q = nullptr;
+    auto cleanup = [&]() { hipFree(d_ra); hipFree(d_cig); hipFree(d_cnt); hipFree(d_pos); hipFree(d_as); hipFree(d_xm); hipFree(d_slot);
+                           hipFree(d_co); hipFree(d_so); hipFree(d_seq); hipFree(d_q); };
+#define UP(dst, src, n, T) do { if (dmalloc(&dst, (u64)(n)) != hipSuccess || ((n) && hipMemcpyAsync(dst, src, (u64)(n) * sizeof(T), hipMemcpyHostToDevice, h->stream) != hipSuccess)) \
+                                { cleanup(); return fail(h, MLST_E_HIP, "upload of the alignment arrays failed"); } } while (0)
+    UP(d_ra, rec_allele, n_rec, u32); UP(d_pos, rec_pos0, n_rec, int); UP(d_as, rec_as, n_rec, int); UP(d_xm, rec_xm, n_rec, int);
+    UP(d_co, cigar_off, n_rec + 1, u64); UP(d_cig, cigar, n_cig, u32); UP(d_so, seq_off, n_rec + 1, u64);
+    UP(d_seq, seq, n_seq, u8); UP(d_q, qual, n_seq, u8); UP(d_slot, slot.data(), h->n_alleles, int);
+#undef UP
+    if (dmalloc(&d_cnt, (ncols ? ncols : 1) * 4) != hipSuccess) { cleanup(); return fail(h, MLST_E_HIP, "out of device memory"); }
+    hipMemsetAsync(d_cnt, 0, (ncols ? ncols : 1) * 16, h->stream);
+    if (n_rec && ncols)
+        hipLaunchKernelGGL(k_pileup_aln, dim3(grid_for(n_rec, 256, 4096)), dim3(256), 0, h->stream, (u64)n_rec, d_ra, d_pos, d_as, d_xm, d_co, d_cig,
+                           d_so, d_seq, d_q, d_slot, h->d_aoff, (int)minscore, (int)max_xm, (int)minqual, d_cnt);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && ncols) e = hipMemcpyAsync(counts, d_cnt, ncols * 16, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(h, MLST_E_HIP, "mlst_pileup_alignments: %s", hipGetErrorString(e));
     return MLST_OK;
 }
 

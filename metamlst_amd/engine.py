@@ -96,6 +96,8 @@ def load_library(path: str | None = None):
         "mlst_pileup_device": (C.c_int, [H, u32p, C.c_uint32, u32p, C.POINTER(C.c_uint64)]),
         "mlst_consensus": (C.c_int, [H, u32p, C.c_uint32, C.c_uint32, C.c_char, u8p, u32p]),
         "mlst_consensus_from_counts_device": (C.c_int, [H, u32p, C.c_uint64, C.c_uint32, C.c_char, u8p]),
+        "mlst_pileup_alignments": (C.c_int, [H, u32p, C.c_uint32, C.c_uint64, u32p, i32p, i32p, i32p, u64p, u32p, u64p, u8p, u8p,
+                                             C.c_int32, C.c_int32, C.c_int32, u32p]),
         "mlst_typing_layout": (C.c_int, [H, u64p, C.POINTER(C.c_uint64)]),
         "mlst_typing_enqueue": (C.c_int, [H, C.c_int32, C.c_uint32, C.c_char]),
         "mlst_typing_choose_pileup": (C.c_int, [H, C.c_int32, u32p]),
@@ -204,6 +206,22 @@ class Engine:
         self._check(self.lib.mlst_get_allele_stats(self._h, _ptr(s.sum_score), _ptr(s.n_hits), _ptr(s.locus_len_sum),
                                                    _ptr(s.locus_first), _ptr(s.counters)), "mlst_get_allele_stats")
         return s
+
+    def pileup_alignments(self, chosen, rec_allele, rec_pos0, rec_as, rec_xm, cigar_off, cigar, seq_off, seq, qual,
+                          minscore: int = 80, max_xm: int = 5, minqual: int = 20) -> dict[int, np.ndarray]:
+        """Pass 2 over ready-made alignment records (metamlst_amd.samin); {allele idx: uint32[len, 4]}."""
+        ch = np.ascontiguousarray(chosen, np.uint32)
+        lens = [int(self.index.off[a + 1] - self.index.off[a]) for a in ch]
+        counts = np.zeros((max(1, sum(lens)), 4), np.uint32)
+        arr = [np.ascontiguousarray(x, t) for x, t in ((rec_allele, np.uint32), (rec_pos0, np.int32), (rec_as, np.int32), (rec_xm, np.int32),
+                                                       (cigar_off, np.uint64), (cigar, np.uint32), (seq_off, np.uint64), (seq, np.uint8), (qual, np.uint8))]
+        self._check(self.lib.mlst_pileup_alignments(self._h, _ptr(ch), len(ch), len(arr[0]), *[_ptr(x) for x in arr],
+                                                    int(minscore), int(max_xm), int(minqual), _ptr(counts)), "mlst_pileup_alignments")
+        out, at = {}, 0
+        for a, L in zip(ch, lens):
+            out[int(a)] = counts[at:at + L]
+            at += L
+        return out
 
     # ---- typing tail on the device ----
     def typing_enqueue(self, penalty: int = 100, mincov: int = 1, none_char: str = "N"):

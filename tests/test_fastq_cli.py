@@ -97,3 +97,44 @@ def test_gpu_fastq_parser_equals_host_parser():
     with pytest.raises(MlstError, match="longer than 320"):
         eng.submit_fastq(b"@a\n" + b"A" * 400 + b"\n+\n" + b"I" * 400 + b"\n")
     assert eng.submit_fastq(b"") == 0
+
+
+@pytest.mark.gpu
+def test_cli_alignment_input_sam_and_bam_end_to_end():
+    """`type --alignments` on a SAM and on the same records as BAM: reads tiled over the alleles of a known ST (perfect
+    local alignments, AS = 2 x length) plus weaker secondary records on a neighbouring allele -> the planted ST."""
+    import bam_writer
+    from metamlst_amd.cli import main
+    db, idx = fx.ecoli_small(80)
+    st_row = 9
+    want_alleles = db.profiles["ecoli"][st_row]
+    recs, refs = [], []
+    for a in range(idx.n_alleles):
+        refs.append((idx.label(a), int(idx.off[a + 1] - idx.off[a])))
+    k = 0
+    for (gene, _), alno in zip(db.loci["ecoli"], want_alleles):
+        l = idx.locus_index("ecoli", gene)
+        b = int(idx.locus_begin[l]); nos = idx.allele_no[b:b + int(idx.locus_count[l])]
+        a = b + int(np.nonzero(nos == alno)[0][0]); other = b + (int(np.nonzero(nos == alno)[0][0]) + 1) % int(idx.locus_count[l])
+        seq = idx.sequence(a)
+        for at in range(0, len(seq) - 100 + 1, 7):
+            L = min(150, len(seq) - at)
+            s = seq[at:at + L]
+            tags = ["AS:i:%d" % (2 * L), "XS:i:%d" % (2 * L - 16), "XN:i:0", "XM:i:0", "XO:i:0", "XG:i:0", "NM:i:0", "YT:Z:UU"]
+            recs.append(("q%d" % k, 0, idx.label(a), at + 1, 255, "%dM" % L, s, "I" * L, tags))
+            tags2 = ["AS:i:%d" % (2 * L - 16), "XS:i:%d" % (2 * L), "XN:i:0", "XM:i:2", "XO:i:0", "XG:i:0", "NM:i:2", "YT:Z:UU"]
+            recs.append(("q%d" % k, 256, idx.label(other), at + 1, 255, "%dM" % L, s, "I" * L, tags2))
+            k += 1
+    hdr = "@HD\tVN:1.0\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    d = tempfile.mkdtemp()
+    with open(d + "/alnS.sam", "w") as f:
+        f.write(hdr)
+        for r in recs:
+            f.write("\t".join([r[0], str(r[1]), r[2], str(r[3]), str(r[4]), r[5], "*", "0", "0", r[6], r[7]] + r[8]) + "\n")
+    bam_writer.write_bam(d + "/alnB.bam", hdr, refs, recs)
+    for name in ("alnS.sam", "alnB.bam"):
+        assert main(["type", d + "/" + name, "--alignments", "-d", db.path, "-o", d + "/out", "--quiet"]) == 0
+    assert open(d + "/out/alnS.nfo").read().replace("alnS", "X") == open(d + "/out/alnB.nfo").read().replace("alnB", "X")
+    assert main(["merge", d + "/out", "-d", db.path]) == 0
+    rep = sorted(open(d + "/out/merged/ecoli_report.txt").read().splitlines()[1:])
+    assert [r.split("\t") for r in rep] == [[str(st_row + 1), "100.0", "alnB"], [str(st_row + 1), "100.0", "alnS"]]
