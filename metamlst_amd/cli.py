@@ -7,7 +7,7 @@
 `type` takes reads instead of a bowtie2 BAM: the alignment happens on the GPU.  Everything it
 writes (<out>/<sample>.nfo, optional --log file) has the reference's format; `merge` writes
 merged/<species>_ST.txt and _report.txt.  --presorted / --debug / --version of the reference have
-no meaning here and are accepted and ignored; --outseqformat and -j/--jgroup are out of scope."""
+no meaning here and are accepted and ignored."""
 from __future__ import annotations
 
 import argparse
@@ -56,6 +56,9 @@ def _merge_parser(sub):
     p.add_argument("-z", metavar="ED", default=5, type=int)
     p.add_argument("--meta", metavar="METADATA_PATH")
     p.add_argument("--idField", default=0, type=int)
+    p.add_argument("--outseqformat", choices=["A", "A+", "B", "B+", "C", "C+"])
+    p.add_argument("-j", metavar="subjectID,diet,age...")
+    p.add_argument("--jgroup", action="store_true")
     p.add_argument("--device", default=0, type=int)
     return p
 
@@ -146,7 +149,7 @@ def run_merge(a) -> int:
     eng = Engine(a.device)
     eng.load_reference(idx)
     tables = merge_folder(a.folder, database, EngineMatcher(eng, idx), z=a.z, filter=a.filter, meta=a.meta, idField=a.idField,
-                          cache=mdb.DbCache(database.conn))
+                          cache=mdb.DbCache(database.conn), outseqformat=a.outseqformat, j=a.j, jgroup=a.jgroup)
     for sp, t in tables.items():
         print("%s: %d sample(s) typed, %d new profile(s)" % (sp, len(t["isolates"]), sum(1 for v in t["encounteredProfiles"].values() if v[2] in (1, 2))))
     return 0

@@ -7,11 +7,16 @@ merged/<species>_ST.txt and merged/<species>_report.txt.
 
 The only heavy step -- the stringDiff scan over every allele of a locus
 (metamlst-merge.py:177-181) -- is delegated to `matcher`, which in the product is the GPU
-Hamming kernel (Engine.hamming_le).  Sequence outputs (--outseqformat, MUSCLE) are out of scope.
+Hamming kernel (Engine.hamming_le).  Sequence outputs (--outseqformat A / A+ / B / B+ / C / C+, -j, --jgroup;
+metamlst-merge.py:345-494) are written by write_sequences; format A needs MUSCLE only when the sequences of a locus
+differ in length, exactly as in the reference.
 """
 from __future__ import annotations
 
+import itertools
 import os
+import shutil
+import subprocess
 
 from . import db as mdb
 
@@ -188,6 +193,7 @@ def write_species(folder: str, bacterium: str, tables: dict, meta: str | None = 
     identifiers = {}
     p1line = False
     keys = []
+    metadataJoinField = "sampleID"                                               # merge:130
     if meta:
         for line in open(meta):
             if line == "":
@@ -195,24 +201,151 @@ def write_species(folder: str, bacterium: str, tables: dict, meta: str | None = 
             if not p1line:
                 p1line = True
                 keys = [str(x).strip() for x in line.split("\t")]
+                metadataJoinField = keys[idField]
             else:
                 l = line.strip().split("\t")
                 if len(l) == len(keys):
                     identifiers[l[idField]] = dict((keys[i], l[i]) for i in range(0, len(keys)))
     with open(folder + "/merged/" + bacterium + "_report.txt", "w", newline="") as isolafil:
         isolafil.write("ST\tConfidence\t" + "\t".join(keys) + "\n")
+        STmapper: dict = {}          # merge:321: which samples (or their metadata rows) carry each ST
         for profileST, meanAccur, sampleName in isolates:
+            if profileST not in STmapper:
+                STmapper[profileST] = []
             if sampleName.endswith(".fna"):
                 sampleName = sampleName.split(".")[0]
             if sampleName in identifiers:
                 strl = [identifiers[sampleName][ky] for ky in keys]
                 isolafil.write(str(profileST) + "\t" + str(round(meanAccur, 2)) + "\t" + "\t".join(strl) + "\n")
+                STmapper[profileST].append(identifiers[sampleName])
             else:
                 isolafil.write(str(profileST) + "\t" + str(round(meanAccur, 2)) + "\t" + str(sampleName) + "\n")
+                STmapper[profileST].append({"sampleID": sampleName})
+    return STmapper, metadataJoinField
+
+
+def _fasta(records, path):
+    """Bio.SeqIO.write(records, path, "fasta") [Biopython NOT IN TREE]: '>id description', sequence in lines of 60."""
+    with open(path, "w") as f:
+        for rid, seq in records:
+            f.write(">" + rid + "\n")
+            for at in range(0, len(seq), 60):
+                f.write(seq[at:at + 60] + "\n")
+
+
+def _muscle(seqs):
+    """MuscleCommandline('muscle')(stdin=fasta) of merge:402-405; only reached when a locus has sequences of different lengths."""
+    exe = shutil.which("muscle")
+    if exe is None:
+        raise RuntimeError("the sequences of a locus differ in length: MUSCLE is needed to align them "
+                           "(metamlst-merge.py:402-403) and is not installed")
+    fa = "".join(">%s\n%s\n" % (i, q) for i, q in seqs)
+    out = subprocess.run([exe], input=fa.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+    res, name = {}, None
+    for line in out.splitlines():
+        if line.startswith(">"):
+            name = line[1:].split()[0]; res[name] = ""
+        elif name is not None:
+            res[name] += line.strip()
+    return res
+
+
+def write_sequences(folder: str, bacterium: str, tables: dict, database: mdb.metaMLST_db, outseqformat: str,
+                    STmapper: dict, metadataJoinField: str = "sampleID", j: str | None = None, jgroup: bool = False) -> None:
+    """metamlst-merge.py:345-494: merged/<sp>_sequences.fna (A, A+, B, B+) or merged/<sp>_sequences.txt (C)."""
+    oldProfiles, encounteredProfiles = tables["oldProfiles"], tables["encounteredProfiles"]
+    lastGenes, newSequences = tables["lastGenes"], tables["newSequences"]          # newSequences[gene] = [(label, seq), ...]
+    base = folder + "/merged/" + bacterium + "_sequences"
+    if outseqformat == "B":
+        _fasta(sorted(itertools.chain(*newSequences.values()), key=lambda x: x[0]), base + ".fna")
+    seqTable: dict = {}
+    preaLignTable: dict = {}
+    for row in database.cursor.execute("SELECT gene,alleleVariant,sequence FROM alleles WHERE bacterium = ? "
+                                       "ORDER BY bacterium,gene,alleleVariant", (bacterium,)):
+        preaLignTable.setdefault(row["gene"], []).append((bacterium + "_" + row["gene"] + "_" + str(row["alleleVariant"]), row["sequence"]))
+    for seqGene, seqList in newSequences.items():
+        preaLignTable.setdefault(seqGene, []).extend(seqList)
+    if outseqformat == "B+":
+        _fasta(sorted(itertools.chain(*preaLignTable.values()), key=lambda x: x[0]), base + ".fna")
+    if outseqformat == "C":                                                       # 'C+' never enters this block (merge:368)
+        with open(base + ".txt", "w", newline="") as seqfile:
+            nalign_Table = dict(itertools.chain(*preaLignTable.values()))
+            seqfile.write("ST\t" + "\t".join([str(x) for x in sorted(lastGenes.keys())]) + "\r\n")
+            for profileCode, (hits, profile) in oldProfiles.items():
+                if hits > 0 or outseqformat == "C+":
+                    seqfile.write(str(profileCode) + "\t" + "\t".join([str(nalign_Table[bacterium + "_" + gen + "_" + str(alle)])
+                                                                      for gen, alle in sorted(profile.items())]) + "\r\n")
+            for profileCode, (profile, hits, isNewProfile) in encounteredProfiles.items():
+                if isNewProfile == 3:
+                    continue
+                seqfile.write(str(profileCode) + "\t" + "\t".join([str(nalign_Table[bacterium + "_" + gen + "_" + str(alle[0])])
+                                                                  for gen, alle in sorted(profile.items())]) + "\r\n")
+    if outseqformat in ["A", "A+"]:
+        for gene, seqs in preaLignTable.items():
+            tld = []
+            for _, q in seqs:
+                if len(q) not in tld:
+                    tld.append(len(q))
+            if len(tld) > 1:
+                seqTable.update(_muscle(seqs))
+            else:
+                for i, q in seqs:
+                    seqTable[i] = str(q)
+        phyloSeq = []
+
+        def described(stSeq, profileCode, hits):
+            # merge:431-447 / :469-484: one record per sample with the -j fields, or one per ST when --jgroup
+            listofkeys = dict((k, []) for k in j.split(","))
+            descriptionString = None
+            if profileCode in STmapper:
+                prog = 0
+                for i in [x for x in STmapper[profileCode]]:
+                    if jgroup:
+                        descriptionString = "n=" + str(hits)
+                        for (kl, v) in i.items():
+                            if kl in listofkeys.keys():
+                                listofkeys[kl].append(v)
+                        descriptionString += "".join([kll + "{" + "|".join(ell) + "}" for kll, ell in listofkeys.items()])
+                    else:
+                        prog += 1
+                        descriptionString = "-".join([kll + "{" + str(ell) + "}" for kll, ell in i.items() if kll in j.split(",")])
+                        phyloSeq.append((bacterium + "_ST" + str(profileCode) + "_" + str(prog) + "_" + descriptionString, stSeq))
+            if jgroup:
+                phyloSeq.append((bacterium + "_ST" + str(profileCode) + "_" + descriptionString, stSeq))
+
+        for profileCode, (hits, profile) in oldProfiles.items():
+            stSeq = ""
+            if hits > 0:
+                for gen, alle in sorted(profile.items()):
+                    stSeq += str(seqTable[bacterium + "_" + gen + "_" + str(alle)])
+                if j:
+                    described(stSeq, profileCode, hits)
+                else:
+                    for profileInstance in STmapper[profileCode]:
+                        metadataPointer = metadataJoinField if metadataJoinField in profileInstance else "sampleID"
+                        phyloSeq.append((bacterium + "_ST" + str(profileCode) + "_" + profileInstance[metadataPointer], stSeq))
+            elif outseqformat == "A+":
+                for gen, alle in sorted(profile.items()):
+                    stSeq += str(seqTable[bacterium + "_" + gen + "_" + str(alle)])
+                phyloSeq.append(("ST_" + str(profileCode), stSeq))
+        for profileCode, (profile, hits, isNewProfile) in encounteredProfiles.items():
+            if isNewProfile == 3:
+                continue
+            stSeq = ""
+            for gen, alle in sorted(profile.items()):
+                stSeq += str(seqTable[bacterium + "_" + gen + "_" + alle[0]])
+            if j:
+                described(stSeq, profileCode, hits)
+            else:
+                for profileInstance in STmapper[profileCode]:
+                    metadataPointer = metadataJoinField if metadataJoinField in profileInstance else "sampleID"
+                    phyloSeq.append((bacterium + "_ST" + str(profileCode) + "_" + profileInstance[metadataPointer], stSeq))
+        _fasta(phyloSeq, base + ".fna")
 
 
 def merge_folder(folder: str, database: mdb.metaMLST_db, matcher, z: int | None = 5, filter: str | None = None,
-                 meta: str | None = None, idField: int = 0, cache: mdb.DbCache | None = None) -> dict:
+                 meta: str | None = None, idField: int = 0, cache: mdb.DbCache | None = None,
+                 outseqformat: str | None = None, j: str | None = None, jgroup: bool = False) -> dict:
     """The whole metamlst-merge.py run for one folder of .nfo files.  Returns {species: tables}."""
     if not os.path.isdir(folder + "/merged"):
         os.makedirs(folder + "/merged")
@@ -220,6 +353,8 @@ def merge_folder(folder: str, database: mdb.metaMLST_db, matcher, z: int | None 
     out = {}
     for bacterium, bactRecord in cel.items():
         tables = call_species(database, bacterium, bactRecord, z, matcher, cache)
-        write_species(folder, bacterium, tables, meta, idField)
+        STmapper, joinField = write_species(folder, bacterium, tables, meta, idField)
+        if outseqformat:
+            write_sequences(folder, bacterium, tables, database, outseqformat, STmapper, joinField, j, jgroup)
         out[bacterium] = tables
     return out

@@ -20,5 +20,5 @@ for it in range(10):
     eng.reset_sample(); eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), n, wpr, qs)
 eng.synchronize()
 s = eng.stats()
-t, c = eng.kernel_time('sieve')
-print(os.environ.get('MLST_LIB', 'default'), 'sieve ms/launch', round(t / c, 4), 'candidates', int(s.counters[3]))
+t, c = eng.kernel_time(os.environ.get('KERNEL', 'sieve'))
+print(os.environ.get('MLST_LIB', 'default'), os.environ.get('KERNEL', 'sieve') + ' ms/launch', round(t / c, 4), 'candidates', int(s.counters[3]))

@@ -282,12 +282,24 @@ def part_c(dbpath):
     lb = {g: (a, "", "100.0", "0.0") for g, a in pb.items()}
     lb["h1"] = (pb["h1"], seq_of(dbpath, "spB", "h1", pb["h1"])[:-12], "95.5", "0.0")                                       # truncated: zip() hides it (Q10)
     lines.append(line("spB", "s9", lb))
-    for case, z in (("case1_z5", ["-z", "5"]), ("case2_z1", ["-z", "1"]), ("case3_filter", ["--filter", "spA"])):
+    meta_text = ("sampleID\tcountry\tage\n" + "s1\tIT\t31\n" + "s2\tIT\t7\n" + "s3\tDE\t52\n" + "s4\tDE\t52\n" + "s6\tFR\t19\n"
+                 + "s7\tFR\n" + "s8\tUK\t44\n")        # s5 absent (rejected anyway), s7 malformed (dropped, merge:316)
+    for case, z in (("case1_z5", ["-z", "5"]), ("case2_z1", ["-z", "1"]), ("case3_filter", ["--filter", "spA"]),
+                    ("case4_seqB", ["--outseqformat", "B"]), ("case5_seqBplus", ["--outseqformat", "B+", "--filter", "spA"]),
+                    ("case6_seqC", ["--outseqformat", "C"]), ("case7_seqCplus", ["--outseqformat", "C+"]),
+                    ("case8_seqA_meta", ["--outseqformat", "A", "--filter", "spA", "--meta", "META"]),
+                    ("case9_seqAplus_j", ["--outseqformat", "A+", "--filter", "spA", "--meta", "META", "-j", "country,age"]),
+                    ("case10_seqA_jgroup", ["--outseqformat", "A", "--filter", "spA", "--meta", "META", "--idField", "0", "-j", "country", "--jgroup"]),
+                    ("case11_seqA_nometa", ["--outseqformat", "A", "--filter", "spA", "-z", "1"])):
         work = tempfile.mkdtemp()
         open(os.path.join(work, "all.nfo"), "w", newline="").write("".join(lines))
+        meta_dir = tempfile.mkdtemp()
+        if "META" in z:
+            open(os.path.join(meta_dir, "meta.tsv"), "w").write(meta_text)
+        z_run = [os.path.join(meta_dir, "meta.tsv") if t == "META" else t for t in z]
         env = dict(os.environ)
         env["PYTHONPATH"] = STUBS + os.pathsep + REF
-        r = subprocess.run([sys.executable, os.path.join(REF, "metamlst-merge.py"), work, "-d", dbpath] + z, env=env, cwd=work,
+        r = subprocess.run([sys.executable, os.path.join(REF, "metamlst-merge.py"), work, "-d", dbpath] + z_run, env=env, cwd=work,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         if r.returncode != 0:
             raise RuntimeError("reference metamlst-merge.py failed: " + r.stderr.decode()[-2000:])
@@ -295,8 +307,11 @@ def part_c(dbpath):
         os.makedirs(os.path.join(cd, "expected"))
         shutil.copy(os.path.join(work, "all.nfo"), os.path.join(cd, "all.nfo"))
         json.dump(z, open(os.path.join(cd, "args.json"), "w"))
-        for f in glob.glob(os.path.join(work, "merged", "*.txt")):
+        for f in glob.glob(os.path.join(work, "merged", "*")):
             shutil.copy(f, os.path.join(cd, "expected", os.path.basename(f)))
+        if "META" in z:
+            shutil.copy(os.path.join(meta_dir, "meta.tsv"), os.path.join(cd, "meta.tsv"))
+        shutil.rmtree(meta_dir)
         shutil.rmtree(work)
     conn.close()
 

@@ -4,9 +4,17 @@ from .SeqRecord import SeqRecord
 
 
 def write(records, path, fmt):
-    with open(path, "w") as f:
-        for r in records:
-            f.write(">%s\n%s\n" % (r.id, r.seq))
+    """Biopython's FastaWriter [NOT IN TREE]: title '>id description' (id alone when the description is empty), the
+    sequence wrapped at 60 columns.  `path` may be a file name or an open handle."""
+    records = list(records)
+    f = open(path, "w") if isinstance(path, str) else path
+    for r in records:
+        f.write(">%s\n" % (("%s %s" % (r.id, r.description)) if r.description else r.id))
+        s = str(r.seq)
+        for at in range(0, len(s), 60):
+            f.write(s[at:at + 60] + "\n")
+    if isinstance(path, str):
+        f.close()
     return len(records)
 
 

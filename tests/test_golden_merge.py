@@ -1,4 +1,4 @@
-"""metamlst-merge.py:93-341 pinned: the reference script was run on a folder of .nfo lines
+"""metamlst-merge.py:93-494 pinned (ST tables, reports, and the --outseqformat / -j / --jgroup sequence outputs): the reference script was run on a folder of .nfo lines
 (tests/golden/make_golden.py, part C); the package's merge must write identical files."""
 import glob
 import json
@@ -23,6 +23,8 @@ def test_reference_merged_files(case, cached):
     argv = json.load(open(os.path.join(case, "args.json")))
     z = int(argv[argv.index("-z") + 1]) if "-z" in argv else 5
     flt = argv[argv.index("--filter") + 1] if "--filter" in argv else None
+    opt = lambda name: argv[argv.index(name) + 1] if name in argv else None
+    meta = os.path.join(case, "meta.tsv") if opt("--meta") else None
     dbp = gu.golden_db()
     idx = load_index(dbp)
     orc = oracle_lib.Oracle(idx)
@@ -33,7 +35,9 @@ def test_reference_merged_files(case, cached):
     work = tempfile.mkdtemp()
     shutil.copy(os.path.join(case, "all.nfo"), work)
     database = mdb.metaMLST_db(dbp)
-    merge_folder(work, database, matcher, z=z, filter=flt, cache=mdb.DbCache(database.conn) if cached else None)
+    merge_folder(work, database, matcher, z=z, filter=flt, cache=mdb.DbCache(database.conn) if cached else None,
+                 meta=meta, idField=int(opt("--idField") or 0), outseqformat=opt("--outseqformat"), j=opt("-j"),
+                 jgroup="--jgroup" in argv)
     want = sorted(os.listdir(os.path.join(case, "expected")))
     assert sorted(os.listdir(os.path.join(work, "merged"))) == want
     for f in want:
