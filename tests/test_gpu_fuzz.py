@@ -21,8 +21,14 @@ def random_case(seed):
     n_loci = int(rng.integers(1, 5))
     loci = [("g%d" % k, int(rng.choice([40, 77, 130, 256, 401, 512, 700]))) for k in range(n_loci)]
     n_all = int(rng.integers(2, 40))
-    db = synth.make_db(d + "/f.db", {"spX": loci, "spY": loci[:1]}, alleles_per_locus=n_all, n_profiles=5, seed=seed,
-                       indel_every=int(rng.choice([0, 0, 3, 5])), max_div=float(rng.choice([0.03, 0.08])))
+    indel_every, max_div = int(rng.choice([0, 0, 3, 5])), float(rng.choice([0.03, 0.08]))
+    while True:
+        try:
+            db = synth.make_db(d + "/f.db", {"spX": loci, "spY": loci[:1]}, alleles_per_locus=n_all, n_profiles=5, seed=seed,
+                               indel_every=indel_every, max_div=max_div)
+            break
+        except RuntimeError:          # a short locus cannot hold that many distinct alleles within max_div: fewer alleles
+            n_all = max(2, n_all // 2)
     if rng.random() < 0.5:        # sprinkle ambiguity codes / truncate some alleles
         conn = sqlite3.connect(db.path)
         for rid, seq in conn.execute("SELECT recID, sequence FROM alleles").fetchall():
