@@ -985,11 +985,11 @@ __device__ inline u32 ld_row(GP<const u32>::G* row, u32 byte_off) {
 
 // NB = 32-base read blocks the instantiation supports.  TRACK = also report the aligned span [bs, be) (only the
 // gap-trigger policy needs it, and only for pairs with many mismatches).  Value-identical to ungapped<>.
-// rl/rh/od = read planes and the non-default-penalty mask, block-uniform (scalar registers); s_rn, s_pen stay in LDS
+// rl/rh/od/rn = read planes, non-default-penalty mask and N mask, block-uniform (scalar registers); s_pen stays in LDS
 // because they are needed only for reads with N / for the rare non-default penalty.
 template <int NB, bool TRACK>
 __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, const LocusDev& L, u32 a_local, int m, int n, int d,
-                                      const u32 (&rl)[NB], const u32 (&rh)[NB], const u32 (&od)[NB], const u32* s_rn, const u8* s_pen,
+                                      const u32 (&rl)[NB], const u32 (&rh)[NB], const u32 (&od)[NB], const u32 (&rn)[NB], const u8* s_pen,
                                       int pen_def, bool read_has_n, int& mm_total, int& bs, int& be) {
     const int i0 = d < 0 ? -d : 0;                             // block-uniform
     const int MA = P.match_bonus << MLST_P_SHIFT;
@@ -1003,11 +1003,13 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
     #pragma unroll
     for (int t = 0; t <= NB; t++) {
         int q = q0 + t; u32 qc = (u32)(q < 0 ? 0 : (q >= (int)L.pblocks ? (int)L.pblocks - 1 : q));
-        auto row = pbase + (u64)(qc * 2) * L.n_pad;
-        A[2 * t] = ld_row(row, aoff);
-        A[2 * t + 1] = ld_row(row + L.n_pad, aoff);
+        // one base pointer for every load + a 32-bit byte offset (scalar row offset added to the lane's): the saddr
+        // form, one 32-bit VALU add per load instead of a 64-bit one (arenas are far below 4 GB, checked at load time)
+        const u32 rowoff = qc * 2u * (L.n_pad * 4u);
+        A[2 * t] = ld_row(pbase, rowoff + aoff);
+        A[2 * t + 1] = ld_row(pbase, rowoff + L.n_pad * 4u + aoff);
         AW[t] = 0;
-        if (L.has_n) AW[t] = ld_row(nbase + (u64)qc * L.n_pad, aoff);
+        if (L.has_n) AW[t] = ld_row(nbase, qc * (L.n_pad * 4u) + aoff);
     }
     tie_all<2 * (NB + 1)>(A);
     if (L.has_n) tie_all<NB + 1>(AW);
@@ -1021,7 +1023,7 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
     for (int w = 0; w < NB; w++) {
         u32 lo = __builtin_amdgcn_alignbit(A[2 * w + 2], A[2 * w], r), hi = __builtin_amdgcn_alignbit(A[2 * w + 3], A[2 * w + 1], r);
         M[w] = (lo ^ rl[w]) | (hi ^ rh[w]);
-        if (read_has_n) M[w] |= s_rn[w];
+        M[w] |= rn[w];                                          // read N mask (zero for reads without N), scalar
         AN[w] = 0;
         if (L.has_n) { AN[w] = __builtin_amdgcn_alignbit(AW[w + 1], AW[w], r); M[w] |= AN[w]; }
         int lo_i = i0 - 32 * w; lo_i = lo_i < 0 ? 0 : (lo_i > 32 ? 32 : lo_i);            // uniform: scalar unit
@@ -1155,11 +1157,12 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
         __syncthreads();
         const bool res_ok = it.res_off + L.n_pad <= E.cap_res;      // else flagged by k_seed
         const int floor_n = E.floor_tab[n];
-        u32 rl[NB], rh[NB], od[NB];               // block-uniform read planes, held in scalar registers
+        u32 rl[NB], rh[NB], od[NB], rn[NB];       // block-uniform read planes, held in scalar registers
         #pragma unroll
         for (int w = 0; w < NB; w++) {
             rl[w] = __builtin_amdgcn_readfirstlane(s_rl[w]); rh[w] = __builtin_amdgcn_readfirstlane(s_rh[w]);
             od[w] = __builtin_amdgcn_readfirstlane(s_odd[w]);
+            rn[w] = read_has_n ? __builtin_amdgcn_readfirstlane(s_rn[w]) : 0u;
         }
         u32 nrec = 0, ndp = 0;
 #ifdef EXP_NO_ALLELES
@@ -1169,14 +1172,14 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
 #endif
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
-            int best = ungapped_planes<NB, false>(E, P, L, a, m, n, it.diag, rl, rh, od, s_rn, s_pen, pen_def, read_has_n, mm, bs, be);
+            int best = ungapped_planes<NB, false>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
 #ifdef EXP_NO_KADANE
             mm = 0;
 #endif
             int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
             bool need_dp = P.trig < 0;
             if (!need_dp && mm > P.trig && score >= floor_n) {       // rare: the policy needs the aligned span
-                ungapped_planes<NB, true>(E, P, L, a, m, n, it.diag, rl, rh, od, s_rn, s_pen, pen_def, read_has_n, mm, bs, be);
+                ungapped_planes<NB, true>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
                 need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
             }
             u32 r = pack_result(score, xm, xo);
@@ -2056,6 +2059,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     for (int q = 0; q < 256; q++) { int qq = q > 40 ? 40 : q; pen_tab[q] = (u8)(h->prm.mm_min + ((h->prm.mm_max - h->prm.mm_min) * qq) / 40); }
     // ---- upload
     HIPCHK(h, dmalloc(&h->d_arena, arena.size())); HIPCHK(h, hipMemcpy(h->d_arena, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    if (planes.size() * 4 >= (1ull << 32) || nmask.size() * 4 >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "allele bit-plane arena exceeds 4 GB (32-bit offsets in k_extend)");
     HIPCHK(h, dmalloc(&h->d_planes, planes.size())); HIPCHK(h, hipMemcpy(h->d_planes, planes.data(), planes.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_nmask, nmask.size())); HIPCHK(h, hipMemcpy(h->d_nmask, nmask.data(), nmask.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_allele_len, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_len, alen.data(), (u64)n_alleles * 2, hipMemcpyHostToDevice));
