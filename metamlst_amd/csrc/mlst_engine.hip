@@ -2,7 +2,7 @@
 //
 // Path (reference file:line in include/mlst.h and DESIGN.md):
 //   K0 k_pack        ASCII reads -> 2-bit rows + Phred rows                (FASTQ/SAM fields)
-//   K1 k_sieve       streaming seed sieve over ALL reads (HBM bound)       (bowtie2 seeding)
+//   K1 k_sieve_q     streaming seed sieve over ALL reads                   (bowtie2 seeding)
 //   K2 k_seed        exact 20-mer seeds -> (read, locus, strand, diag)     (bowtie2 seeding)
 //   K3 k_extend      ungapped XOR/popcount extension vs every allele       (bowtie2 -a extension)
 //   K4 k_banded      banded affine Smith-Waterman for indel-broken pairs   (bowtie2 gapped DP)
@@ -227,10 +227,11 @@ __global__ __launch_bounds__(256) void k_pack_lens(const u64* __restrict__ off, 
 }
 
 // ------------------------------------------------------------------ K1: seed sieve (the streaming kernel)
-// Each 256-thread block stages 256 packed read rows through LDS with coalesced 16-byte loads; each lane then
-// owns one read: a seed is the 20-mer at every 16th base = word t plus the low byte of word t+1.  A seed is
-// looked up in the sieve: 16-byte buckets of eight 16-bit fingerprints (one 16-byte load per seed).  Reads with
-// any hit are compacted into the candidate list with a wave ballot and one atomic per wave.
+// lane = read, wave = one 64-read group of the transposed layout.  A seed is the 20-mer at every 16th base = word t plus
+// the low byte of word t+1.  Two levels: a first-level bitmap test for every seed (LDS half-seed bitmaps for small
+// databases, a hashed global bitmap for big ones), then the seeds that pass, compacted per wave into an LDS queue,
+// against the sieve proper: 16-byte buckets of eight 16-bit fingerprints of the canonical seed (one 16-byte load per
+// queue entry).  Reads with any hit go to the candidate list with one atomic per wave.
 __device__ inline bool bucket_has(uint4 b, u32 fp, bool& full) {
     u32 pat = fp * 0x00010001u;
     u32 x0 = b.x ^ pat, x1 = b.y ^ pat, x2 = b.z ^ pat, x3 = b.w ^ pat;
@@ -238,106 +239,6 @@ __device__ inline bool bucket_has(uint4 b, u32 fp, bool& full) {
     u32 z = ((x0 - 0x00010001u) & ~x0) | ((x1 - 0x00010001u) & ~x1) | ((x2 - 0x00010001u) & ~x2) | ((x3 - 0x00010001u) & ~x3);
     full = (b.w >> 16) != 0;        // slots are filled in order: the bucket is full iff its last slot is occupied
     return (z & 0x80008000u) != 0;
-}
-
-// WPR = words per packed row (even).  A row of WPR words holds at most WPR-1 seeds (seed t = word t + low byte of
-// word t+1).  All WPR-1 bucket loads are issued before any is examined (branchless: seeds beyond the read's length
-// probe a harmless bucket and are masked), so a lane has WPR-1 independent 16-byte loads in flight.
-template <int WPR>
-__global__ __launch_bounds__(256) void k_sieve(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
-                                                const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ gbm, u32 gbm_bits,
-                                                u32* __restrict__ cand, Counters* __restrict__ ctr) {
-    __shared__ __attribute__((aligned(16))) u32 s_rows[256 * WPR];
-    if (threadIdx.x == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());      // execution window (excludes queueing behind other streams)
-    const u32 sshift = (u32)__clz((int)smask);       // buckets = smask + 1 = 2^(32 - sshift)
-    constexpr int NT = WPR - 1;                 // seed slots
-    constexpr int NV = (64 * WPR + 255) / 256;  // 16-byte vectors staged per thread
-    const int tid = threadIdx.x;
-    u64 n_blocks = (n_reads + 255) / 256;
-    for (u64 blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        u64 r0 = blk * 256;
-        u32 nr = (u32)((n_reads - r0) < 256 ? (n_reads - r0) : 256);
-        // stage rows through LDS: a full tile is 64*WPR 16-byte vectors, loaded coalesced and non-temporal
-        // (r0*WPR*4 is 16-byte aligned because r0 % 256 == 0); the last, partial tile takes the scalar path
-        u32 n = (u32)tid < nr ? (u32)(lens[r0 + tid] & 0x7FFFu) : 0u;
-        if (nr == 256) {
-            const v4u* g4 = reinterpret_cast<const v4u*>(packed + r0 * WPR);
-            v4u* s4 = reinterpret_cast<v4u*>(s_rows);
-            v4u stg[NV];
-            #pragma unroll
-            for (int k = 0; k < NV; k++) { u32 v = tid + 256 * k; if (v < 64u * WPR) stg[k] = __builtin_nontemporal_load(g4 + v); }
-            #pragma unroll
-            for (int k = 0; k < NV; k++) { u32 v = tid + 256 * k; if (v < 64u * WPR) s4[v] = stg[k]; }
-        } else {      // last tile: whole groups of 64 rows (the buffer is padded to a full group)
-            const u32* g = packed + r0 * WPR; const u32 lim = ((nr + 63u) & ~63u) * WPR;
-            for (u32 i = tid; i < 256u * WPR; i += 256) s_rows[i] = i < lim ? g[i] : 0u;
-        }
-        __syncthreads();
-        bool hit = false;
-        {
-            int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-            const uint2* row = reinterpret_cast<const uint2*>(s_rows) + (u32)(tid >> 6) * 32 * WPR + (tid & 63);   // group-transposed rows
-            u32 w[WPR];
-            #pragma unroll
-            for (int t2 = 0; t2 < WPR / 2; t2++) { uint2 x = row[t2 * 64]; w[2 * t2] = x.x; w[2 * t2 + 1] = x.y; }
-            // canonical seed keys, then every probe issued before examining any (see tie_all)
-            u32 klo[NT], khi[NT];
-            #pragma unroll
-            for (int t = 0; t < NT; t++) { u32 fl; u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl); klo[t] = (u32)c; khi[t] = (u32)(c >> 32); }
-            // optional first level for big databases: a bitmap in global memory that mostly lives in L2, so that
-            // only seeds whose bit is set go to the (much larger, Infinity-Cache resident) fingerprint sieve
-            u32 pass = nseeds >= 32 ? 0xFFFFFFFFu : ((1u << nseeds) - 1u);
-            if (gbm) {
-                u32 gw[NT], gi[NT];
-                #pragma unroll
-                for (int t = 0; t < NT; t++) { gi[t] = bitmap_hash_bits(klo[t], khi[t], gbm_bits); gw[t] = gbm[gi[t] >> 5]; }
-                tie_all<NT>(gw);
-                #pragma unroll
-                for (int t = 0; t < NT; t++) if (!((gw[t] >> (gi[t] & 31)) & 1u)) pass &= ~(1u << t);
-            }
-            v4u bv[NT];
-            #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                bv[t] = v4u{0u, 0u, 0u, 0u};
-                if ((pass >> t) & 1u) bv[t] = reinterpret_cast<const v4u*>(sieve)[sieve_bucket_hash(klo[t], khi[t]) >> sshift];
-            }
-            tie_all<NT>(bv);
-            uint4 b[NT];
-            #pragma unroll
-            for (int t = 0; t < NT; t++) b[t] = make_uint4(bv[t].x, bv[t].y, bv[t].z, bv[t].w);
-            u32 pending = 0;          // seeds whose first bucket was full without a match (rare)
-            #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                bool full; bool f = bucket_has(b[t], sieve_fp(klo[t], khi[t]), full);
-                bool valid = (pass >> t) & 1u;
-                hit |= valid && f;
-                pending |= (valid && !f && full) ? (1u << t) : 0u;
-            }
-            while (pending && !hit) {   // overflow chain: the key may sit in a following bucket
-                int t = __ffs(pending) - 1; pending &= pending - 1;
-                const u32 w0 = s_rows[packed_index((u32)tid, WPR, (u32)t)], w1 = s_rows[packed_index((u32)tid, WPR, (u32)t + 1)];
-                u32 fl; u64 c = canon40((u64)w0 | ((u64)(w1 & 0xFFu) << 32), fl);
-                u32 lo = (u32)c, hi = (u32)(c >> 32); u32 fp = sieve_fp(lo, hi);
-                u32 bi = sieve_bucket_hash(lo, hi) >> sshift;
-                for (int step = 0; step < 64; step++) {
-                    bi = (bi + 1) & smask; bool full; uint4 bb = sieve[bi];
-                    if (bucket_has(bb, fp, full)) { hit = true; break; }
-                    if (!full) break;
-                }
-            }
-        }
-        u64 mask = __ballot(hit);
-        if (mask) {
-            int lane = tid & 63;
-            int leader = __ffsll((long long)mask) - 1;
-            u64 base = 0;
-            if (lane == leader) base = atomicAdd(&ctr->n_cand, (u64)__popcll(mask));
-            base = __shfl(base, leader);
-            if (hit) cand[base + __popcll(mask & ((1ull << lane) - 1))] = (u32)(r0 + tid);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
 }
 
 // Sieve with an LDS-resident first level.  One 1024-thread workgroup per CU keeps two 2^19-bit bitmaps in LDS (128 KiB),
@@ -406,13 +307,20 @@ __device__ inline void sv_emit(u32* hitw, u32* __restrict__ cand, Counters* __re
         if ((mask >> lane) & 1ull) cand[base + __popcll(mask & ((1ull << lane) - 1))] = (u32)r;
     }
 }
-template <int WPR>
-__global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
-                                                     const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ bitmap,
-                                                     u32* __restrict__ cand, Counters* __restrict__ ctr) {
-    // one LDS block, queue first so that its addresses fit the DS offset field: [queues 16 x SV_CAP x 8 B][hit masks][bitmap]
-    constexpr u32 Q_WORDS = 16 * SV_CAP * 2, H_WORDS = 32, BM_OFF = Q_WORDS + H_WORDS;
-    __shared__ __attribute__((aligned(16))) u32 s_all[BM_OFF + (1u << BITMAP_BITS) / 32];
+// LDSBM = true : the first level is the pair of half-seed bitmaps in LDS (small databases), 16 waves per workgroup.
+// LDSBM = false: big databases, whose half seeds saturate any LDS-sized bitmap: the first level is a hashed bitmap of
+//   the canonical seed in global memory (2^gbm_bits bits, mostly L2 resident); 4 waves per workgroup, several
+//   workgroups per CU; three bucket requests stay in flight (a third of the seeds pass this level).
+template <int WPR, bool LDSBM>
+__global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
+                                                               const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ bitmap,
+                                                               u32 gbm_bits, u32* __restrict__ cand, Counters* __restrict__ ctr) {
+    constexpr int NW = LDSBM ? 16 : 4;                 // waves per workgroup; a tile = NW groups of 64 reads
+    constexpr int NP = LDSBM ? 2 : 3;                  // bucket requests kept in flight across the first level
+    constexpr u32 TILE = NW * 64;
+    // one LDS block, queue first so that its addresses fit the DS offset field: [queues NW x SV_CAP x 8 B][hit masks][bitmap]
+    constexpr u32 Q_WORDS = NW * SV_CAP * 2, H_WORDS = 2 * NW, BM_OFF = Q_WORDS + H_WORDS;
+    __shared__ __attribute__((aligned(16))) u32 s_all[BM_OFF + (LDSBM ? (1u << BITMAP_BITS) / 32 : 4)];
     u32* const s_bm = s_all + BM_OFF;
     const u32 sshift = (u32)__clz((int)smask);       // buckets = smask + 1 = 2^(32 - sshift)
     constexpr int NT = WPR - 1;
@@ -420,29 +328,29 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
     u64* const queue = reinterpret_cast<u64*>(s_all) + wave * SV_CAP;
     u32* const hitw = s_all + Q_WORDS + wave * 2;
     if (tid == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());      // execution window (excludes queueing behind other streams)
-    {   // 32768 words, 16-byte vectors
+    if (LDSBM) {   // 32768 words, 16-byte vectors
         const v4u* g4 = reinterpret_cast<const v4u*>(bitmap); v4u* s4 = reinterpret_cast<v4u*>(s_bm);
         #pragma unroll
         for (int k = 0; k < 8; k++) s4[tid + 1024 * k] = g4[tid + 1024 * k];
-        if (tid < (int)H_WORDS) s_all[Q_WORDS + tid] = 0;
     }
+    if (tid < (int)H_WORDS) s_all[Q_WORDS + tid] = 0;
     __syncthreads();
-    const u64 n_tiles = (n_reads + 1023) / 1024;
+    const u64 n_tiles = (n_reads + TILE - 1) / TILE;
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     v2u xn[WPR / 2]; u16 len_raw = 0; bool live_next = false;
     const u64 n_groups = (n_reads + 63) >> 6;      // the wave's 64 lanes own one group of the transposed layout
     {
-        u64 r = (u64)blockIdx.x * 1024 + tid; u64 grp = (u64)blockIdx.x * 16 + wave;
+        u64 r = (u64)blockIdx.x * TILE + tid; u64 grp = (u64)blockIdx.x * NW + wave;
         live_next = blockIdx.x < n_tiles && r < n_reads;
         const v2u* row = reinterpret_cast<const v2u*>(packed) + (grp < n_groups ? grp : 0) * (32 * WPR) + lane;
         #pragma unroll
         for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
         len_raw = lens[live_next ? r : 0];
     }
-    // Order inside an iteration (tile k): request the rows of tile k+1, request the sieve buckets of the seeds queued by
-    // tile k-1, run the first level of tile k (pure VALU + LDS, which hides both latencies), examine the buckets and emit
-    // the candidates of tile k-1, queue the passing seeds of tile k.  The only wait for global memory is in front of
-    // the bucket examination, so nothing that was requested recently is ever waited for.
+    // Order inside an iteration (tile k): request the sieve buckets of the seeds queued by tile k-1, request the rows of
+    // tile k+1, run the first level of tile k (which hides both latencies), examine the buckets and emit the candidates
+    // of tile k-1, queue the passing seeds of tile k.  The only wait for the buckets sits behind the first level, and
+    // the row requests are younger than the bucket requests, so waiting for the buckets leaves them in flight.
     u32 qcnt = 0;                 // seeds queued by the previous tile (entries 0..qcnt-1 of the wave's queue)
     u64 last_tile = blockIdx.x;
     for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -458,55 +366,74 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
         asm volatile("v_mov_b32 %0, %1" : "=v"(len_cur) : "v"((u32)len_raw));
         const u32 n = live_cur ? (len_cur & 0x7FFFu) : 0u;
         const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-        // ---- buckets of the previous tile's queue: two requests stay in flight across the first level; a queue longer
-        // than 128 entries (rare) is examined on the spot
+        // ---- buckets of the previous tile's queue: NP requests stay in flight across the first level (a request is
+        // made only when the queue reaches it: wave-uniform); a longer queue is examined on the spot
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        SvProbe PA, PB;
-        sv_issue(PA, queue, (u32)lane, qcnt, sieve, sshift);
-        const bool two = qcnt > 64;              // wave-uniform: a second request only for a queue of more than 64 seeds
-        if (two) sv_issue(PB, queue, 64u + (u32)lane, qcnt, sieve, sshift);
-        else { PB.act = false; PB.bv = v4u{0u, 0u, 0u, 0u}; PB.fp = 1u; PB.bi = 0u; PB.src = 0u; }
-        for (u32 base = 128; base < qcnt; base += 64) {
+        SvProbe PR[NP];
+        #pragma unroll
+        for (int j = 0; j < NP; j++) {
+            if (j == 0 || qcnt > 64u * j) sv_issue(PR[j], queue, 64u * j + (u32)lane, qcnt, sieve, sshift);
+            else { PR[j].act = false; PR[j].bv = v4u{0u, 0u, 0u, 0u}; PR[j].fp = 1u; PR[j].bi = 0u; PR[j].src = 0u; }
+        }
+        for (u32 base = 64u * NP; base < qcnt; base += 64) {
             SvProbe Ps; sv_issue(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
             sv_check(Ps, sieve, smask, hitw);
         }
         asm volatile("" ::: "memory");      // the bucket requests are older than the row requests below: waiting for them leaves the rows in flight
         {   // rows of the next tile.  The memory clobber keeps the compiler from sinking the loads towards their first use.
-            u64 tn = tile + gridDim.x; u64 rn = tn * 1024 + tid;
+            u64 tn = tile + gridDim.x; u64 rn = tn * TILE + tid;
             live_next = tn < n_tiles && rn < n_reads;
-            const u64 gn = tn * 16 + wave;
+            const u64 gn = tn * NW + wave;
             const v2u* row = reinterpret_cast<const v2u*>(packed) + (gn < n_groups ? gn : 0) * (32 * WPR) + lane;
             #pragma unroll
             for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
             len_raw = lens[live_next ? rn : 0];
             asm volatile("" ::: "memory");
         }
-        // ---- first level: per word the bit-reversed swapped complement (rb[i] base p = complement of w[i] base 15-p),
-        // per seed the two halves, the pick and one LDS bit
-        u32 rb[WPR];
-        #pragma unroll
-        for (int i = 0; i < WPR; i++) {
-            u32 x = w[i];
-            rb[i] = __brev(~(((x >> 1) & 0x55555555u) | ((x + x) & 0xAAAAAAAAu)));
-        }
         const bool all_full = __all(nseeds >= NT) != 0;
-        u64 pm[NT];
-        #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const u32 A = w[t] & 0xFFFFFu, B = __builtin_amdgcn_alignbit(w[t + 1], w[t], 20) & 0xFFFFFu;
-            const u32 rcB = __builtin_amdgcn_alignbit(rb[t], rb[t + 1], 24) & 0xFFFFFu, rcA = rb[t] >> 12;
-            const bool flip = sieve_half_flip(A, rcB);
-            const u32 L = (flip ? rcB : A) & (SV_HALF_BITS - 1u), R = (flip ? rcA : B) & (SV_HALF_BITS - 1u);
-            const u32 wl = s_bm[L >> 5], wr = s_bm[SV_HALF_BITS / 32 + (R >> 5)];
-            pm[t] = __ballot((((wl >> (L & 31)) & (wr >> (R & 31))) & 1u) != 0);
+        u64 pm[NT]; u32 elo[NT], ehi[NT];            // pass masks; the queue entry of every seed (40 key bits)
+        if (LDSBM) {
+            // ---- first level in LDS: per word the bit-reversed swapped complement (rb[i] base p = complement of w[i]
+            // base 15-p), per seed the two halves, the pick and two LDS bits.  Entry = the seed as it stands.
+            u32 rb[WPR];
+            #pragma unroll
+            for (int i = 0; i < WPR; i++) {
+                u32 x = w[i];
+                rb[i] = __brev(~(((x >> 1) & 0x55555555u) | ((x + x) & 0xAAAAAAAAu)));
+            }
+            #pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const u32 A = w[t] & 0xFFFFFu, B = __builtin_amdgcn_alignbit(w[t + 1], w[t], 20) & 0xFFFFFu;
+                const u32 rcB = __builtin_amdgcn_alignbit(rb[t], rb[t + 1], 24) & 0xFFFFFu, rcA = rb[t] >> 12;
+                const bool flip = sieve_half_flip(A, rcB);
+                const u32 L = (flip ? rcB : A) & (SV_HALF_BITS - 1u), R = (flip ? rcA : B) & (SV_HALF_BITS - 1u);
+                const u32 wl = s_bm[L >> 5], wr = s_bm[SV_HALF_BITS / 32 + (R >> 5)];
+                pm[t] = __ballot((((wl >> (L & 31)) & (wr >> (R & 31))) & 1u) != 0);
+                elo[t] = w[t]; ehi[t] = w[t + 1] & 0xFFu;
+            }
+        } else {
+            // ---- first level in global memory: canonical keys, then every bitmap word requested before any is looked
+            // at.  Entry = the canonical key (canon40 is idempotent, so sv_issue treats it like any seed).
+            u32 gi[NT], gw[NT];
+            #pragma unroll
+            for (int t = 0; t < NT; t++) {
+                u32 fl; const u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl);
+                elo[t] = (u32)c; ehi[t] = (u32)(c >> 32);
+                gi[t] = bitmap ? bitmap_hash_bits(elo[t], ehi[t], gbm_bits) : 0u;
+                gw[t] = bitmap ? bitmap[gi[t] >> 5] : 0xFFFFFFFFu;
+            }
+            tie_all<NT>(gw);
+            #pragma unroll
+            for (int t = 0; t < NT; t++) pm[t] = __ballot(((gw[t] >> (gi[t] & 31)) & 1u) != 0);
         }
         if (!all_full) {
             #pragma unroll
             for (int t = 0; t < NT; t++) pm[t] &= __ballot(t < nseeds);
         }
         // ---- examine the buckets requested above; candidates of the previous tile
-        sv_check(PA, sieve, smask, hitw); if (two) sv_check(PB, sieve, smask, hitw);
-        sv_emit(hitw, cand, ctr, last_tile * 1024 + tid, lane);
+        #pragma unroll
+        for (int j = 0; j < NP; j++) if (j == 0 || qcnt > 64u * j) sv_check(PR[j], sieve, smask, hitw);
+        sv_emit(hitw, cand, ctr, last_tile * TILE + tid, lane);
         // ---- queue the passing seeds of this tile (probed during the next iteration).  If the queue could overflow
         // (dense on-locus data) it is drained on the spot and filling continues.
         u32 cnt = 0; int t0 = 0;
@@ -520,7 +447,7 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
                 if (cnt > SV_CAP - 64) { t_next = t; continue; }
                 u32 pos = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, cnt));
                 if (__builtin_amdgcn_inverse_ballot_w64(m))
-                    queue[pos] = (u64)w[t] | ((u64)((w[t + 1] & 0xFFu) | ((u32)lane << 8)) << 32);
+                    queue[pos] = (u64)elo[t] | ((u64)(ehi[t] | ((u32)lane << 8)) << 32);
                 cnt += (u32)__popcll(m);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -540,7 +467,7 @@ __global__ __launch_bounds__(1024) void k_sieve_lds(const u32* __restrict__ pack
         SvProbe Ps; sv_issue(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
         sv_check(Ps, sieve, smask, hitw);
     }
-    sv_emit(hitw, cand, ctr, last_tile * 1024 + tid, lane);
+    sv_emit(hitw, cand, ctr, last_tile * TILE + tid, lane);
     __syncthreads();
     if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
 }
@@ -1758,6 +1685,7 @@ struct mlst_handle {
     u32* d_packed = nullptr; u8* d_qrows = nullptr; u16* d_lens = nullptr; u64 cap_packed_words = 0, cap_qrow_bytes = 0, cap_lens = 0;
     u64 reads_seen = 0;
     int ext_threads = 256, ext_blocks = 1024;    // k_extend launch shape (set in mlst_load_reference)
+    int sieve_g_blocks = 256 * 5;                // k_sieve_q<.,false> grid (MLST_SIEVE_BLOCKS overrides it)
     u8* d_fq_text = nullptr; u64 cap_fq_text = 0; u32* d_fq_blk = nullptr; u64 cap_fq_blk = 0;
     u64* d_fq_lines = nullptr; u64 cap_fq_lines = 0; u64* d_fq_soff = nullptr; u64* d_fq_qoff = nullptr; u64 cap_fq_reads = 0; u64* d_fq_meta = nullptr;
     // pileup scratch
@@ -2019,7 +1947,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
             b = (b + 1) & smask;
         }
     }
-    // ---- first-level bitmap (LDS resident in k_sieve_lds): only when it is selective
+    // ---- first-level bitmap (LDS resident in k_sieve_q<., true>): only when it is selective
     std::vector<u32> bitmap;
     {
         const u64 nbits = 1ull << BITMAP_BITS;
@@ -2027,7 +1955,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         if (nk <= 4 * nbits && !(off_sw && off_sw[0] == '1')) {       // kept only if it turns out at most half full
             bitmap.assign(nbits / 32, 0);
             u64 set = 0;
-            for (u64 i = 0; i < nk; i++) {      // both orientations of every seed (see k_sieve_lds)
+            for (u64 i = 0; i < nk; i++) {      // both orientations of every seed (see k_sieve_q)
                 for (int o = 0; o < 2; o++) {
                     u32 L, R; sieve_halves_of(o ? revcomp40(ukeys[i]) : ukeys[i], L, R);
                     R += SV_HALF_BITS;
@@ -2123,6 +2051,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         int blocks = 1792 * 256 / thr;     // 7 waves per SIMD fit at the kernel's 68 VGPRs; the work queue balances the rest
         const char* e2 = getenv("MLST_EXT_BLOCKS"); if (e2 && atoi(e2) > 0) blocks = atoi(e2);
         h->ext_threads = thr; h->ext_blocks = blocks;
+        const char* e3 = getenv("MLST_SIEVE_BLOCKS"); if (e3 && atoi(e3) > 0) h->sieve_g_blocks = atoi(e3);
     }
     h->have_ref = h->have_state = true;
     int rc = reset_sample_state(h); if (rc) return rc;
@@ -2179,14 +2108,13 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     { Prof pf(h, 0);
       if (E.bitmap) {      // LDS first level: one 1024-thread workgroup per CU
         dim3 grid(grid_for((n_reads + 1023) / 1024, 1, 256)), block(1024);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_sieve_lds<W>, grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.bitmap, h->d_cand, E.ctr); break;
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, true>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.bitmap, 0u, h->d_cand, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
-      } else {
-        u64 nblk = (n_reads + 255) / 256;
-        dim3 grid(grid_for(nblk, 1, 256 * 8)), block(256);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_sieve<W>, grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.gbitmap, E.gbitmap_bits, h->d_cand, E.ctr); break;
+      } else {      // big database: global first-level bitmap, 256-thread workgroups
+        dim3 grid(grid_for((n_reads + 255) / 256, 1, h->sieve_g_blocks)), block(256);
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, false>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.gbitmap.p, E.gbitmap_bits, h->d_cand, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
