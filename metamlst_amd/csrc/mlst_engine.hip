@@ -272,6 +272,7 @@ __host__ inline void sieve_halves_of(u64 s, u32& L, u32& R) {
 }
 struct SvProbe { v4u bv; u32 fp, bi, src; bool act; };
 // read queue entry e (if any), canonical key, request its sieve bucket
+template <bool NT>
 __device__ inline void sv_issue(SvProbe& P, const u64* queue, u32 e, u32 cnt, const uint4* __restrict__ sieve, u32 sshift) {
     P.act = e < cnt;
     const u64 ent = P.act ? queue[e] : 0ull;
@@ -280,7 +281,9 @@ __device__ inline void sv_issue(SvProbe& P, const u64* queue, u32 e, u32 cnt, co
     P.src = (u32)(ent >> 40) & 63u;
     P.fp = sieve_fp(klo, khi);
     P.bi = P.act ? sieve_bucket_hash(klo, khi) >> sshift : 0u;
-    P.bv = reinterpret_cast<const v4u*>(sieve)[P.bi];
+    // a sieve that does not fit L2 is probed with non-temporal loads, which keeps the first-level bitmap resident there
+    if (NT) P.bv = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(sieve) + P.bi);
+    else P.bv = reinterpret_cast<const v4u*>(sieve)[P.bi];
 }
 // examine a requested bucket; a hit sets the bit of the seed's read (= lane of the tile) in the wave's hit mask
 __device__ inline void sv_check(const SvProbe& P, const uint4* __restrict__ sieve, u32 smask, u32* hitw) {
@@ -372,11 +375,11 @@ __global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __res
         SvProbe PR[NP];
         #pragma unroll
         for (int j = 0; j < NP; j++) {
-            if (j == 0 || qcnt > 64u * j) sv_issue(PR[j], queue, 64u * j + (u32)lane, qcnt, sieve, sshift);
+            if (j == 0 || qcnt > 64u * j) sv_issue<!LDSBM>(PR[j], queue, 64u * j + (u32)lane, qcnt, sieve, sshift);
             else { PR[j].act = false; PR[j].bv = v4u{0u, 0u, 0u, 0u}; PR[j].fp = 1u; PR[j].bi = 0u; PR[j].src = 0u; }
         }
         for (u32 base = 64u * NP; base < qcnt; base += 64) {
-            SvProbe Ps; sv_issue(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
+            SvProbe Ps; sv_issue<!LDSBM>(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
             sv_check(Ps, sieve, smask, hitw);
         }
         asm volatile("" ::: "memory");      // the bucket requests are older than the row requests below: waiting for them leaves the rows in flight
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __res
             if (t_next == NT) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (u32 base = 0; base < cnt; base += 64) {
-                SvProbe Ps; sv_issue(Ps, queue, base + (u32)lane, cnt, sieve, sshift);
+                SvProbe Ps; sv_issue<!LDSBM>(Ps, queue, base + (u32)lane, cnt, sieve, sshift);
                 sv_check(Ps, sieve, smask, hitw);
             }
             cnt = 0; t0 = t_next;
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __res
     // the last tile's queue
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (u32 base = 0; base < qcnt; base += 64) {
-        SvProbe Ps; sv_issue(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
+        SvProbe Ps; sv_issue<!LDSBM>(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
         sv_check(Ps, sieve, smask, hitw);
     }
     sv_emit(hitw, cand, ctr, last_tile * TILE + tid, lane);
