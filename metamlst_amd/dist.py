@@ -122,8 +122,16 @@ class StreamedShard:
         self.force = force_collectives           # tests: issue the collectives even in a group of one
         self.stream = torch.cuda.Stream(device=device)
         n_sum, n_min = engine.flat_sizes()
-        self.t_sum = torch.zeros(max(1, n_sum), dtype=torch.int64, device=device)
-        self.t_min = torch.zeros(max(1, n_min), dtype=torch.int64, device=device)
+        self.n_sum, self.n_min = n_sum, max(1, n_min)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # ONE all-reduce(SUM) per statistics exchange: [additive part | world x n_min slots].  Every rank writes its
+        # first-read vector into its own slot (the other slots are zero), so after the sum every rank holds every rank's
+        # vector and takes the minimum locally -- a second collective (MIN) costs more host time than two tiny kernels.
+        self.t_all = torch.zeros(max(1, n_sum) + self.world * self.n_min, dtype=torch.int64, device=device)
+        self.t_sum = self.t_all[:max(1, n_sum)]
+        self.t_slots = self.t_all[max(1, n_sum):].view(self.world, self.n_min)
+        self.t_min = torch.zeros(self.n_min, dtype=torch.int64, device=device)
         self.t_counts = torch.zeros(max(1, engine.typing_total_cols()) * 4, dtype=torch.int32, device=device)
         torch.cuda.synchronize(device)
         engine.set_stream(self.stream.cuda_stream)
@@ -135,9 +143,10 @@ class StreamedShard:
         with torch.cuda.stream(self.stream):
             submit_fn()
             if multi:
-                e.export_stats_device_async(self.t_sum.data_ptr(), self.t_min.data_ptr())
-                dist.all_reduce(self.t_sum, op=dist.ReduceOp.SUM, group=self.group)
-                dist.all_reduce(self.t_min, op=dist.ReduceOp.MIN, group=self.group)
+                self.t_slots.zero_()
+                e.export_stats_device_async(self.t_sum.data_ptr(), self.t_slots[self.rank].data_ptr())
+                dist.all_reduce(self.t_all, op=dist.ReduceOp.SUM, group=self.group)
+                torch.amin(self.t_slots, dim=0, out=self.t_min)
                 e.import_stats_device_async(self.t_sum.data_ptr(), self.t_min.data_ptr())
             e.typing_choose_pileup(penalty, self.t_counts.data_ptr())
             if multi:
