@@ -110,6 +110,17 @@ def split_counts(index, chosen: list[int], counts: np.ndarray) -> dict[int, np.n
     return out
 
 
+def allreduce_sum_with_min_slots(t_all: torch.Tensor, n_sum: int, n_min: int, t_min: torch.Tensor, group=None) -> None:
+    """One all-reduce(SUM) that also delivers an element-wise MIN.  t_all = [n_sum additive values | world x n_min slots];
+    the caller has zeroed the slots and written its own vector into slot `rank`.  After the sum every slot holds its
+    rank's vector (the others added zeros), so the minimum over the slots is the MIN over ranks.  In place; t_min gets
+    the minimum.  Works on host tensors (gloo) and device tensors (RCCL) alike."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if dist.is_initialized() and world >= 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.SUM, group=group)
+    torch.amin(t_all[n_sum:n_sum + world * n_min].view(world, n_min), dim=0, out=t_min)
+
+
 class StreamedShard:
     """One engine of a rank with everything of a step queued on ONE torch stream: pass 1, export of the statistics,
     the two all-reduces (RCCL orders a collective against the current stream), import, allele choice + pileup, the
@@ -145,8 +156,7 @@ class StreamedShard:
             if multi:
                 self.t_slots.zero_()
                 e.export_stats_device_async(self.t_sum.data_ptr(), self.t_slots[self.rank].data_ptr())
-                dist.all_reduce(self.t_all, op=dist.ReduceOp.SUM, group=self.group)
-                torch.amin(self.t_slots, dim=0, out=self.t_min)
+                allreduce_sum_with_min_slots(self.t_all, max(1, self.n_sum), self.n_min, self.t_min, self.group)
                 e.import_stats_device_async(self.t_sum.data_ptr(), self.t_min.data_ptr())
             e.typing_choose_pileup(penalty, self.t_counts.data_ptr())
             if multi:

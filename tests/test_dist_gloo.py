@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 import fixtures as fx
 import oracle_lib
-from metamlst_amd.dist import allreduce_pileup, allreduce_stats, shard_range, split_counts
+from metamlst_amd.dist import allreduce_pileup, allreduce_stats, allreduce_sum_with_min_slots, shard_range, split_counts
 from metamlst_amd.engine import MLST_CNT_N
 from metamlst_amd.typing import SampleStats, pick_alleles_fast
 
@@ -61,6 +61,17 @@ def worker(rank, world, port, tmp):
     orc = oracle_lib.Oracle(idx)
     orc.submit_reads(fb[int(o[0]):int(o[-1])], fq[int(o[0]):int(o[-1])], o - o[0], read_base=lo)
     p = OraclePort(orc, idx)
+    # the single-collective form used by StreamedShard (SUM buffer with per-rank MIN slots) against two collectives
+    n_sum, n_min = p.flat_sizes()
+    t_all = torch.zeros(n_sum + world * n_min, dtype=torch.int64)
+    p.export_stats(t_all[:n_sum], t_all[n_sum + rank * n_min:n_sum + (rank + 1) * n_min])
+    t_min1 = torch.zeros(n_min, dtype=torch.int64)
+    allreduce_sum_with_min_slots(t_all, n_sum, n_min, t_min1)
+    t_sum2, t_min2 = torch.zeros(n_sum, dtype=torch.int64), torch.zeros(n_min, dtype=torch.int64)
+    p.export_stats(t_sum2, t_min2)
+    dist.all_reduce(t_sum2, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t_min2, op=dist.ReduceOp.MIN)
+    assert torch.equal(t_all[:n_sum], t_sum2) and torch.equal(t_min1, t_min2)
     allreduce_stats(p, torch.device("cpu"))
     chosen = sorted(pick_alleles_fast(idx, p.st, 100).values())
     n_cols = sum(int(idx.off[a + 1] - idx.off[a]) for a in chosen)
