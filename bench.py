@@ -249,8 +249,18 @@ def main():
 
     run(args.warmup)
     # strictly serial steps (one engine), a few of them: the latency of one step, reported beside the throughput
-    engines[0].set_profiling(True)
+    # strictly serial steps on one engine, untimed, with HIP events around the kernel groups: every kernel has the GPU to
+    # itself (event profiling launches kernel by kernel; the timed regions below replay the launch sequence as a hipGraph)
+    KNAMES = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup", "sieve_inkernel")
+    engines[0].set_profiling(1)
     engines[0].reset_kernel_time()
+    for k in range(min(10, args.steps)):
+        submit(0)
+        finish(0)
+    fence()
+    isolated = {k: engines[0].kernel_time(k) for k in KNAMES}
+    engines[0].set_profiling(0)
+    # the latency of one strictly serial step, reported beside the throughput
     fence()
     t0 = time.perf_counter()
     n_serial = min(20, args.steps)
@@ -259,10 +269,8 @@ def main():
         finish(0)
     fence()
     serial_ms = (time.perf_counter() - t0) / max(1, n_serial) * 1e3
-    KNAMES = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup", "sieve_inkernel")
-    isolated = {k: engines[0].kernel_time(k) for k in KNAMES}       # no other stream is busy during these steps
     for e in engines:
-        e.set_profiling(True)
+        e.set_profiling(2)          # in-kernel sieve window only
         e.reset_kernel_time()
     for k in host_ms:
         host_ms[k] = 0.0
@@ -281,7 +289,7 @@ def main():
         parts = [e.kernel_time(k) for e in engines]
         kernels[k] = (sum(p_[0] for p_ in parts), sum(p_[1] for p_ in parts))
     for e in engines:
-        e.set_profiling(False)
+        e.set_profiling(0)
 
     if rank != 0:
         if world > 1:
@@ -292,13 +300,12 @@ def main():
     total_reads = args.reads * world
     value = total_reads / (dt / args.steps) / 1e6
     # ---- roofline of the dominant kernel
-    dom = max((k for k in kernels if k != "sieve_inkernel"), key=lambda k: kernels[k][0])
+    iso_launch = {k: (isolated[k][0] / max(1, isolated[k][1])) for k in isolated}
+    dom = max((k for k in iso_launch if k != "sieve_inkernel"), key=lambda k: iso_launch[k])
     per_launch = {k: (kernels[k][0] / max(1, kernels[k][1])) for k in kernels}
     # The sieve's launch duration over the timed region is its execution window measured inside the kernel (wall clock
-    # at the first workgroup's start / the last one's end): HIP events on a stream also count the time a launch queues
-    # behind the kernels of the other engines, which is not the kernel's.  rocprofv3's kernel trace shows the same window.
-    sieve_ms = per_launch["sieve_inkernel"] if per_launch.get("sieve_inkernel", 0) > 0 else per_launch["sieve"]
-    sieve_events_ms = per_launch["sieve"]
+    # at the first workgroup's start / the last one's end); rocprofv3's kernel trace shows the same window.
+    sieve_ms = per_launch["sieve_inkernel"] if per_launch.get("sieve_inkernel", 0) > 0 else iso_launch["sieve"]
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "sieve_pmc.json")
     if os.path.exists(pmc_path):
@@ -312,7 +319,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "alg_bytes_per_read": ALG_BYTES_BASES, "reads_per_launch": args.reads, "avg_launch_ms": round(sieve_ms, 4),
                 "achieved_at_188B_per_read": round(args.reads * ALG_BYTES_SURVEY / (sieve_ms * 1e-3) / 1e9, 1) if sieve_ms > 0 else 0.0,
-                "dominant_by_time": dom, "avg_launch_ms_events_incl_queueing": round(sieve_events_ms, 4)}
+                "dominant_by_time": dom}
     # the same kernel with the GPU to itself (the strictly serial steps before the timed region): in the timed region
     # the kernels of up to `depth` steps share the GPU, which lengthens each launch
     iso_ms = isolated["sieve_inkernel"][0] / max(1, isolated["sieve_inkernel"][1]) or isolated["sieve"][0] / max(1, isolated["sieve"][1])
@@ -371,8 +378,7 @@ def main():
                       "reads_per_gpu": args.reads, "n_alleles": int(idx.n_alleles), "parallelism": "reads sharded x%d" % world, "pipeline_depth": depth,
                       "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (wpr * 4, qstride)},
            "roofline": roofline, "cpu_baseline": cpu, "concordance": conc,
-           "kernel_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
-           "kernel_ms_per_launch_isolated": {k: round(v[0] / max(1, v[1]), 4) for k, v in isolated.items()},
+           "kernel_ms_per_launch_isolated": {k: round(v, 4) for k, v in iso_launch.items()},
            "host_ms_per_step": {k: round(v / args.steps, 4) for k, v in host_ms.items()},
            "serial_ms_per_step": round(serial_ms, 4),
            "counters": {"records": int(stats.counters[0]), "ignored": int(stats.counters[1]), "candidates": int(stats.counters[3]),

@@ -248,7 +248,7 @@ int mlst_set_stream(mlst_handle* h, void* stream);
 int mlst_export_stats_device_async(mlst_handle* h, int64_t* d_sum, int64_t* d_min);
 int mlst_import_stats_device_async(mlst_handle* h, const int64_t* d_sum, const int64_t* d_min);
 
-int mlst_set_profiling(mlst_handle* h, int on);
+int mlst_set_profiling(mlst_handle* h, int on);   /* 0 = off, 1 = events + sieve window, 2 = sieve window only (keeps the hipGraph replay of the launch sequences, which event profiling turns off) */
 int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms, uint64_t* launches);
 int mlst_reset_kernel_time(mlst_handle* h);
 /* Bytes of the device-resident index structures: [0]=allele arena [1]=sieve [2]=seed table;

@@ -1704,7 +1704,11 @@ struct mlst_handle {
     u64 off_sum = 0, off_len = 0, off_ctr = 0, off_hits = 0, off_first = 0;
     u8* h_pin = nullptr; u64 cap_pin = 0;          // pinned staging for pileup tables / counts
     // profiling
-    bool profiling = false;
+    bool profiling = false;                     // HIP events around the kernel groups (mlst_set_profiling(1))
+    bool window = false;                        // in-kernel sieve window only (mlst_set_profiling(1 or 2))
+    // the launch sequence of one submission / one typing tail, captured once per argument set and replayed (hipGraph)
+    struct GraphSlot { hipGraphExec_t exec = nullptr; std::vector<u64> sig; };
+    GraphSlot g_submit, g_typing; bool use_graphs = true;
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool;
     double k_ms[8] = {0}; u64 k_n[8] = {0};
@@ -1741,6 +1745,30 @@ static void drain_events(mlst_handle* h) {
     h->events.clear();
 }
 
+// hipGraph replay of a fixed launch sequence.  graph_enter returns 1 when a cached graph with the same signature was
+// launched (nothing left to do), 2 when stream capture has begun (the caller issues its launches, then graph_leave
+// instantiates and launches the graph), 0 when the caller should launch directly (profiling with events, a caller's
+// stream, graphs disabled or capture unavailable).
+static int graph_enter(mlst_handle* h, mlst_handle::GraphSlot& g, const std::vector<u64>& sig) {
+    if (!h->use_graphs || h->profiling || h->stream != h->own_stream) return 0;
+    if (g.exec && g.sig == sig) return hipGraphLaunch(g.exec, h->stream) == hipSuccess ? 1 : 0;
+    if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    // capture + instantiate cost more than one direct submission: a graph is built only for an argument set that
+    // comes a second time in a row (the first call launches directly and remembers the arguments)
+    if (g.sig != sig) { g.sig = sig; return 0; }
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->use_graphs = false; return 0; }
+    return 2;
+}
+static int graph_leave(mlst_handle* h, mlst_handle::GraphSlot& g) {
+    hipGraph_t graph = nullptr;
+    if (hipStreamEndCapture(h->stream, &graph) != hipSuccess || !graph) { h->use_graphs = false; return fail(h, MLST_E_HIP, "hipStreamEndCapture failed"); }
+    hipError_t e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) { g.exec = nullptr; h->use_graphs = false; return fail(h, MLST_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    HIPCHK(h, hipGraphLaunch(g.exec, h->stream));
+    return MLST_OK;
+}
+
 extern "C" void mlst_default_params(mlst_params* p) {
     memset(p, 0, sizeof *p);
     p->minscore = MLST_DEF_MINSCORE; p->max_xm = MLST_DEF_MAX_XM; p->min_read_len = MLST_DEF_MIN_READ_LEN;
@@ -1770,6 +1798,7 @@ extern "C" int mlst_create(int device, const mlst_params* p, mlst_handle** out) 
     h->device = device; h->prm = prm;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(nullptr, MLST_E_HIP, "cannot initialise device %d", device); }
     h->own_stream = h->stream;
+    { const char* g = getenv("MLST_GRAPHS"); if (g && g[0] == '0') h->use_graphs = false; }
     { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) h->wall_khz = (double)khz; }
     KParams& k = h->kp;
     k.minscore = prm.minscore; k.max_xm = prm.max_xm; k.min_read_len = prm.min_read_len; k.minqual = prm.minqual;
@@ -1816,6 +1845,7 @@ extern "C" void mlst_destroy(mlst_handle* h) {
     hipFree(h->d_cand); hipFree(h->d_in_bases); hipFree(h->d_in_quals); hipFree(h->d_in_off);
     hipFree(h->d_fq_text); hipFree(h->d_fq_blk); hipFree(h->d_fq_lines); hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); hipFree(h->d_fq_meta);
     hipFree(h->d_packed); hipFree(h->d_qrows); hipFree(h->d_lens); hipFree(h->d_counts); hipFree(h->d_dist); hipFree(h->d_query);
+    for (auto* g : {&h->g_submit, &h->g_typing}) if (g->exec) hipGraphExecDestroy(g->exec);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -1838,6 +1868,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     free_ref(h); free_state(h);
+    for (auto* g : {&h->g_submit, &h->g_typing}) { if (g->exec) { hipGraphExecDestroy(g->exec); g->exec = nullptr; } g->sig.clear(); }
     h->n_alleles = n_alleles;
     // ---- locus table
     u32 n_loci = 0;
@@ -2108,6 +2139,9 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     (void)paired;   // mates are typed independently; they share a QNAME only for the coverage figure
     if (h->cap_cand < n_reads) { hipStreamSynchronize(h->stream); hipFree(h->d_cand); h->d_cand = nullptr; HIPCHK(h, dmalloc(&h->d_cand, n_reads)); h->cap_cand = n_reads; }
     EngineDev& E = h->E;
+    const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
+                                               (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand});
+    if (gs == 1) { h->reads_seen += n_reads; return MLST_OK; }
     { Prof pf(h, 0);
       if (E.bitmap) {      // LDS first level: one 1024-thread workgroup per CU
         dim3 grid(grid_for((n_reads + 1023) / 1024, 1, 256)), block(1024);
@@ -2134,6 +2168,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
       hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, h->d_E); }
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, h->stream, E.ctr, n_reads);
+    if (gs == 2) { int rc = graph_leave(h, h->g_submit); if (rc) return rc; }
     HIPCHK(h, hipGetLastError());
     h->reads_seen += n_reads;
     return MLST_OK;
@@ -2254,7 +2289,7 @@ static int fetch_stats(mlst_handle* h, Counters** c_out) {
 static int check_overflow(mlst_handle* h) { return fetch_stats(h, nullptr); }
 // in-kernel execution window of the sample's sieve launch (one submission per sample), slot 7 of the kernel times
 static void note_sieve_window(mlst_handle* h, const Counters* c) {
-    if (!h->profiling || !c->sv_t1 || !c->sv_t0n) return;
+    if (!h->window || !c->sv_t1 || !c->sv_t0n) return;
     const u64 t0 = ~c->sv_t0n;
     if (c->sv_t1 > t0) { h->k_ms[7] += (double)(c->sv_t1 - t0) / h->wall_khz; h->k_n[7]++; }
 }
@@ -2473,8 +2508,14 @@ extern "C" int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_cha
     return MLST_OK;
 }
 extern "C" int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char) {
-    int rc = mlst_typing_choose_pileup(h, penalty, nullptr); if (rc) return rc;
-    return mlst_typing_finish(h, mincov, none_char, nullptr);
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    hipSetDevice(h->device);
+    const int gs = graph_enter(h, h->g_typing, {(u64)(u32)penalty, (u64)mincov, (u64)(u8)none_char});
+    if (gs == 1) { h->auto_pending = true; return MLST_OK; }
+    int rc = mlst_typing_choose_pileup(h, penalty, nullptr);
+    if (!rc) rc = mlst_typing_finish(h, mincov, none_char, nullptr);
+    if (gs == 2) { int rc2 = graph_leave(h, h->g_typing); if (!rc) rc = rc2; }
+    return rc;
 }
 
 // Run the engine on a caller's HIP stream (e.g. the stream a torch.distributed collective is ordered against), or
@@ -2575,7 +2616,7 @@ extern "C" int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint
     return MLST_OK;
 }
 
-extern "C" int mlst_set_profiling(mlst_handle* h, int on) { if (!h) return MLST_E_INVALID; drain_events(h); h->profiling = on != 0; return MLST_OK; }
+extern "C" int mlst_set_profiling(mlst_handle* h, int on) { if (!h) return MLST_E_INVALID; drain_events(h); h->profiling = on == 1; h->window = on != 0; return MLST_OK; }
 extern "C" int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms, uint64_t* launches) {
     if (!h || which < 0 || which >= 8) return MLST_E_INVALID;
     hipSetDevice(h->device); drain_events(h);

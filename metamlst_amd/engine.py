@@ -356,7 +356,8 @@ class Engine:
         k = min(cap, int(n.value))
         return np.array([(b.read_index, b.locus, b.strand, b.diag, b.votes) for b in buf[:k]], dtype=np.int64).reshape(-1, 5)
 
-    def set_profiling(self, on: bool):
+    def set_profiling(self, on):
+        """0 / False = off, 1 / True = HIP events + sieve window, 2 = sieve window only (hipGraph replay stays on)."""
         self._check(self.lib.mlst_set_profiling(self._h, int(on)), "mlst_set_profiling")
 
     def kernel_time(self, which: int | str) -> tuple[float, int]:
