@@ -449,3 +449,31 @@ def test_streamed_shard_step_on_a_torch_stream():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_dense_on_locus_reads_overflow_the_sieve_queue():
+    """Amplicon-like data: every read comes from a locus, so nearly every seed passes the first level and the per-wave
+    queue of the sieve must be drained several times per tile (early drains, synchronous rounds) -- both sieve variants."""
+    import os
+    db, idx = fx.ecoli_small(80)
+    rng = np.random.default_rng(21)
+    seqs = [idx.sequence(int(idx.locus_begin[l]) + int(rng.integers(int(idx.locus_count[l])))) for l in range(idx.n_loci)]
+    reads, quals = [], []
+    for k in range(6000):
+        s = seqs[k % len(seqs)]
+        L = int(rng.choice([150, 150, 120, 75]))
+        at = int(rng.integers(0, len(s) - L + 1))
+        r = s[at:at + L].encode()
+        if k % 2:
+            r = r[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+        reads.append(r); quals.append(bytes([40 + 33]) * L)
+    fb, fq, off = synth.ragged_reads(reads, quals)
+    for env in ("0", "1"):
+        os.environ["MLST_NO_LDS_SIEVE"] = env
+        try:
+            eng, orc = both(idx)
+            s, so = run_both(eng, orc, fb, fq, off)
+            assert int(s.counters[4]) == 6000          # every read retained
+            check_pileup(eng, orc, idx, s)
+        finally:
+            os.environ.pop("MLST_NO_LDS_SIEVE", None)
