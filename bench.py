@@ -247,6 +247,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    # untimed priming, whatever W is: every engine sees its launch sequence often enough for the hipGraph of it to be built
+    # (that happens on the second identical submission) and replayed once; then the W warm-up steps proper
+    for e_i in range(depth):
+        for _ in range(3):
+            submit(e_i)
+            finish(e_i)
+    fence()
     run(args.warmup)
     # strictly serial steps (one engine), a few of them: the latency of one step, reported beside the throughput
     # strictly serial steps on one engine, untimed, with HIP events around the kernel groups: every kernel has the GPU to
