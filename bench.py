@@ -386,6 +386,10 @@ def main():
                       "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (wpr * 4, qstride)},
            "roofline": roofline, "cpu_baseline": cpu, "concordance": conc,
            "kernel_ms_per_launch_isolated": {k: round(v, 4) for k, v in iso_launch.items()},
+           # SURVEY.md 8(d) secondary figure for the on-locus minority: ungapped (XOR / bit-plane) cells of k_extend
+           "extend": {"pairs_per_launch": int(stats.counters[5]) * (int(idx.n_alleles) // max(1, int(idx.n_loci))),
+                      "Gcells_per_s": round(int(stats.counters[5]) * (int(idx.n_alleles) // max(1, int(idx.n_loci))) * args.read_len
+                                            / max(1e-9, iso_launch["extend"] * 1e-3) / 1e9, 1)},
            "host_ms_per_step": {k: round(v / args.steps, 4) for k, v in host_ms.items()},
            "serial_ms_per_step": round(serial_ms, 4),
            "counters": {"records": int(stats.counters[0]), "ignored": int(stats.counters[1]), "candidates": int(stats.counters[3]),
