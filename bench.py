@@ -150,7 +150,7 @@ def main():
         dist.barrier()
     from metamlst_amd import db as mdb
     from metamlst_amd import synth
-    from metamlst_amd.dist import StreamedShard
+    from metamlst_amd.dist import DeviceStatsPort, StreamedShard, allreduce_consensus, allreduce_stats
     from metamlst_amd.engine import Engine
     from metamlst_amd.index import load_index
     from metamlst_amd.merge import EngineMatcher, SpeciesSession, parse_nfo_line
@@ -176,6 +176,8 @@ def main():
     # N > 1: every engine runs on its own torch stream, so that its kernels and the RCCL all-reduces of its step are
     # ordered on the device and the host synchronises once per step (metamlst_amd.dist.StreamedShard)
     shards = [StreamedShard(e, device) for e in engines] if world > 1 else None
+    ports = [DeviceStatsPort(e, device) for e in engines] if world > 1 else None
+    mode = {"streamed": world > 1}
     matcher = EngineMatcher(eng, idx)
     true_st = args.st_row + 1
     # merge-run prologue (metamlst-merge.py:119-142) happens once per run of many samples: untimed setup
@@ -201,8 +203,10 @@ def main():
             e.set_read_index_base(rank * args.reads)
             e.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), args.reads, wpr, qstride)
 
-        if world > 1:
+        if world > 1 and mode["streamed"]:
             shards[k % depth].enqueue(pass1, penalty=100)
+        elif world > 1:
+            pass1()                                   # host-driven exchange: the collectives follow in finish()
         else:
             pass1()
             e.typing_enqueue(penalty=100)
@@ -212,9 +216,22 @@ def main():
         """The host part of step k: wait for its device work, then .nfo line (gap-fill, accuracy gate) and ST call."""
         e = engines[k % depth]
         t_b = time.perf_counter()
-        st, chosen_dev, letters_dev = e.typing_fetch()
-        t_c = time.perf_counter()
-        res = type_sample(idx, st, None, database, "sample", fast=True, cache=cache, typed=(chosen_dev, letters_dev))
+        if world > 1 and not mode["streamed"]:
+            # fallback: the same two exchanges driven from the host with a synchronisation around every collective
+            port = ports[k % depth]
+            allreduce_stats(port, device)
+            st = e.stats()
+            t_c = time.perf_counter()
+
+            def consensus_fn(chosen):
+                n_cols = sum(int(idx.off[a + 1] - idx.off[a]) for a in chosen)
+                return allreduce_consensus(port, idx, chosen, n_cols, device)
+
+            res = type_sample(idx, st, None, database, "sample", fast=True, cache=cache, consensus_fn=consensus_fn)
+        else:
+            st, chosen_dev, letters_dev = e.typing_fetch()
+            t_c = time.perf_counter()
+            res = type_sample(idx, st, None, database, "sample", fast=True, cache=cache, typed=(chosen_dev, letters_dev))
         t_d = time.perf_counter()
         out = {}
         if rank == 0:
@@ -247,6 +264,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    # N > 1: one step both ways before anything is timed.  The streamed step (kernels and RCCL collectives ordered on a
+    # torch stream, one host synchronisation) must reproduce the host-driven exchange bit for bit on every rank; if it
+    # does not, or raises, every rank falls back to the host-driven form together (agreed through an all-reduce).
+    if world > 1:
+        ok = 1
+        try:
+            mode["streamed"] = False
+            submit(0)
+            ref_out, ref_st = finish(0)
+            mode["streamed"] = True
+            submit(0)
+            got_out, got_st = finish(0)
+            if not (np.array_equal(ref_st.sum_score, got_st.sum_score) and np.array_equal(ref_st.n_hits, got_st.n_hits)
+                    and np.array_equal(ref_st.locus_first, got_st.locus_first) and ref_out == got_out):
+                ok = 0
+        except Exception as exc:      # noqa: BLE001 -- any failure of the streamed form means: use the other one
+            print("rank %d: streamed step failed (%s); falling back to host-driven collectives" % (rank, exc), file=sys.stderr)
+            ok = 0
+        if os.environ.get("MLST_BENCH_HOST_COLLECTIVES"):      # test switch: take the fallback
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int64, device=device)
+        torch.cuda.synchronize(device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        mode["streamed"] = bool(int(flag.item()))
     # untimed priming, whatever W is: every engine sees its launch sequence often enough for the hipGraph of it to be built
     # (that happens on the second identical submission) and replayed once; then the W warm-up steps proper
     for e_i in range(depth):
@@ -383,6 +424,7 @@ def main():
            "config": {"workload": "cfg2: %d x %d bp SE reads per GPU, one E. coli-like isolate (%.1f Mb), synthetic DB 7 loci x %d alleles "
                                   "(metamlstDB_2022 is not available offline)" % (args.reads, args.read_len, args.genome / 1e6, args.alleles),
                       "reads_per_gpu": args.reads, "n_alleles": int(idx.n_alleles), "parallelism": "reads sharded x%d" % world, "pipeline_depth": depth,
+                      "collectives": ("streamed on a torch stream" if mode["streamed"] else "host-driven") if world > 1 else None,
                       "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (wpr * 4, qstride)},
            "roofline": roofline, "cpu_baseline": cpu, "concordance": conc,
            "kernel_ms_per_launch_isolated": {k: round(v, 4) for k, v in iso_launch.items()},
