@@ -486,6 +486,274 @@ __device__ inline u32 wave_excl_scan_u32(u32 v, u32& total) {      // exclusive 
 __device__ inline u64 wave_sum_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 __device__ inline u64 wave_min_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) { u64 w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
 __device__ inline u32 wave_sum_u32(u32 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+// ------------------------------------------------------------------ K1b: XCD-binned sieve for big databases
+// With millions of seeds no first-level filter fits LDS, and a filter that all 8 XCDs probe is served at ~80 G random
+// requests/s (16 MiB table; profiles/microbench/xcd_probe.hip) -- while probes that stay inside ONE XCD's 4 MiB L2 run at
+// ~270 G/s.  So the seeds are routed to the XCD that owns their key range:
+//   k_bin        streams the reads once; per seed the canonical key, a 39-bit hash of it (3 bits = owner, 36 bits =
+//                Bloom address), and an 8-byte entry appended to the owner's queue (LDS ring per wave and owner, flushed
+//                in coalesced 512-byte pieces into the wave's own region of the owner's arena -- no global atomics; a
+//                read whose seeds crowd one ring, or whose region is full, simply becomes a candidate);
+//   k_bin_probe  workgroups read which XCD they run on (HW_REG_XCC_ID) and drain that owner's arena: one 8-byte probe
+//                per entry into the owner's blocked Bloom filter (2 MiB per owner, L2 resident); the ~1 % that pass
+//                go the exact way: seed re-read from the read's row, canonical key, fingerprint sieve, candidate flag;
+//                a workgroup whose arena is drained helps the others (completeness never depends on the placement);
+//   k_flag_compact  candidate flags -> candidate list.
+#define BIN_OWNERS 8
+#define BIN_RING 128                 // entries per (wave, owner) LDS ring (flushed twice per tile)
+__host__ __device__ inline void bin_hash(u32 lo, u32 hi, u32& owner, u64& h36) {
+    u32 a = table_hash(lo, hi);                                         // also the exact table's hash: well mixed
+    u32 b = (lo ^ (hi * 0x9E3779B1u)) * 0x85EBCA6Bu; b ^= b >> 13;
+    owner = a >> 29;
+    h36 = ((u64)(a & 0x1FFFFFFFu) << 7) | (u64)(b >> 25);              // 29 + 7 bits
+}
+// Bloom address of a 36-bit hash inside an owner's filter of 2^blk_bits 8-byte blocks: block index + three bit positions
+__host__ __device__ inline void bin_bloom_addr(u64 h36, u32 blk_bits, u32& block, u64& mask) {
+    block = (u32)(h36 >> 7) & ((1u << blk_bits) - 1u);
+    u32 m = (u32)h36 * 0xC2B2AE35u; m ^= m >> 15; m *= 0x27D4EB2Fu; m ^= m >> 13;
+    mask = (1ull << (m & 63)) | (1ull << ((m >> 6) & 63)) | (1ull << ((m >> 12) & 63));
+}
+struct BinDev {                      // device-resident description of one binned submission
+    GP<u64> arena;                   // [owner][producer wave][cap] entries
+    GP<u32> counts;                  // [producer wave][owner] entries written
+    GP<u32> next;                    // [owner] work-queue cursor of k_bin_probe (zeroed per submission)
+    GP<const u64> bloom;             // [owner][1 << blk_bits] blocks
+    GP<u32> flags;                   // candidate flag per read (zeroed per submission)
+    u64 cap; u32 n_pw, blk_bits;
+};
+// exact check of one seed: canonical key -> fingerprint sieve; true = candidate
+__device__ inline bool bin_exact(u32 w0, u32 w1, const uint4* __restrict__ sieve, u32 smask, u32 sshift) {
+    u32 fl; const u64 c = canon40((u64)w0 | ((u64)(w1 & 0xFFu) << 32), fl);
+    const u32 klo = (u32)c, khi = (u32)(c >> 32), fp = sieve_fp(klo, khi);
+    u32 bi = sieve_bucket_hash(klo, khi) >> sshift;
+    for (int step = 0; step < 65; step++) {
+        bool full; const uint4 bb = sieve[bi];
+        if (bucket_has(bb, fp, full)) return true;
+        if (!full) return false;
+        bi = (bi + 1) & smask;
+    }
+    return false;
+}
+template <int WPR>
+__global__ __launch_bounds__(256) void k_bin(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
+                                             const BinDev B, Counters* __restrict__ ctr) {
+    __shared__ u64 s_ring[4][BIN_OWNERS][BIN_RING];            // 32 KiB
+    __shared__ u32 s_tail[4][BIN_OWNERS], s_head[4][BIN_OWNERS];
+    constexpr int NT = WPR - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());
+    if (lane < BIN_OWNERS) { s_tail[wave][lane] = 0; s_head[wave][lane] = 0; }
+    const u32 pw = blockIdx.x * 4 + wave;                       // producer wave
+    const u64 n_groups = (n_reads + 63) >> 6;
+    u32 head[BIN_OWNERS], written[BIN_OWNERS];                  // wave-uniform
+    #pragma unroll
+    for (int o = 0; o < BIN_OWNERS; o++) { head[o] = 0; written[o] = 0; }
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    // Whole 64-entry pieces of every owner's ring go out after seeds 0..4 and after the last seed.  Two things that
+    // random-looking keys never do are answered conservatively, by making the read a candidate outright (k_seed looks
+    // every candidate up exactly, so a superfluous one costs time, never correctness): a tile whose seeds crowd one key
+    // range (poly-A reads) overflows the ring, and a batch that does so throughout fills the owner's region.
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        #pragma unroll
+        for (int o = 0; o < BIN_OWNERS; o++) {
+            u32 tl = (u32)__builtin_amdgcn_readfirstlane((int)s_tail[wave][o]);
+            if (tl - head[o] > BIN_RING) { tl = head[o] + BIN_RING; if (lane == 0) s_tail[wave][o] = tl; }
+            bool moved = false;
+            while (tl - head[o] >= 64) {
+                const u64 e = s_ring[wave][o][(head[o] + lane) & (BIN_RING - 1)];
+                if (written[o] + 64 <= B.cap) { B.arena[((u64)o * B.n_pw + pw) * B.cap + written[o] + lane] = e; written[o] += 64; }
+                else {
+                    const u64 rr = ((u64)pw + (u64)((u32)(e >> 6) & 0x3FFFFu) * B.n_pw) * 64 + ((u32)e & 63u);
+                    atomicOr(&B.flags[rr >> 5], 1u << (rr & 31));
+                }
+                head[o] += 64; moved = true;
+            }
+            if (moved && lane == 0) s_head[wave][o] = head[o];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+    u32 k = 0;
+    v2u xn[WPR / 2]; u16 len_raw = 0;                          // rows of the NEXT group are requested a group ahead
+    {
+        const u64 g0 = pw < n_groups ? pw : 0, r0 = g0 * 64 + lane;
+        const v2u* row = reinterpret_cast<const v2u*>(packed) + g0 * (32 * WPR) + lane;
+        #pragma unroll
+        for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
+        len_raw = lens[r0 < n_reads ? r0 : 0];
+    }
+    for (u64 g = pw; g < n_groups; g += B.n_pw, k++) {
+        const u64 r = g * 64 + lane;
+        const bool live = r < n_reads;
+        u32 w[WPR]; u32 len_cur;
+        #pragma unroll
+        for (int t2 = 0; t2 < WPR / 2; t2++) {
+            asm volatile("v_mov_b32 %0, %1" : "=v"(w[2 * t2]) : "v"(xn[t2].x));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(w[2 * t2 + 1]) : "v"(xn[t2].y));
+        }
+        asm volatile("v_mov_b32 %0, %1" : "=v"(len_cur) : "v"((u32)len_raw));
+        {
+            const u64 gn = g + B.n_pw < n_groups ? g + B.n_pw : g, rn = gn * 64 + lane;
+            const v2u* row = reinterpret_cast<const v2u*>(packed) + gn * (32 * WPR) + lane;
+            #pragma unroll
+            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
+            len_raw = lens[rn < n_reads ? rn : 0];
+            asm volatile("" ::: "memory");
+        }
+        const u32 n = live ? (len_cur & 0x7FFFu) : 0u;
+        const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
+        bool crowded = false;
+        #pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (t < nseeds) {
+                u32 fl; const u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl);
+                u32 owner; u64 h36; bin_hash((u32)c, (u32)(c >> 32), owner, h36);
+                const u32 pos = atomicAdd(&s_tail[wave][owner], 1u);            // LDS atomic: slot in the owner's ring
+                if (pos - s_head[wave][owner] < BIN_RING)
+                    s_ring[wave][owner][pos & (BIN_RING - 1)] = (h36 << 28) | ((u64)t << 24) | ((u64)(k & 0x3FFFFu) << 6) | (u64)lane;
+                else crowded = true;
+            }
+            if (t == 4 || t == NT - 1) flush();
+        }
+        if (crowded) atomicOr(&B.flags[r >> 5], 1u << (r & 31));
+    }
+    // the remainders (< 64 per owner), then the counts
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    #pragma unroll
+    for (int o = 0; o < BIN_OWNERS; o++) {
+        u32 tl = (u32)__builtin_amdgcn_readfirstlane((int)s_tail[wave][o]);
+        if (tl - head[o] > BIN_RING) tl = head[o] + BIN_RING;
+        const u32 rem = tl - head[o];
+        if ((u32)lane < rem) {
+            const u64 e = s_ring[wave][o][(head[o] + lane) & (BIN_RING - 1)];
+            if (written[o] + rem <= B.cap) B.arena[((u64)o * B.n_pw + pw) * B.cap + written[o] + lane] = e;
+            else {
+                const u64 rr = ((u64)pw + (u64)((u32)(e >> 6) & 0x3FFFFu) * B.n_pw) * 64 + ((u32)e & 63u);
+                atomicOr(&B.flags[rr >> 5], 1u << (rr & 31));
+            }
+        }
+        if (written[o] + rem <= B.cap) written[o] += rem;
+        if (lane == 0) B.counts[(u64)pw * BIN_OWNERS + o] = written[o];
+    }
+}
+
+__device__ inline u32 hw_xcc_id() { u32 v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xFu; }
+
+__global__ __launch_bounds__(256) void k_bin_probe(const u32* __restrict__ packed, u32 wpr, u64 n_reads, const uint4* __restrict__ sieve,
+                                                   u32 smask, const BinDev B, Counters* __restrict__ ctr) {
+    // Entries that pass the Bloom filter (a few per thousand) are not examined where they are found -- one lane going the
+    // exact way (two random row reads and a sieve probe) would hold its whole wave for microseconds -- but parked in an
+    // LDS queue and examined 256 at a time, every lane busy.
+    constexpr u32 QCAP = 2048; constexpr int EPT = 4;      // entries per thread and iteration (independent loads in flight)
+    __shared__ u32 s_region, s_qn;
+    __shared__ u64 s_q[QCAP];                                   // read index | seed slot << 40
+    const int tid = threadIdx.x;
+    const u32 sshift = (u32)__clz((int)smask);
+    const u32 home = hw_xcc_id() % BIN_OWNERS;
+    const u64 nblk = 1ull << B.blk_bits;
+    if (tid == 0) s_qn = 0;
+    __syncthreads();
+    auto drain = [&](bool all) {                                // block-uniform call sites
+        for (;;) {
+            __syncthreads();
+            const u32 qn = s_qn;
+            if (qn == 0 || (!all && qn < 256)) break;
+            const u32 take = qn < 256 ? qn : 256;
+            u64 q = 0;
+            if ((u32)tid < take) q = s_q[qn - take + tid];
+            __syncthreads();
+            if (tid == 0) s_qn = qn - take;
+            if ((u32)tid < take) {
+                const u64 rr = q & 0xFFFFFFFFFFull; const u32 tt = (u32)(q >> 40);
+                if (bin_exact(packed[packed_index(rr, wpr, tt)], packed[packed_index(rr, wpr, tt + 1)], sieve, smask, sshift))
+                    atomicOr(&B.flags[rr >> 5], 1u << (rr & 31));
+            }
+        }
+        __syncthreads();
+    };
+    for (u32 turn = 0; turn < BIN_OWNERS; turn++) {            // own arena first, then help the others
+        const u32 o = (home + turn) % BIN_OWNERS;
+        const auto bloom = B.bloom.g() + (u64)o * nblk;
+        for (;;) {
+            if (tid == 0) s_region = atomicAdd(&B.next[o], 1u);
+            __syncthreads();
+            const u32 reg = s_region;
+            __syncthreads();
+            if (reg >= B.n_pw) break;
+            const u32 cnt = B.counts[(u64)reg * BIN_OWNERS + o];
+            const auto ent = B.arena.g() + ((u64)o * B.n_pw + reg) * B.cap;
+            // the entries of the next iteration are requested before this iteration's Bloom probes: the stream from
+            // HBM and the probes into L2 overlap instead of alternating
+            u64 en[EPT];
+            #pragma unroll
+            for (int j = 0; j < EPT; j++) { const u32 i = j * 256 + tid; en[j] = i < cnt ? __builtin_nontemporal_load(&ent[i]) : 0ull; }
+            for (u32 i0 = 0; i0 < cnt; i0 += 256 * EPT) {
+                u64 e[EPT]; u64 blk[EPT]; u64 msk[EPT];
+                #pragma unroll
+                for (int j = 0; j < EPT; j++) {       // register copies free en[] for the loads below (see k_sieve_q)
+                    u32 lo = (u32)en[j], hi = (u32)(en[j] >> 32), lo2, hi2;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(lo2) : "v"(lo));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(hi2) : "v"(hi));
+                    e[j] = (u64)lo2 | ((u64)hi2 << 32);
+                }
+                #pragma unroll
+                for (int j = 0; j < EPT; j++) { u32 bi; bin_bloom_addr(e[j] >> 28, B.blk_bits, bi, msk[j]); blk[j] = bloom[bi]; }
+                {
+                    const u32 i1 = i0 + 256 * EPT;
+                    #pragma unroll
+                    for (int j = 0; j < EPT; j++) { const u32 i = i1 + j * 256 + tid; en[j] = i < cnt ? __builtin_nontemporal_load(&ent[i]) : 0ull; }
+                    asm volatile("" ::: "memory");
+                }
+                #pragma unroll
+                for (int j = 0; j < EPT; j++) {
+                    const u32 i = i0 + j * 256 + tid;
+                    if (i < cnt && (blk[j] & msk[j]) == msk[j]) {          // Bloom pass: park it
+                        const u32 tt = (u32)(e[j] >> 24) & 15u, ll = (u32)e[j] & 63u, kk = (u32)(e[j] >> 6) & 0x3FFFFu;
+                        const u64 rr = ((u64)reg + (u64)kk * B.n_pw) * 64 + ll;
+                        if (rr < n_reads) {
+                            const u32 at = atomicAdd(&s_qn, 1u);
+                            if (at < QCAP) s_q[at] = rr | ((u64)tt << 40);
+                            else {      // queue full (a filter that passes nearly everything): on the spot
+                                atomicSub(&s_qn, 1u);
+                                if (bin_exact(packed[packed_index(rr, wpr, tt)], packed[packed_index(rr, wpr, tt + 1)], sieve, smask, sshift))
+                                    atomicOr(&B.flags[rr >> 5], 1u << (rr & 31));
+                            }
+                        }
+                    }
+                }
+                drain(false);                                   // at most 256 * EPT entries were parked since the last look: QCAP holds them
+            }
+        }
+    }
+    drain(true);
+    if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
+}
+
+// candidate flags -> candidate list (one atomic per 1024-thread workgroup that holds candidates)
+__global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ flags, u64 n_reads, u32* __restrict__ cand, Counters* __restrict__ ctr) {
+    __shared__ u32 s_cnt[16]; __shared__ u64 s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u64 n_words = (n_reads + 31) >> 5;
+    for (u64 w0 = (u64)blockIdx.x * 1024; w0 < n_words; w0 += (u64)gridDim.x * 1024) {
+        const u64 wi = w0 + tid;
+        const u32 f = wi < n_words ? flags[wi] : 0u;
+        u32 c = (u32)__popc(f), tot;
+        const u32 pre = wave_excl_scan_u32(c, tot);
+        if (lane == 0) s_cnt[wv] = tot;
+        __syncthreads();
+        u32 before = 0, all = 0;
+        for (int k = 0; k < 16; k++) { if (k < wv) before += s_cnt[k]; all += s_cnt[k]; }
+        if (all) {
+            if (tid == 0) s_base = atomicAdd(&ctr->n_cand, (u64)all);
+            __syncthreads();
+            u64 at = s_base + before + pre; u32 m = f;
+            while (m) { int b = __ffs(m) - 1; m &= m - 1; cand[at++] = (u32)(wi * 32 + b); }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ FASTQ text -> packed reads (GPU parser)
 #define FQ_BLOCK 4096        // bytes of text per workgroup
 // pass A: newlines per FQ_BLOCK bytes
@@ -1684,6 +1952,10 @@ struct mlst_handle {
     bool have_ref = false, have_state = false;
     // batch scratch
     u32* d_cand = nullptr; u64 cap_cand = 0;
+    // XCD-binned sieve (big databases): per-owner Bloom filters (reference) and the per-submission arena
+    u64* d_bloom = nullptr; u32 bloom_blk_bits = 0; bool binned = false;
+    u64* d_bin_arena = nullptr; u64 cap_bin_arena = 0; u32* d_bin_counts = nullptr; u32* d_bin_next = nullptr; u32* d_bin_flags = nullptr; u64 cap_bin_flags = 0;
+    u32 bin_pw = 0, bin_blocks = 0; u64 bin_cap = 0;
     u8* d_in_bases = nullptr; u8* d_in_quals = nullptr; u64* d_in_off = nullptr; u64 cap_in_bytes = 0, cap_in_reads = 0;
     u32* d_packed = nullptr; u8* d_qrows = nullptr; u16* d_lens = nullptr; u64 cap_packed_words = 0, cap_qrow_bytes = 0, cap_lens = 0;
     u64 reads_seen = 0;
@@ -1814,6 +2086,7 @@ static void free_ref(mlst_handle* h) {
     hipFree(h->d_arena); hipFree(h->d_planes); hipFree(h->d_nmask); hipFree(h->d_allele_len); hipFree(h->d_allele_locus); hipFree(h->d_loci);
     hipFree(h->d_sieve); hipFree(h->d_bitmap); h->d_bitmap = nullptr; hipFree(h->d_gbitmap); h->d_gbitmap = nullptr; hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
     hipFree(h->d_ascii); hipFree(h->d_aoff);
+    hipFree(h->d_bloom); h->d_bloom = nullptr; h->binned = false;
     hipFree(h->d_allele_no); hipFree(h->d_auto_chosen); hipFree(h->d_fixed_colbase); hipFree(h->d_auto_counts); hipFree(h->d_auto_letters);
     if (h->h_auto) { hipHostFree(h->h_auto); h->h_auto = nullptr; }
     h->d_allele_no = h->d_auto_chosen = nullptr; h->d_fixed_colbase = nullptr; h->d_auto_counts = nullptr; h->d_auto_letters = nullptr; h->auto_pending = false;
@@ -1823,6 +2096,8 @@ static void free_ref(mlst_handle* h) {
 }
 static void free_state(mlst_handle* h) {
     EngineDev& E = h->E;
+    hipFree(h->d_bin_arena); hipFree(h->d_bin_counts); hipFree(h->d_bin_next); hipFree(h->d_bin_flags);
+    h->d_bin_arena = nullptr; h->d_bin_counts = nullptr; h->d_bin_next = nullptr; h->d_bin_flags = nullptr; h->cap_bin_arena = 0; h->cap_bin_flags = 0; h->bin_pw = 0;
     hipFree(h->d_E); h->d_E = nullptr;
     hipFree(h->d_stats); h->d_stats = nullptr; if (h->h_stats) { hipHostFree(h->h_stats); h->h_stats = nullptr; }
     hipFree(E.ret_bases); hipFree(E.ret_quals); hipFree(E.ret_len); hipFree(E.ret_ridx); hipFree(E.ret_nrec);
@@ -2011,6 +2286,25 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
             for (u64 i = 0; i < nk; i++) { u32 bi = bitmap_hash_bits((u32)ukeys[i], (u32)(ukeys[i] >> 32), gbits); gbitmap[bi >> 5] |= 1u << (bi & 31); }
         } else gbits = 0;
     }
+    // ---- XCD-binned sieve (big databases): one blocked Bloom filter per owner (key range), 2 MiB each so that it stays
+    // in the owner XCD's L2 beside the entry stream; built whenever the LDS first level is not in use
+    std::vector<u64> bloom; u32 blk_bits = 0;
+    {
+        // worth it once the shared first-level bitmap is crowded (cfg3 size: 12.7 M seeds, 5.8 -> 4.2 ms; at 4.2 M seeds the
+        // single kernel is still 10 % ahead).  MLST_BINNED=1 / 0 forces it on / off (tests, tuning).
+        const char* bsw = getenv("MLST_BINNED");
+        const bool want = bsw ? bsw[0] == '1' : nk >= 8000000ull;
+        if (bitmap.empty() && nk > 0 && want) {
+            const char* bb = getenv("MLST_BLOOM_BITS"); blk_bits = bb ? (u32)atoi(bb) : 18u;     // 2^18 blocks x 8 B = 2 MiB per owner (swept 17..20 on cfg3)
+            if (blk_bits < 10 || blk_bits > 22) blk_bits = 18;
+            bloom.assign((u64)BIN_OWNERS << blk_bits, 0ull);
+            for (u64 i = 0; i < nk; i++) {
+                u32 owner, bi; u64 h36, m; bin_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32), owner, h36);
+                bin_bloom_addr(h36, blk_bits, bi, m);
+                bloom[((u64)owner << blk_bits) + bi] |= m;
+            }
+        }
+    }
     // ---- tables derived from the parameters
     std::vector<int> floor_tab(MLST_MAX_READ_LEN + 1);
     for (int n = 0; n <= MLST_MAX_READ_LEN; n++) {
@@ -2029,6 +2323,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_loci, (u64)n_loci)); HIPCHK(h, hipMemcpy(h->d_loci, loci.data(), (u64)n_loci * sizeof(LocusDev), hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_sieve, nb)); HIPCHK(h, hipMemcpy(h->d_sieve, sv.data(), nb * 16, hipMemcpyHostToDevice));
     if (!bitmap.empty()) { HIPCHK(h, dmalloc(&h->d_bitmap, (u64)bitmap.size())); HIPCHK(h, hipMemcpy(h->d_bitmap, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice)); }
+    if (!bloom.empty()) { HIPCHK(h, dmalloc(&h->d_bloom, (u64)bloom.size())); HIPCHK(h, hipMemcpy(h->d_bloom, bloom.data(), bloom.size() * 8, hipMemcpyHostToDevice)); h->bloom_blk_bits = blk_bits; h->binned = true; }
     if (!gbitmap.empty()) { HIPCHK(h, dmalloc(&h->d_gbitmap, (u64)gbitmap.size())); HIPCHK(h, hipMemcpy(h->d_gbitmap, gbitmap.data(), gbitmap.size() * 4, hipMemcpyHostToDevice)); }
     HIPCHK(h, dmalloc(&h->d_keys, tcap)); HIPCHK(h, hipMemcpy(h->d_keys, tkeys.data(), tcap * 8, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_vals, tcap)); HIPCHK(h, hipMemcpy(h->d_vals, tvals.data(), tcap * 4, hipMemcpyHostToDevice));
@@ -2038,7 +2333,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     u64 abytes = off[n_alleles];
     HIPCHK(h, dmalloc(&h->d_ascii, abytes)); if (abytes) HIPCHK(h, hipMemcpy(h->d_ascii, ascii, abytes, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_aoff, (u64)n_alleles + 1)); HIPCHK(h, hipMemcpy(h->d_aoff, off, ((u64)n_alleles + 1) * 8, hipMemcpyHostToDevice));
-    h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
+    h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4 + bloom.size() * 8; h->bytes_table = tcap * 12 + posts.size() * 4;
     h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
     {   // device-side typing: allele numbers, one slot of max_len columns per locus
         HIPCHK(h, dmalloc(&h->d_allele_no, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_no, allele_no, (u64)n_alleles * 4, hipMemcpyHostToDevice));
@@ -2126,6 +2421,26 @@ extern "C" int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, co
     return MLST_OK;
 }
 
+// arena / flag buffers of the XCD-binned sieve for a batch of n_reads (grow-only; must run outside stream capture)
+static int ensure_bin_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
+    const u64 n_groups = (n_reads + 63) >> 6;
+    u32 blocks = (u32)std::min<u64>(256 * 5, (n_groups + 3) / 4); if (blocks < 1) blocks = 1;
+    const u32 n_pw = blocks * 4;
+    const u64 per_wave = (n_groups + n_pw - 1) / n_pw;                                  // groups per producer wave
+    u64 cap = (u64)((double)(per_wave * 64 * (wpr - 1)) / BIN_OWNERS * 1.3) + 256; cap = (cap + 63) & ~63ull;
+    const u64 need = (u64)BIN_OWNERS * n_pw * cap;
+    if (h->cap_bin_arena < need || h->bin_pw != n_pw) {
+        hipStreamSynchronize(h->stream);
+        hipFree(h->d_bin_arena); hipFree(h->d_bin_counts); hipFree(h->d_bin_next); h->d_bin_arena = nullptr; h->d_bin_counts = nullptr; h->d_bin_next = nullptr;
+        HIPCHK(h, dmalloc(&h->d_bin_arena, need)); HIPCHK(h, dmalloc(&h->d_bin_counts, (u64)n_pw * BIN_OWNERS)); HIPCHK(h, dmalloc(&h->d_bin_next, (u64)BIN_OWNERS));
+        h->cap_bin_arena = need; h->bin_pw = n_pw;
+    }
+    const u64 n_flag_words = (n_reads + 31) >> 5;
+    if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words; }
+    h->bin_blocks = blocks; h->bin_cap = cap;
+    return MLST_OK;
+}
+
 extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packed, const uint8_t* d_qrows, const uint16_t* d_lens,
                                          uint64_t n_reads, uint32_t wpr, uint32_t qstride, int paired) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
@@ -2139,8 +2454,10 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     (void)paired;   // mates are typed independently; they share a QNAME only for the coverage figure
     if (h->cap_cand < n_reads) { hipStreamSynchronize(h->stream); hipFree(h->d_cand); h->d_cand = nullptr; HIPCHK(h, dmalloc(&h->d_cand, n_reads)); h->cap_cand = n_reads; }
     EngineDev& E = h->E;
+    if (!E.bitmap && h->binned) { int rc = ensure_bin_buffers(h, n_reads, wpr); if (rc) return rc; }
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
-                                               (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand});
+                                               (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand, (u64)(uintptr_t)h->d_bin_arena,
+                                               (u64)(uintptr_t)h->d_bin_flags, h->bin_cap});
     if (gs == 1) { h->reads_seen += n_reads; return MLST_OK; }
     { Prof pf(h, 0);
       if (E.bitmap) {      // LDS first level: one 1024-thread workgroup per CU
@@ -2149,6 +2466,18 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
+      } else if (h->binned) {      // big database: seeds routed to the XCD that owns their key range (K1b)
+        const u32 blocks = h->bin_blocks, n_pw = blocks * 4; const u64 cap = h->bin_cap, n_flag_words = (n_reads + 31) >> 5;
+        HIPCHK(h, hipMemsetAsync(h->d_bin_flags, 0, n_flag_words * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_bin_next, 0, BIN_OWNERS * 4, h->stream));
+        BinDev B; B.arena = h->d_bin_arena; B.counts = h->d_bin_counts; B.next = h->d_bin_next; B.bloom = h->d_bloom; B.flags = h->d_bin_flags;
+        B.cap = cap; B.n_pw = n_pw; B.blk_bits = h->bloom_blk_bits;
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_bin<W>, dim3(blocks), dim3(256), 0, h->stream, d_packed, d_lens, (u64)n_reads, B, E.ctr); break;
+        switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
+                       SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
+#undef SIEVE_CASE
+        hipLaunchKernelGGL(k_bin_probe, dim3(2048), dim3(256), 0, h->stream, d_packed, wpr, (u64)n_reads, E.sieve, E.sieve_mask, B, E.ctr);
+        hipLaunchKernelGGL(k_flag_compact, dim3(grid_for(n_flag_words, 1024, 256)), dim3(1024), 0, h->stream, h->d_bin_flags, (u64)n_reads, h->d_cand, E.ctr);
       } else {      // big database: global first-level bitmap, 256-thread workgroups
         dim3 grid(grid_for((n_reads + 255) / 256, 1, h->sieve_g_blocks)), block(256);
 #define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, false>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.gbitmap.p, E.gbitmap_bits, h->d_cand, E.ctr); break;

@@ -222,14 +222,34 @@ def test_sharded_engines_reduce_to_the_single_engine_result():
     assert letters == b"".join(whole.consensus(chosen)[a] for a in chosen)
 
 
-def test_plain_sieve_kernel_without_lds_bitmap(monkeypatch):
-    """Large databases skip the LDS first-level bitmap; force that path on a small one."""
+@pytest.mark.parametrize("binned", ["0", "1"])
+def test_big_database_sieves_on_a_small_database(monkeypatch, binned):
+    """Large databases skip the LDS first-level bitmap; force those paths on a small one: the single-kernel sieve with
+    the global bitmap (MLST_BINNED=0) and the XCD-binned sieve (k_bin -> k_bin_probe -> k_flag_compact, MLST_BINNED=1),
+    the latter also with Bloom filters so small that nearly every seed goes the exact way."""
     monkeypatch.setenv("MLST_NO_LDS_SIEVE", "1")
+    monkeypatch.setenv("MLST_BINNED", binned)
     db, idx = fx.ecoli_small(80)
     fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 8, n_reads=9000)
-    eng, orc = both(idx)
-    s, _ = run_both(eng, orc, fb, fq, off)
-    check_pileup(eng, orc, idx, s)
+    for bloom_bits in (("18", "10") if binned == "1" else ("18",)):
+        monkeypatch.setenv("MLST_BLOOM_BITS", bloom_bits)
+        eng, orc = both(idx)
+        s, _ = run_both(eng, orc, fb, fq, off)
+        check_pileup(eng, orc, idx, s)
+        # ragged lengths (fewer seeds than slots, reads shorter than a seed) and N bases through the same path
+        rng = np.random.default_rng(5)
+        reads, quals = [], []
+        for k in range(0, 3000):
+            o = int(off[k]); L = int(rng.integers(1, 151))
+            r = bytearray(fb[o:o + L].tobytes())
+            if k % 9 == 0:
+                r[int(rng.integers(L))] = ord("N")
+            reads.append(bytes(r)); quals.append(fq[o:o + L].tobytes())
+        fbr, fqr, offr = synth.ragged_reads(reads, quals)
+        orc2 = oracle_lib.Oracle(idx)
+        eng.reset_sample()
+        eng.submit_reads(fbr, fqr, offr); orc2.submit_reads(fbr, fqr, offr)
+        fx.assert_stats_equal(eng.stats(), orc2.stats())
 
 
 def test_alleles_with_ambiguity_codes_use_the_n_mask_paths():
@@ -453,7 +473,7 @@ def test_streamed_shard_step_on_a_torch_stream():
 
 def test_dense_on_locus_reads_overflow_the_sieve_queue():
     """Amplicon-like data: every read comes from a locus, so nearly every seed passes the first level and the per-wave
-    queue of the sieve must be drained several times per tile (early drains, synchronous rounds) -- both sieve variants."""
+    queue of the sieve must be drained several times per tile (early drains, synchronous rounds) -- all three sieve variants."""
     import os
     db, idx = fx.ecoli_small(80)
     rng = np.random.default_rng(21)
@@ -468,8 +488,9 @@ def test_dense_on_locus_reads_overflow_the_sieve_queue():
             r = r[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
         reads.append(r); quals.append(bytes([40 + 33]) * L)
     fb, fq, off = synth.ragged_reads(reads, quals)
-    for env in ("0", "1"):
+    for env, binned in (("0", "0"), ("1", "0"), ("1", "1")):
         os.environ["MLST_NO_LDS_SIEVE"] = env
+        os.environ["MLST_BINNED"] = binned
         try:
             eng, orc = both(idx)
             s, so = run_both(eng, orc, fb, fq, off)
@@ -477,3 +498,4 @@ def test_dense_on_locus_reads_overflow_the_sieve_queue():
             check_pileup(eng, orc, idx, s)
         finally:
             os.environ.pop("MLST_NO_LDS_SIEVE", None)
+            os.environ.pop("MLST_BINNED", None)
