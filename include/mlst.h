@@ -239,7 +239,10 @@ int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint64_t* n);
  * which: 0=sieve 1=seed 2=extend 3=banded-SW 4=accumulate 5=pileup 6=pack (events bracket the launch on the engine's
  * stream, so with several engines on one GPU they include the time a kernel queues behind another stream's kernel);
  * 7 = the sieve's execution window measured inside the kernel (wall clock at the first workgroup's start and the last
- * one's end; one submission per sample), added up when the sample's statistics are fetched. */
+ * one's end; one submission per sample), added up when the sample's statistics are fetched;
+ * 8 = the longest residency of one workgroup of that launch (LDS sieve; one workgroup per CU, each doing an equal share):
+ * what the launch takes once its workgroups run -- when it shares the GPU with another stream's kernel its workgroups
+ * start one by one as CUs free up, which stretches the window (7) without the kernel being any slower. */
 /* Run the engine on the caller's HIP stream (hipStream_t; NULL = back on the engine's own stream).  Work queued so
  * far is waited for.  With the engine on the stream a torch.distributed collective is ordered against, a multi-GPU
  * step needs no host synchronisation between its kernels and its collectives (metamlst_amd/dist.py). */

@@ -118,6 +118,7 @@ struct Counters {
     u64 ext_q[EXT_Q][16];
     u64 err;             // bit0 retained overflow, bit1 item overflow, bit2 result overflow, bit3 dp overflow
     u64 sv_t0n, sv_t1;   // sieve execution window in wall-clock ticks: max over workgroups of ~start and of end (profiling)
+    u64 sv_wgmax;        // longest residency of one sieve workgroup (end - start), wall-clock ticks
     u64 cnt[MLST_CNT_N];
 };
 // item_state bits
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u64* const queue = reinterpret_cast<u64*>(s_all) + wave * SV_CAP;
     u32* const hitw = s_all + Q_WORDS + wave * 2;
-    if (tid == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());      // execution window (excludes queueing behind other streams)
+    const u64 wg_t0 = (u64)wall_clock64();
+    if (tid == 0) atomicMax(&ctr->sv_t0n, ~wg_t0);      // execution window (excludes queueing behind other streams)
     if (LDSBM) {   // 32768 words, 16-byte vectors
         const v4u* g4 = reinterpret_cast<const v4u*>(bitmap); v4u* s4 = reinterpret_cast<v4u*>(s_bm);
         #pragma unroll
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __res
     }
     sv_emit(hitw, cand, ctr, last_tile * TILE + tid, lane);
     __syncthreads();
-    if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
+    if (tid == 0) { const u64 t1 = (u64)wall_clock64(); atomicMax(&ctr->sv_t1, t1); atomicMax(&ctr->sv_wgmax, t1 - wg_t0); }
 }
 
 // ------------------------------------------------------------------ wave helpers
@@ -1983,7 +1985,7 @@ struct mlst_handle {
     GraphSlot g_submit, g_typing; bool use_graphs = true;
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool;
-    double k_ms[8] = {0}; u64 k_n[8] = {0};
+    double k_ms[9] = {0}; u64 k_n[9] = {0};
     double wall_khz = 100000.0;                  // wall_clock64 rate (hipDeviceAttributeWallClockRate)
 };
 
@@ -2621,6 +2623,7 @@ static void note_sieve_window(mlst_handle* h, const Counters* c) {
     if (!h->window || !c->sv_t1 || !c->sv_t0n) return;
     const u64 t0 = ~c->sv_t0n;
     if (c->sv_t1 > t0) { h->k_ms[7] += (double)(c->sv_t1 - t0) / h->wall_khz; h->k_n[7]++; }
+    if (c->sv_wgmax) { h->k_ms[8] += (double)c->sv_wgmax / h->wall_khz; h->k_n[8]++; }
 }
 
 extern "C" int mlst_get_allele_stats(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_len,
@@ -2947,13 +2950,13 @@ extern "C" int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint
 
 extern "C" int mlst_set_profiling(mlst_handle* h, int on) { if (!h) return MLST_E_INVALID; drain_events(h); h->profiling = on == 1; h->window = on != 0; return MLST_OK; }
 extern "C" int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms, uint64_t* launches) {
-    if (!h || which < 0 || which >= 8) return MLST_E_INVALID;
+    if (!h || which < 0 || which >= 9) return MLST_E_INVALID;
     hipSetDevice(h->device); drain_events(h);
     if (total_ms) *total_ms = h->k_ms[which];
     if (launches) *launches = h->k_n[which];
     return MLST_OK;
 }
-extern "C" int mlst_reset_kernel_time(mlst_handle* h) { if (!h) return MLST_E_INVALID; drain_events(h); for (int i = 0; i < 8; i++) { h->k_ms[i] = 0; h->k_n[i] = 0; } return MLST_OK; }
+extern "C" int mlst_reset_kernel_time(mlst_handle* h) { if (!h) return MLST_E_INVALID; drain_events(h); for (int i = 0; i < 9; i++) { h->k_ms[i] = 0; h->k_n[i] = 0; } return MLST_OK; }
 extern "C" int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]) {
     if (!h || !out) return MLST_E_INVALID;
     out[0] = h->bytes_arena; out[1] = h->bytes_sieve; out[2] = h->bytes_table; out[3] = (u64)(h->bitmap_fill * 1e6); return MLST_OK;

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("MLST_LIB", os.path.join(_HERE, "libmlst_hip.so"))   #
 
 MLST_CNT_N = 8
 CNT_TOTAL_RECORDS, CNT_IGNORED, CNT_READS_SEEN, CNT_CANDIDATES, CNT_RETAINED, CNT_ITEMS, CNT_DP_PAIRS = range(7)
-KERNELS = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup", "pack", "sieve_inkernel")
+KERNELS = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup", "pack", "sieve_inkernel", "sieve_wg_longest")
 
 
 class MlstParams(C.Structure):
