@@ -1178,6 +1178,22 @@ __device__ inline int stage_read_planes(const EngineDev& E, const KParams& P, co
     return (int)pen_def;
 }
 
+// a * b + c with 24-bit factors, b wave-uniform (full-rate v_mad_i32_i24; the host pass only type-checks device code)
+__device__ inline int mad24(int a, int b, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c)); return r;      // b: wave-uniform
+#else
+    return a * b + c;
+#endif
+}
+// a + b + c, b wave-uniform (one v_add3_u32; left to itself the compiler re-associates the Kadane update into three adds)
+__device__ inline int add3(int a, int b, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r; asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c)); return r;
+#else
+    return a + b + c;
+#endif
+}
 // uniform row pointer (scalar registers) + 32-bit byte offset of the lane: the saddr form of global_load
 __device__ inline u32 ld_row(GP<const u32>::G* row, u32 byte_off) {
     return *reinterpret_cast<GP<const u32>::G*>(reinterpret_cast<GP<const char>::G*>(row) + byte_off);
@@ -1237,8 +1253,12 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
     }
     const int PD = (pen_def << MLST_P_SHIFT) + 1;
     if (!TRACK) {
-        // g = cur - last*MA, so the running value just before column i is g + i*MA
-        int g = P0 - i0 * MA, best = P0;
+        // g = cur - last*MA, so the running value just before column i is g + i*MA; gw = g + 32*w*MA is the same with
+        // the column counted inside word w.  One mismatch = nine full-rate VALU operations: the value before it is one
+        // 24-bit multiply-add (v_mad_i32_i24; a 32-bit multiply runs at a quarter of the rate), the new offset one
+        // three-operand add.
+        int gw = P0 - i0 * MA, best = P0;
+        const int negMA = -MA;
         #pragma unroll
         for (int w = 0; w < NB; w++) {
             u32 Mw = M[w];
@@ -1246,28 +1266,28 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
             Mw = 0;
 #endif
             const u32 special = od[w] | AN[w];
-            const int ub = 32 * w * MA;
             if (__any((Mw & special) != 0)) {                  // some mismatch of this wave has a non-default penalty
                 while (Mw) {
-                    int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
-                    int u = bit * MA + ub, t = g + u;
+                    const int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
+                    const int t = mad24(bit, MA, gw);
                     best = t > best ? t : best;
                     int dec = PD;
                     if ((special >> bit) & 1u) dec = ((((AN[w] >> bit) & 1u) ? P.n_penalty : (int)s_pen[32 * w + bit]) << MLST_P_SHIFT) + 1;
-                    t -= dec; t = t > P0 ? t : P0;
-                    g = t - u - MA;
+                    int dd = P0 - t; dd = dd > -dec ? dd : -dec;       // (value after the mismatch, floored at P0) - t
+                    gw = add3(gw, negMA, dd);
                 }
             } else {
                 while (Mw) {
-                    int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
-                    int u = bit * MA + ub, t = g + u;
+                    const int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
+                    const int t = mad24(bit, MA, gw);
                     best = t > best ? t : best;
-                    t -= PD; t = t > P0 ? t : P0;
-                    g = t - u - MA;
+                    int dd = P0 - t; dd = dd > -PD ? dd : -PD;         // (value after the mismatch, floored at P0) - t
+                    gw = add3(gw, negMA, dd);
                 }
             }
+            gw += 32 * MA;
         }
-        int t = g + i1 * MA;
+        const int t = gw + (i1 - 32 * NB) * MA;
         return t > best ? t : best;
     }
     if (i1 <= i0) return P0;
@@ -2065,6 +2085,7 @@ extern "C" int mlst_create(int device, const mlst_params* p, mlst_handle** out) 
     mlst_params prm; if (p) prm = *p; else mlst_default_params(&prm);
     if (prm.band_w < 1 || prm.band_w > MAX_W) return fail(nullptr, MLST_E_INVALID, "band_w must be in 1..%d", MAX_W);
     if (prm.max_xm > 254 || prm.minscore > 1000) return fail(nullptr, MLST_E_INVALID, "max_xm/minscore out of range");
+    if (prm.match_bonus < 1 || prm.match_bonus > 127) return fail(nullptr, MLST_E_INVALID, "match_bonus must be in 1..127");
     if (!prm.max_retained_reads) prm.max_retained_reads = 4ull << 20;
     if (!prm.max_items) prm.max_items = 8ull << 20;
     if (!prm.max_pair_results) prm.max_pair_results = 256ull << 20;
