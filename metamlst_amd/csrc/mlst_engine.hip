@@ -1329,9 +1329,6 @@ __device__ inline bool accept_rec(const KParams& P, u32 r, int n, bool use_xo) {
     return score >= P.minscore && n >= P.min_read_len && (use_xo ? xo : xm) <= P.max_xm;
 }
 
-#ifndef EXT_WAVES
-#define EXT_WAVES 4          // waves per SIMD the register allocator must leave room for (swept on MI355X)
-#endif
 // Take a ticket from queue q unless a plain look shows it already drained (a stale look only costs one atomic).
 __device__ inline u64 ext_steal(const EngineDev& E, u32 q, u64 begin, u64 end) {
     u64 seen = __hip_atomic_load((u64*)&E.ctr->ext_q[q][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1340,7 +1337,7 @@ __device__ inline u64 ext_steal(const EngineDev& E, u32 q, u64 begin, u64 end) {
 }
 
 template <int NB>
-__global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ Ep, KParams P) {
+__device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, const KParams& P) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     __shared__ u32 s_rl[RW / 2 + 2]; __shared__ u32 s_rh[RW / 2 + 2]; __shared__ u32 s_rn[RW / 2 + 2]; __shared__ u32 s_odd[RW / 2 + 2];
     __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
@@ -1462,6 +1459,12 @@ __global__ __launch_bounds__(1024) void k_extend(const EngineDev* __restrict__ E
         if (c_ign) atomicAdd(&E.ctr->cnt[MLST_CNT_IGNORED], c_ign);
     }
 }
+
+// Two instantiations: reads up to 160 bases (five 32-base blocks; held to 72 VGPRs = 7 waves per SIMD, which measured
+// 3 % faster than the 80 the allocator takes when left alone) and up to MLST_MAX_READ_LEN.
+__attribute__((amdgpu_waves_per_eu(7, 7)))
+__global__ __launch_bounds__(1024) void k_extend_160(const EngineDev* __restrict__ Ep, KParams P) { extend_body<5>(Ep, P); }
+__global__ __launch_bounds__(1024) void k_extend_320(const EngineDev* __restrict__ Ep, KParams P) { extend_body<RW / 2>(Ep, P); }
 
 // ---- DPP lane moves (gfx9 encodings).  update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): a lane whose
 // source is out of range, or whose row is masked off, keeps `old`.
@@ -2400,7 +2403,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         u32 mx = 0; for (auto& L : loci) mx = std::max(mx, L.n_alleles);
         int thr = mx <= 64 ? 64 : (mx <= 128 ? 128 : (mx <= 192 ? 192 : 256));
         const char* e1 = getenv("MLST_EXT_THREADS"); if (e1 && atoi(e1) >= 64 && atoi(e1) <= 1024 && atoi(e1) % 64 == 0) thr = atoi(e1);
-        int blocks = 1792 * 256 / thr;     // 7 waves per SIMD fit at the kernel's 68 VGPRs; the work queue balances the rest
+        int blocks = 1792 * 256 / thr;     // 7 waves per SIMD (k_extend_160 is held to 72 VGPRs); the work queue balances the rest
         const char* e2 = getenv("MLST_EXT_BLOCKS"); if (e2 && atoi(e2) > 0) blocks = atoi(e2);
         h->ext_threads = thr; h->ext_blocks = blocks;
         const char* e3 = getenv("MLST_SIEVE_BLOCKS"); if (e3 && atoi(e3) > 0) h->sieve_g_blocks = atoi(e3);
@@ -2514,8 +2517,8 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       hipLaunchKernelGGL(k_retain, dim3(1024), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
     { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
       const int thr = h->ext_threads, blocks = h->ext_blocks;
-      if (wpr <= 10) hipLaunchKernelGGL(k_extend<5>, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
-      else hipLaunchKernelGGL(k_extend<RW / 2>, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
+      if (wpr <= 10) hipLaunchKernelGGL(k_extend_160, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
+      else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
       hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, h->d_E); }
