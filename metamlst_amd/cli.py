@@ -17,7 +17,7 @@ import time
 
 from . import db as mdb
 from .engine import Engine, default_params
-from .fastq import text_chunks
+from .fastq import text_chunks, tile_fasta
 from .index import load_index
 from .merge import EngineMatcher, merge_folder
 from .typing import TypingArgs, log_table, sample_name, type_sample
@@ -29,6 +29,10 @@ def _type_parser(sub):
     p.add_argument("--alignments", action="store_true",
                    help="READS is a SAM / BAM made by `bowtie2 --very-sensitive-local -a --no-unal` against the database's "
                         "alleles (the reference's own input): hit accumulation as metamlst.py:101-130, pileup on the GPU")
+    p.add_argument("--contigs", action="store_true",
+                   help="READS is a FASTA of contigs or an assembled genome (the input of the reference's mlst.py): it is cut into "
+                        "overlapping windows (--tile LEN,STEP) that go through the same path as reads")
+    p.add_argument("--tile", default="150,25", metavar="LEN,STEP")
     p.add_argument("-2", dest="mates", help="second FASTQ of a paired-end sample")
     p.add_argument("-o", metavar="OUTPUT FOLDER", default="./out")
     p.add_argument("-d", "--database", metavar="DB PATH", required=True)
@@ -112,6 +116,11 @@ def run_type(a) -> int:
         from .samin import AlignmentSample
         smp = AlignmentSample(idx, targs).add_file(a.READS)
         return _finish_type(a, idx, database, targs, smp.stats(), lambda chosen: smp.pileup(eng, chosen))
+    if a.contigs:
+        read_len, stride = (int(x) for x in a.tile.split(","))
+        for chunk in tile_fasta(a.READS, read_len, stride, a.min_read_len):
+            eng.submit_fastq(chunk, paired=False)
+        return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)
     # FASTQ text goes to the GPU as is and is parsed there (mlst_submit_fastq).  Mates are unpaired reads for this
     # pipeline (bowtie2 -U), so a second file is simply submitted after the first.
     for path in [a.READS] + ([a.mates] if a.mates else []):

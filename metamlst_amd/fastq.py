@@ -77,3 +77,45 @@ def text_chunks(path: str, chunk_bytes: int = 256 << 20):
             carry = data[cut:]
     if carry.strip():
         yield carry
+
+
+def tile_fasta(path: str, read_len: int = 150, stride: int = 25, min_len: int = 50, chunk_reads: int = 500_000):
+    """Contigs / an assembled genome as input (the modality of the reference's mlst.py, which BLASTs contigs against
+    the alleles; BLAST is not in the tree -- here the contigs go through the same alignment path as reads): every
+    contig is cut into overlapping windows (read_len bases every stride bases, the last window flush with the contig
+    end), written as FASTQ text with Phred 40 and handed to Engine.submit_fastq in chunks.  Contigs shorter than
+    min_len are skipped, shorter than read_len become one read.  Read names: <contig index>_<0-based start>."""
+    if read_len < 1 or stride < 1:
+        raise ValueError("read_len and stride must be positive")
+
+    def contigs():
+        name, parts = None, []
+        with _open(path) as f:
+            for line in f:
+                if line.startswith(b">"):
+                    if name is not None:
+                        yield b"".join(parts)
+                    name, parts = line, []
+                elif name is not None:
+                    parts.append(line.strip())
+        if name is not None:
+            yield b"".join(parts)
+
+    out, n_out = [], 0
+    for ci, seq in enumerate(contigs()):
+        seq = seq.upper()
+        n = len(seq)
+        if n < min_len:
+            continue
+        starts = list(range(0, max(n - read_len, 0) + 1, stride))
+        if n > read_len and starts[-1] != n - read_len:
+            starts.append(n - read_len)
+        for st in starts:
+            w = seq[st:st + read_len]
+            out.append(b"@%d_%d\n%s\n+\n%s\n" % (ci, st, w, b"I" * len(w)))
+            n_out += 1
+            if n_out == chunk_reads:
+                yield b"".join(out)
+                out, n_out = [], 0
+    if out:
+        yield b"".join(out)

@@ -8,7 +8,7 @@ import pytest
 
 import fixtures as fx
 from metamlst_amd import synth
-from metamlst_amd.fastq import interleave, read_batches
+from metamlst_amd.fastq import interleave, read_batches, tile_fasta
 
 
 def write_fastq(path, bases, quals, gz=False):
@@ -33,6 +33,50 @@ def test_fastq_roundtrip_plain_gz_and_batches():
         assert got[0][3][3] == b"r3"
     pairs = list(interleave(d + "/a.fastq", d + "/a.fastq.gz", batch_pairs=100))[0]
     assert len(pairs[2]) - 1 == 50 and np.array_equal(pairs[0][:60], pairs[0][60:120])
+
+
+def test_tile_fasta_covers_every_base_of_every_contig():
+    rng = np.random.default_rng(5)
+    lens = [1000, 149, 150, 151, 49, 50, 333]
+    seqs = [synth._ACGT[rng.integers(0, 4, size=n)].tobytes() for n in lens]
+    d = tempfile.mkdtemp()
+    with open(d + "/c.fa", "wb") as f:
+        for k, s in enumerate(seqs):
+            f.write(b">c%d desc\n" % k + b"\n".join(s[i:i + 70].lower() if k == 0 else s[i:i + 70] for i in range(0, len(s), 70)) + b"\n")
+    text = b"".join(tile_fasta(d + "/c.fa", 150, 25, 50, chunk_reads=7))
+    recs = text.split(b"\n")[:-1]
+    assert len(recs) % 4 == 0
+    cover = [np.zeros(n, int) for n in lens]
+    for k in range(0, len(recs), 4):
+        ci, st = (int(x) for x in recs[k][1:].split(b"_"))
+        w = recs[k + 1]
+        assert recs[k + 2] == b"+" and recs[k + 3] == b"I" * len(w)
+        assert w == seqs[ci][st:st + len(w)] and len(w) == min(150, lens[ci])
+        cover[ci][st:st + len(w)] += 1
+    assert cover[4].sum() == 0                                   # 49 bases: below min_len
+    for ci in (0, 1, 2, 3, 5, 6):
+        assert cover[ci].min() >= 1
+    assert cover[0][200:800].min() == 6                          # 150 / 25 windows over every interior base
+
+
+@pytest.mark.gpu
+def test_cli_types_an_assembled_genome_from_its_contigs():
+    """--contigs: the genome itself (three contigs, one reverse-complemented) instead of reads; the planted ST is called."""
+    from metamlst_amd.cli import main
+    db, idx = fx.ecoli_small(80)
+    g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][11], size=200_000)
+    comp = np.zeros(256, np.uint8)
+    for x, y in zip(b"ACGT", b"TGCA"):
+        comp[x] = y
+    parts = [g[:70_000], comp[g[70_000:140_000]][::-1], g[140_000:]]
+    d = tempfile.mkdtemp()
+    with open(d + "/asm12.fna", "wb") as f:
+        for k, s in enumerate(parts):
+            f.write(b">contig%d\n" % k + s.tobytes() + b"\n")
+    assert main(["type", d + "/asm12.fna", "--contigs", "-d", db.path, "-o", d + "/out", "--quiet"]) == 0
+    assert main(["merge", d + "/out", "-d", db.path]) == 0
+    rep = open(d + "/out/merged/ecoli_report.txt").read().splitlines()
+    assert rep[1].split("\t")[0] == "12" and rep[1].split("\t")[1] == "100.0"
 
 
 @pytest.mark.gpu
