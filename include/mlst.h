@@ -99,6 +99,18 @@ int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uint8_t* quals
  * bowtie2 [NOT IN TREE].  n_reads_out (optional) receives the number of records found. */
 int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int paired, uint64_t* n_reads_out);
 
+/* The same from BGZF-compressed FASTQ (bgzip; a series of independent <= 64 KiB deflate blocks): the COMPRESSED bytes
+ * cross PCIe, every block is inflated by one GPU thread (csrc/inflate_dev.h), the text is parsed as above.  A chunk is
+ * a run of whole BGZF blocks cut anywhere between blocks; a record that straddles two chunks is completed by the next
+ * call; the last chunk of a file is passed with final_chunk != 0 and must end with a whole record.  Block CRCs are
+ * not verified (the inflated size is).  Plain gzip has no block structure to parallelise: inflate it on the host and
+ * use mlst_submit_fastq. */
+int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out);
+
+/* Test hook: the deflate decoder of the call above run on the HOST on one raw deflate stream (returns 0 or a negative
+ * code of csrc/inflate_dev.h; *produced = bytes written).  Not a data path. */
+int mlst_selftest_inflate(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced);
+
 /* Same, with the three arrays already in DEVICE memory (GPU-side FASTQ decode feeds this). */
 int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
                              const uint64_t* d_off, uint64_t n_reads, uint32_t max_len, int paired);

@@ -17,7 +17,7 @@ import time
 
 from . import db as mdb
 from .engine import Engine, default_params
-from .fastq import text_chunks, tile_fasta
+from .fastq import bgzf_chunks, is_bgzf, text_chunks, tile_fasta
 from .index import load_index
 from .merge import EngineMatcher, merge_folder
 from .typing import TypingArgs, log_table, sample_name, type_sample
@@ -124,6 +124,10 @@ def run_type(a) -> int:
     # FASTQ text goes to the GPU as is and is parsed there (mlst_submit_fastq).  Mates are unpaired reads for this
     # pipeline (bowtie2 -U), so a second file is simply submitted after the first.
     for path in [a.READS] + ([a.mates] if a.mates else []):
+        if is_bgzf(path):      # bgzip'd FASTQ: the compressed blocks go to the GPU and are inflated there
+            for chunk, last in bgzf_chunks(path):
+                eng.submit_fastq_bgzf(chunk, final=last, paired=False)
+            continue
         for chunk in text_chunks(path):
             eng.submit_fastq(chunk, paired=False)
     return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)

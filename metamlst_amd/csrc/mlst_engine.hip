@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "mlst.h"
+#include "inflate_dev.h"
 #include "mlst_policy.h"
 
 typedef unsigned long long u64;
@@ -756,6 +757,18 @@ __global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ f
     }
 }
 
+// ------------------------------------------------------------------ BGZF -> text (one thread per <= 64 KiB deflate block)
+struct BgzfBlk { u64 in_off, out_off; u32 in_len, out_len; };
+__global__ __launch_bounds__(64) void k_inflate(const u8* __restrict__ comp, const BgzfBlk* __restrict__ blk, u32 n_blk, u8* __restrict__ out, u32* __restrict__ err /* [0] = 1 + first bad block, [1] = its code */) {
+    __shared__ mlst_inflate::Tables s_tb[64];     // Huffman tables of the 64 streams: LDS latency instead of scratch-memory latency per code bit
+    const u32 i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_blk) return;
+    const BgzfBlk B = blk[i];
+    uint64_t produced = 0;
+    int rc = mlst_inflate::inflate_raw(comp + B.in_off, B.in_len, out + B.out_off, B.out_len, &produced, &s_tb[threadIdx.x]);
+    if (rc == mlst_inflate::OK && produced != B.out_len) rc = mlst_inflate::E_SHORT;
+    if (rc != mlst_inflate::OK && atomicCAS(&err[0], 0u, i + 1u) == 0u) err[1] = (u32)(-rc);
+}
 // ------------------------------------------------------------------ FASTQ text -> packed reads (GPU parser)
 #define FQ_BLOCK 4096        // bytes of text per workgroup
 // pass A: newlines per FQ_BLOCK bytes
@@ -769,15 +782,15 @@ __global__ __launch_bounds__(256) void k_fq_count(const u8* __restrict__ text, u
     if (threadIdx.x == 0) blk_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
 }
 // pass B: exclusive scan of the block counts (one workgroup; n_blocks is small: 4 GB of text = 1 M blocks)
-__global__ __launch_bounds__(1024) void k_fq_scan(u32* __restrict__ blk_count, u32 n_blocks, u64* __restrict__ n_lines_out, u64 n_bytes, const u8* __restrict__ text) {
+__global__ __launch_bounds__(1024) void k_fq_scan(u32* __restrict__ blk_count, u32 n_blocks, u64* __restrict__ n_lines_out, u64 n_bytes, const u8* __restrict__ text, int count_partial) {
     __shared__ u64 s_part[1024];
     u32 per = (n_blocks + 1023) / 1024; u32 lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
     u64 sum = 0; for (u32 i = lo; i < hi; i++) sum += blk_count[i];
     s_part[threadIdx.x] = sum;
     __syncthreads();
     if (threadIdx.x == 0) { u64 run = 0; for (int i = 0; i < 1024; i++) { u64 t = s_part[i]; s_part[i] = run; run += t; }
-                            // a last line without a trailing newline still counts as a line
-                            *n_lines_out = run + ((n_bytes > 0 && text[n_bytes - 1] != '\n') ? 1 : 0); }
+                            // a last line without a trailing newline still counts as a line (unless more text follows in the next chunk)
+                            *n_lines_out = run + ((count_partial && n_bytes > 0 && text[n_bytes - 1] != '\n') ? 1 : 0); }
     __syncthreads();
     u64 run = s_part[threadIdx.x];
     for (u32 i = lo; i < hi; i++) { u32 t = blk_count[i]; blk_count[i] = (u32)run; run += t; }     // < 2^32 lines per chunk (checked on the host)
@@ -1987,6 +2000,8 @@ struct mlst_handle {
     int ext_threads = 256, ext_blocks = 1024;    // k_extend launch shape (set in mlst_load_reference)
     int sieve_g_blocks = 256 * 5;                // k_sieve_q<.,false> grid (MLST_SIEVE_BLOCKS overrides it)
     u8* d_fq_text = nullptr; u64 cap_fq_text = 0; u32* d_fq_blk = nullptr; u64 cap_fq_blk = 0;
+    // BGZF input: compressed bytes + block descriptors on the device; the partial record at the end of a chunk (carry)
+    u8* d_bgzf = nullptr; u64 cap_bgzf = 0; void* d_bgzf_blk = nullptr; u64 cap_bgzf_blk = 0; u8* d_fq_carry = nullptr; u64 cap_fq_carry = 0, fq_carry_len = 0;
     u64* d_fq_lines = nullptr; u64 cap_fq_lines = 0; u64* d_fq_soff = nullptr; u64* d_fq_qoff = nullptr; u64 cap_fq_reads = 0; u64* d_fq_meta = nullptr;
     // pileup scratch
     int* d_locus_chosen = nullptr; u64* d_locus_colbase = nullptr; u64* d_pl_list = nullptr; u8* d_tb = nullptr;
@@ -2145,6 +2160,7 @@ extern "C" void mlst_destroy(mlst_handle* h) {
     if (h->h_pin) hipHostFree(h->h_pin);
     hipFree(h->d_cand); hipFree(h->d_in_bases); hipFree(h->d_in_quals); hipFree(h->d_in_off);
     hipFree(h->d_fq_text); hipFree(h->d_fq_blk); hipFree(h->d_fq_lines); hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); hipFree(h->d_fq_meta);
+    hipFree(h->d_bgzf); hipFree(h->d_bgzf_blk); hipFree(h->d_fq_carry); h->d_bgzf = nullptr; h->d_bgzf_blk = nullptr; h->d_fq_carry = nullptr; h->cap_bgzf = h->cap_bgzf_blk = h->cap_fq_carry = h->fq_carry_len = 0;
     hipFree(h->d_packed); hipFree(h->d_qrows); hipFree(h->d_lens); hipFree(h->d_counts); hipFree(h->d_dist); hipFree(h->d_query);
     for (auto* g : {&h->g_submit, &h->g_typing}) if (g->exec) hipGraphExecDestroy(g->exec);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -2158,7 +2174,7 @@ static inline int base_code(u8 c) {
 static int reset_sample_state(mlst_handle* h) {
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, h->stats_zero_bytes, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_stats + h->off_first, 0xFF, h->stats_bytes - h->off_first, h->stream));
-    h->reads_seen = 0;
+    h->reads_seen = 0; h->fq_carry_len = 0;
     return MLST_OK;
 }
 
@@ -2574,37 +2590,43 @@ extern "C" int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uin
     return mlst_submit_reads_device(h, h->d_in_bases, h->d_in_quals, (const uint64_t*)h->d_in_off, n_reads, max_len, paired);
 }
 
-extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int paired, uint64_t* n_reads_out) {
-    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
-    if (n_reads_out) *n_reads_out = 0;
-    if (n_bytes == 0) return MLST_OK;
-    if (!text) return fail(h, MLST_E_INVALID, "NULL argument");
-    if (n_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
-    hipSetDevice(h->device);
+// FASTQ text in h->d_fq_text[0 .. n_bytes) -> packed reads -> pass 1.  whole: the text consists of whole records; else
+// the partial record at its end is kept (h->d_fq_carry) for the next chunk.
+static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, uint64_t* n_reads_out) {
     const u64 n_blocks = (n_bytes + FQ_BLOCK - 1) / FQ_BLOCK;
-    hipStreamSynchronize(h->stream);     // the previous chunk may still be read
-    if (h->cap_fq_text < n_bytes) { hipFree(h->d_fq_text); h->d_fq_text = nullptr; HIPCHK(h, dmalloc(&h->d_fq_text, n_bytes + 16)); h->cap_fq_text = n_bytes; }
     if (h->cap_fq_blk < n_blocks) { hipFree(h->d_fq_blk); h->d_fq_blk = nullptr; HIPCHK(h, dmalloc(&h->d_fq_blk, n_blocks + 1)); h->cap_fq_blk = n_blocks; }
-    if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
-    HIPCHK(h, hipMemcpyAsync(h->d_fq_text, text, n_bytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_fq_meta, 0, 32, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_fq_meta, 0, 16, h->stream));
     Prof pf(h, 6);
     hipLaunchKernelGGL(k_fq_count, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_blk);
-    hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, h->stream, h->d_fq_blk, (u32)n_blocks, h->d_fq_meta, (u64)n_bytes, h->d_fq_text);
+    hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, h->stream, h->d_fq_blk, (u32)n_blocks, h->d_fq_meta, (u64)n_bytes, h->d_fq_text, whole ? 1 : 0);
     u64 n_lines = 0;
     HIPCHK(h, hipMemcpyAsync(&n_lines, h->d_fq_meta, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n_lines >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "more than 2^32 lines in one FASTQ chunk");
-    if (n_lines % 4 != 0) return fail(h, MLST_E_INVALID, "FASTQ chunk holds %llu lines: not a whole number of 4-line records", (unsigned long long)n_lines);
+    if (whole && n_lines % 4 != 0) return fail(h, MLST_E_INVALID, "FASTQ chunk holds %llu lines: not a whole number of 4-line records", (unsigned long long)n_lines);
     const u64 n_reads = n_lines / 4;
-    if (n_reads == 0) return MLST_OK;
     if (h->cap_fq_lines < n_lines + 2) { hipFree(h->d_fq_lines); h->d_fq_lines = nullptr; HIPCHK(h, dmalloc(&h->d_fq_lines, n_lines + 2)); h->cap_fq_lines = n_lines + 2; }
+    hipLaunchKernelGGL(k_fq_lines, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_blk, h->d_fq_lines);
+    h->fq_carry_len = 0;
+    if (!whole) {      // text behind the last whole record waits for the next chunk
+        u64 end_off = 0;
+        HIPCHK(h, hipMemcpyAsync(&end_off, h->d_fq_lines + 4 * n_reads, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (end_off > n_bytes) return fail(h, MLST_E_HIP, "FASTQ line table inconsistent");
+        const u64 keep = n_bytes - end_off;
+        if (keep) {
+            if (h->cap_fq_carry < keep) { hipFree(h->d_fq_carry); h->d_fq_carry = nullptr; HIPCHK(h, dmalloc(&h->d_fq_carry, keep + 16)); h->cap_fq_carry = keep; }
+            HIPCHK(h, hipMemcpyAsync(h->d_fq_carry, h->d_fq_text + end_off, keep, hipMemcpyDeviceToDevice, h->stream));
+            h->fq_carry_len = keep;
+        }
+        n_bytes = end_off; n_lines = 4 * n_reads;
+    }
+    if (n_reads == 0) return MLST_OK;
     if (h->cap_fq_reads < n_reads) { hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); h->d_fq_soff = h->d_fq_qoff = nullptr;
                                      HIPCHK(h, dmalloc(&h->d_fq_soff, n_reads)); HIPCHK(h, dmalloc(&h->d_fq_qoff, n_reads)); h->cap_fq_reads = n_reads; }
     // lengths are needed before the packed buffers can be sized: worst-case row width first, then the real one
     int rc = ensure_pack_buffers(h, n_reads, 2, 8); if (rc) return rc;
     u32* d_flags = reinterpret_cast<u32*>(h->d_fq_meta + 1);
-    hipLaunchKernelGGL(k_fq_lines, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_blk, h->d_fq_lines);
     hipLaunchKernelGGL(k_fq_records, dim3(grid_for(n_reads, 256)), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_lines, n_lines, n_reads,
                        h->d_fq_soff, h->d_fq_qoff, h->d_lens, d_flags);
     u32 flags[2] = {0, 0};
@@ -2628,6 +2650,84 @@ extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n
     HIPCHK(h, hipGetLastError());
     if (n_reads_out) *n_reads_out = n_reads;
     return mlst_submit_packed_device(h, h->d_packed, h->d_qrows, h->d_lens, n_reads, wpr, qstride, paired);
+}
+
+extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int paired, uint64_t* n_reads_out) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (n_reads_out) *n_reads_out = 0;
+    if (n_bytes == 0) return MLST_OK;
+    if (!text) return fail(h, MLST_E_INVALID, "NULL argument");
+    if (n_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
+    if (h->fq_carry_len) return fail(h, MLST_E_INVALID, "a BGZF stream is open (its last chunk was not marked final)");
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);     // the previous chunk may still be read
+    if (h->cap_fq_text < n_bytes) { hipFree(h->d_fq_text); h->d_fq_text = nullptr; HIPCHK(h, dmalloc(&h->d_fq_text, n_bytes + 16)); h->cap_fq_text = n_bytes; }
+    if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
+    HIPCHK(h, hipMemcpyAsync(h->d_fq_text, text, n_bytes, hipMemcpyHostToDevice, h->stream));
+    return fastq_pipeline(h, n_bytes, paired, true, n_reads_out);
+}
+
+// BGZF framing (SAM spec 4.1): gzip member with an extra subfield 'B','C' holding the block size - 1; deflate data; CRC32, ISIZE
+static bool bgzf_block(const u8* p, u64 left, u64& total, u64& cdata_off, u64& cdata_len, u32& isize) {
+    if (left < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
+    const u32 xlen = (u32)p[10] | ((u32)p[11] << 8);
+    if (left < 12ull + xlen) return false;
+    u32 bsize = 0; bool found = false;
+    for (u32 o = 0; o + 4 <= xlen; ) {
+        const u8* sf = p + 12 + o; const u32 slen = (u32)sf[2] | ((u32)sf[3] << 8);
+        if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && o + 6 <= xlen) { bsize = (u32)sf[4] | ((u32)sf[5] << 8); found = true; }
+        o += 4 + slen;
+    }
+    if (!found) return false;
+    total = (u64)bsize + 1;
+    if (total > left || total < 12ull + xlen + 8) return false;
+    cdata_off = 12ull + xlen; cdata_len = total - cdata_off - 8;
+    isize = (u32)p[total - 4] | ((u32)p[total - 3] << 8) | ((u32)p[total - 2] << 16) | ((u32)p[total - 1] << 24);
+    return true;
+}
+
+extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (n_reads_out) *n_reads_out = 0;
+    if (n_bytes && !data) return fail(h, MLST_E_INVALID, "NULL argument");
+    if (n_bytes >= (1ull << 36)) return fail(h, MLST_E_LIMIT, "BGZF chunk too large");
+    hipSetDevice(h->device);
+    std::vector<BgzfBlk> blks;
+    u64 text_bytes = h->fq_carry_len;
+    for (u64 off = 0; off < n_bytes; ) {
+        u64 total, coff, clen; u32 isize;
+        if (!bgzf_block(data + off, n_bytes - off, total, coff, clen, isize)) return fail(h, MLST_E_INVALID, "not a whole BGZF block at byte %llu of the chunk", (unsigned long long)off);
+        if (isize > 65536) return fail(h, MLST_E_INVALID, "BGZF block at byte %llu claims %u bytes of data", (unsigned long long)off, isize);
+        if (isize) { BgzfBlk b; b.in_off = off + coff; b.in_len = (u32)clen; b.out_off = text_bytes; b.out_len = isize; blks.push_back(b); text_bytes += isize; }
+        off += total;
+    }
+    if (text_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
+    if (text_bytes == 0) return MLST_OK;
+    hipStreamSynchronize(h->stream);     // the previous chunk may still be read
+    if (h->cap_fq_text < text_bytes) { hipFree(h->d_fq_text); h->d_fq_text = nullptr; HIPCHK(h, dmalloc(&h->d_fq_text, text_bytes + 16)); h->cap_fq_text = text_bytes; }
+    if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
+    if (h->fq_carry_len) HIPCHK(h, hipMemcpyAsync(h->d_fq_text, h->d_fq_carry, h->fq_carry_len, hipMemcpyDeviceToDevice, h->stream));
+    if (!blks.empty()) {
+        if (h->cap_bgzf < n_bytes) { hipFree(h->d_bgzf); h->d_bgzf = nullptr; HIPCHK(h, dmalloc(&h->d_bgzf, n_bytes + 16)); h->cap_bgzf = n_bytes; }
+        if (h->cap_bgzf_blk < blks.size()) { hipFree(h->d_bgzf_blk); h->d_bgzf_blk = nullptr; BgzfBlk* pb = nullptr; HIPCHK(h, dmalloc(&pb, (u64)blks.size())); h->d_bgzf_blk = pb; h->cap_bgzf_blk = blks.size(); }
+        HIPCHK(h, hipMemcpyAsync(h->d_bgzf, data, n_bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_bgzf_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->stream));
+        u32* d_err = reinterpret_cast<u32*>(h->d_fq_meta + 2);
+        HIPCHK(h, hipMemsetAsync(d_err, 0, 8, h->stream));
+        hipLaunchKernelGGL(k_inflate, dim3((u32)((blks.size() + 63) / 64)), dim3(64), 0, h->stream, h->d_bgzf, (const BgzfBlk*)h->d_bgzf_blk, (u32)blks.size(), h->d_fq_text, d_err);
+        u32 err[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));      // also: blks / data may be released by the caller after this
+        if (err[0]) return fail(h, MLST_E_INVALID, "corrupt deflate data in BGZF block %u of the chunk (code %u)", err[0] - 1, err[1]);
+    }
+    return fastq_pipeline(h, text_bytes, paired, final_chunk != 0, n_reads_out);
+}
+
+// the decoder of k_inflate run on the host: a test hook (tests/test_inflate.py compares it with zlib without a GPU)
+extern "C" int mlst_selftest_inflate(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced) {
+    uint64_t p = 0; mlst_inflate::Tables tb; const int rc = mlst_inflate::inflate_raw(in, n_in, out, cap, &p, &tb);
+    if (produced) *produced = p;
+    return rc;
 }
 
 // one D2H copy of the whole statistics block into pinned memory, one synchronisation

@@ -85,6 +85,8 @@ def load_library(path: str | None = None):
         "mlst_load_reference": (C.c_int, [H, u8p, u64p, u32p, u32p, i32p, C.c_uint32]),
         "mlst_submit_reads": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_int]),
         "mlst_submit_fastq": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
+        "mlst_submit_fastq_bgzf": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+        "mlst_selftest_inflate": (C.c_int, [u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
         "mlst_submit_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_int]),
         "mlst_pack_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, u32p, u8p, u16p, C.c_uint32, C.c_uint32]),
         "mlst_submit_packed_device": (C.c_int, [H, u32p, u8p, u16p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
@@ -183,6 +185,15 @@ class Engine:
         buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
         n = C.c_uint64()
         self._check(self.lib.mlst_submit_fastq(self._h, _ptr(buf) if buf.size else None, buf.size, int(paired), C.byref(n)), "mlst_submit_fastq")
+        return int(n.value)
+
+    def submit_fastq_bgzf(self, data, final: bool, paired: bool = False) -> int:
+        """Pass 1 from BGZF-compressed FASTQ: a run of whole BGZF blocks (fastq.bgzf_chunks), inflated and parsed on the GPU.
+        final marks the last chunk of the file.  Returns the number of records completed by this chunk."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+        n = C.c_uint64()
+        self._check(self.lib.mlst_submit_fastq_bgzf(self._h, _ptr(buf) if buf.size else None, buf.size, int(final), int(paired), C.byref(n)),
+                    "mlst_submit_fastq_bgzf")
         return int(n.value)
 
     def submit_reads_device(self, d_bases: int, d_quals: int, d_off: int, n_reads: int, max_len: int, paired: bool = False):

@@ -119,3 +119,55 @@ def tile_fasta(path: str, read_len: int = 150, stride: int = 25, min_len: int = 
                 out, n_out = [], 0
     if out:
         yield b"".join(out)
+
+
+def _bgzf_block_size(buf, off: int) -> int:
+    """Total size of the BGZF block that starts at buf[off], 0 if the header is incomplete, -1 if it is not BGZF."""
+    if len(buf) - off < 18:
+        return 0
+    if buf[off] != 0x1F or buf[off + 1] != 0x8B or buf[off + 2] != 8 or not (buf[off + 3] & 4):
+        return -1
+    xlen = buf[off + 10] | (buf[off + 11] << 8)
+    if len(buf) - off < 12 + xlen:
+        return 0
+    o = 0
+    while o + 4 <= xlen:
+        p = off + 12 + o
+        slen = buf[p + 2] | (buf[p + 3] << 8)
+        if buf[p] == 66 and buf[p + 1] == 67 and slen == 2:
+            return (buf[p + 4] | (buf[p + 5] << 8)) + 1
+        o += 4 + slen
+    return -1
+
+
+def is_bgzf(path: str) -> bool:
+    with open(path, "rb") as f:
+        return _bgzf_block_size(f.read(4096), 0) > 0
+
+
+def bgzf_chunks(path: str, chunk_bytes: int = 256 << 20):
+    """Yield (compressed bytes holding whole BGZF blocks, is_last) for Engine.submit_fastq_bgzf.  The only host work is
+    walking the block headers; inflating and parsing happen on the GPU."""
+    carry = b""
+    pending = None
+    with open(path, "rb") as f:
+        while True:
+            block = f.read(chunk_bytes)
+            data = carry + block
+            off = 0
+            while True:
+                n = _bgzf_block_size(data, off)
+                if n < 0:
+                    raise ValueError("%s: not a BGZF block at byte offset %d of a chunk" % (path, off))
+                if n == 0 or off + n > len(data):
+                    break
+                off += n
+            if pending is not None:
+                yield pending, False
+            pending = data[:off] if off else None
+            carry = data[off:]
+            if not block:
+                break
+    if carry:
+        raise ValueError("%s: truncated BGZF block at the end of the file" % path)
+    yield (pending if pending is not None else b""), True

@@ -144,6 +144,62 @@ def test_gpu_fastq_parser_equals_host_parser():
 
 
 @pytest.mark.gpu
+def test_bgzf_fastq_inflated_on_the_gpu_equals_the_text_path():
+    """mlst_submit_fastq_bgzf: the compressed blocks are inflated by k_inflate and parsed on the GPU; chunks are cut between
+    blocks, i.e. in the middle of records, which the next chunk completes.  Same statistics as the uncompressed text."""
+    import zlib
+    from bam_writer import _bgzf_block
+    from metamlst_amd.engine import Engine, MlstError
+    from metamlst_amd.fastq import bgzf_chunks
+    from metamlst_amd.cli import main
+    db, idx = fx.ecoli_small(60)
+    rng = np.random.default_rng(9)
+    g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][4], size=80_000)
+    recs = []
+    for k in range(9000):
+        L = int(rng.choice([150, 150, 101, 250, 60]))
+        at = int(rng.integers(0, len(g) - L))
+        recs.append(b"@read%d/1 x\n" % k + g[at:at + L].tobytes() + b"\n+\n" + bytes((rng.integers(2, 42, size=L)).astype(np.uint8) + 33) + b"\n")
+    text = b"".join(recs)
+    eng = Engine(0)
+    eng.load_reference(idx)
+    assert eng.submit_fastq(text) == len(recs)
+    want = eng.stats()
+    d = tempfile.mkdtemp()
+    sizes = [65280, 1000, 30000, 17, 65280, 4096]
+    blocks, at, k = [], 0, 0
+    while at < len(text):
+        n = sizes[k % len(sizes)]; k += 1
+        blocks.append(_bgzf_block(text[at:at + n])); at += n
+        if k % 5 == 0:
+            blocks.append(_bgzf_block(b""))          # empty blocks are legal anywhere
+    blocks.append(_bgzf_block(b""))
+    path = d + "/s5.fastq.gz"
+    open(path, "wb").write(b"".join(blocks))
+    for chunk_bytes in (1 << 30, 90_000):
+        eng.reset_sample()
+        chunks = list(bgzf_chunks(path, chunk_bytes=chunk_bytes))
+        n = sum(eng.submit_fastq_bgzf(c, final=last) for c, last in chunks)
+        assert n == len(recs) and (chunk_bytes > 1 << 20 or len(chunks) > 5)
+        fx.assert_stats_equal(eng.stats(), want)
+    # a corrupt block, a chunk that is not whole blocks, a file that ends inside a record
+    eng.reset_sample()
+    bad = bytearray(b"".join(blocks[:3]))
+    bad[len(blocks[0]) + 40] ^= 0x5A
+    with pytest.raises(MlstError, match="corrupt deflate|not a whole number"):
+        eng.submit_fastq_bgzf(bytes(bad), final=True)
+    eng.reset_sample()
+    with pytest.raises(MlstError, match="not a whole BGZF block"):
+        eng.submit_fastq_bgzf(b"".join(blocks[:2])[:-3], final=False)
+    eng.reset_sample()
+    with pytest.raises(MlstError, match="4-line records"):
+        eng.submit_fastq_bgzf(_bgzf_block(text[:len(recs[0]) + 7]), final=True)
+    # the CLI takes the bgzip'd file as it is
+    assert main(["type", path, "-d", db.path, "-o", d + "/out", "--quiet"]) == 0
+    assert os.path.exists(d + "/out/s5.nfo")
+
+
+@pytest.mark.gpu
 def test_cli_alignment_input_sam_and_bam_end_to_end():
     """`type --alignments` on a SAM and on the same records as BAM: reads tiled over the alleles of a known ST (perfect
     local alignments, AS = 2 x length) plus weaker secondary records on a neighbouring allele -> the planted ST."""

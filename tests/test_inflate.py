@@ -1,0 +1,79 @@
+"""The deflate decoder of the BGZF path (csrc/inflate_dev.h) against zlib, on the host through its test hook, and the
+BGZF chunker; the GPU kernel that runs the same code per block is checked in test_fastq_cli.py."""
+import ctypes as C
+import os
+import tempfile
+import zlib
+
+import numpy as np
+import pytest
+
+from metamlst_amd import engine
+from metamlst_amd.fastq import bgzf_chunks, is_bgzf
+from bam_writer import _bgzf_block
+
+
+def inflate(raw: bytes, cap: int):
+    lib = engine.load_library()
+    src = np.frombuffer(raw, np.uint8) if raw else np.zeros(1, np.uint8)
+    out = np.zeros(max(cap, 1), np.uint8)
+    n = C.c_uint64()
+    rc = lib.mlst_selftest_inflate(src.ctypes.data_as(C.POINTER(C.c_uint8)), len(raw), out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n))
+    return rc, out[:int(n.value)].tobytes()
+
+
+def deflate(data: bytes, level: int, strategy: int = zlib.Z_DEFAULT_STRATEGY) -> bytes:
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    return c.compress(data) + c.flush()
+
+
+def payloads():
+    rng = np.random.default_rng(7)
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (k, bytes(rng.choice(list(b"ACGT"), 150).astype(np.uint8)), bytes((rng.integers(2, 41, 150) + 33).astype(np.uint8)))
+                  for k in range(180))
+    return [b"", b"A", b"abc" * 5000, bytes(rng.integers(0, 256, 40000, dtype=np.uint8)), fq[:65280], bytes(60000), b"ACGT" * 16000 + fq[:1000]]
+
+
+@pytest.mark.parametrize("level,strategy", [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                                             (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)])
+def test_decoder_equals_zlib(level, strategy):
+    for data in payloads():
+        rc, got = inflate(deflate(data, level, strategy), len(data))
+        assert rc == 0 and got == data
+
+
+def test_decoder_rejects_damage_without_reading_or_writing_out_of_bounds():
+    rng = np.random.default_rng(11)
+    data = payloads()[4]
+    raw = deflate(data, 6)
+    assert inflate(raw, len(data) - 1)[0] < 0            # output too small
+    assert inflate(raw[:len(raw) // 2], len(data))[0] < 0   # input cut short
+    for _ in range(300):                                  # random corruption: any return code, but it has to return
+        bad = bytearray(raw)
+        for _ in range(int(rng.integers(1, 6))):
+            bad[int(rng.integers(len(bad)))] = int(rng.integers(256))
+        rc, got = inflate(bytes(bad), len(data))
+        assert rc <= 0 and len(got) <= len(data)
+    assert inflate(b"\x07", 10)[0] < 0                   # block type 3
+
+
+def test_bgzf_chunks_cut_between_blocks():
+    rng = np.random.default_rng(3)
+    text = bytes(rng.choice(list(b"ACGT\n"), 400000).astype(np.uint8))
+    d = tempfile.mkdtemp()
+    blocks = [_bgzf_block(text[i:i + 30000]) for i in range(0, len(text), 30000)] + [_bgzf_block(b"")]
+    with open(d + "/t.gz", "wb") as f:
+        f.write(b"".join(blocks))
+    assert is_bgzf(d + "/t.gz")
+    import gzip
+    with gzip.open(d + "/plain.gz", "wb") as f:
+        f.write(text)
+    assert not is_bgzf(d + "/plain.gz")
+    got = list(bgzf_chunks(d + "/t.gz", chunk_bytes=50000))
+    assert [last for _, last in got] == [False] * (len(got) - 1) + [True] and len(got) > 3
+    assert b"".join(c for c, _ in got) == b"".join(blocks)
+    assert zlib.decompress(b"".join(c for c, _ in got), 31) == text[:30000]      # first member decodes
+    with open(d + "/cut.gz", "wb") as f:
+        f.write(b"".join(blocks)[:-5])
+    with pytest.raises(ValueError, match="truncated"):
+        list(bgzf_chunks(d + "/cut.gz"))
