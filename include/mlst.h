@@ -103,9 +103,12 @@ int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int
  * cross PCIe, every block is inflated by one GPU thread (csrc/inflate_dev.h), the text is parsed as above.  A chunk is
  * a run of whole BGZF blocks cut anywhere between blocks; a record that straddles two chunks is completed by the next
  * call; the last chunk of a file is passed with final_chunk != 0 and must end with a whole record.  Block CRCs are
- * not verified (the inflated size is).  Plain gzip has no block structure to parallelise: inflate it on the host and
- * use mlst_submit_fastq. */
-int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out);
+ * not verified (the inflated size is).  With n_consumed_out != NULL a non-final buffer may also end inside a block:
+ * the call takes the whole blocks, reports their size, and the caller passes the rest again in front of the next
+ * buffer (so a reader never has to walk the block headers itself).  Plain gzip has no block structure to parallelise:
+ * inflate it on the host and use mlst_submit_fastq. */
+int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out,
+                           uint64_t* n_consumed_out);
 
 /* Test hook: the deflate decoder of the call above run on the HOST on one raw deflate stream (returns 0 or a negative
  * code of csrc/inflate_dev.h; *produced = bytes written).  Not a data path. */

@@ -17,7 +17,7 @@ import time
 
 from . import db as mdb
 from .engine import Engine, default_params
-from .fastq import bgzf_chunks, is_bgzf, text_chunks, tile_fasta
+from .fastq import is_bgzf, text_chunks, tile_fasta
 from .index import load_index
 from .merge import EngineMatcher, merge_folder
 from .typing import TypingArgs, log_table, sample_name, type_sample
@@ -125,8 +125,7 @@ def run_type(a) -> int:
     # pipeline (bowtie2 -U), so a second file is simply submitted after the first.
     for path in [a.READS] + ([a.mates] if a.mates else []):
         if is_bgzf(path):      # bgzip'd FASTQ: the compressed blocks go to the GPU and are inflated there
-            for chunk, last in bgzf_chunks(path):
-                eng.submit_fastq_bgzf(chunk, final=last, paired=False)
+            eng.submit_fastq_bgzf_file(path, paired=False)
             continue
         for chunk in text_chunks(path):
             eng.submit_fastq(chunk, paired=False)

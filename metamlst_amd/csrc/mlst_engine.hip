@@ -2686,9 +2686,11 @@ static bool bgzf_block(const u8* p, u64 left, u64& total, u64& cdata_off, u64& c
     return true;
 }
 
-extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out) {
+extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out,
+                                      uint64_t* n_consumed_out) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     if (n_reads_out) *n_reads_out = 0;
+    if (n_consumed_out) *n_consumed_out = 0;
     if (n_bytes && !data) return fail(h, MLST_E_INVALID, "NULL argument");
     if (n_bytes >= (1ull << 36)) return fail(h, MLST_E_LIMIT, "BGZF chunk too large");
     hipSetDevice(h->device);
@@ -2696,12 +2698,18 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
     u64 text_bytes = h->fq_carry_len;
     for (u64 off = 0; off < n_bytes; ) {
         u64 total, coff, clen; u32 isize;
-        if (!bgzf_block(data + off, n_bytes - off, total, coff, clen, isize)) return fail(h, MLST_E_INVALID, "not a whole BGZF block at byte %llu of the chunk", (unsigned long long)off);
+        if (!bgzf_block(data + off, n_bytes - off, total, coff, clen, isize)) {
+            // a block cut off by the end of the buffer is left to the caller when it asked how much was taken (and more is to come)
+            const bool cut = n_bytes - off < 18 || (data[off] == 0x1f && data[off + 1] == 0x8b && data[off + 2] == 8 && (data[off + 3] & 4));
+            if (n_consumed_out && !final_chunk && cut) { n_bytes = off; break; }
+            return fail(h, MLST_E_INVALID, "not a whole BGZF block at byte %llu of the chunk", (unsigned long long)off);
+        }
         if (isize > 65536) return fail(h, MLST_E_INVALID, "BGZF block at byte %llu claims %u bytes of data", (unsigned long long)off, isize);
         if (isize) { BgzfBlk b; b.in_off = off + coff; b.in_len = (u32)clen; b.out_off = text_bytes; b.out_len = isize; blks.push_back(b); text_bytes += isize; }
         off += total;
     }
     if (text_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
+    if (n_consumed_out) *n_consumed_out = n_bytes;
     if (text_bytes == 0) return MLST_OK;
     hipStreamSynchronize(h->stream);     // the previous chunk may still be read
     if (h->cap_fq_text < text_bytes) { hipFree(h->d_fq_text); h->d_fq_text = nullptr; HIPCHK(h, dmalloc(&h->d_fq_text, text_bytes + 16)); h->cap_fq_text = text_bytes; }

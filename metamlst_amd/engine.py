@@ -85,7 +85,7 @@ def load_library(path: str | None = None):
         "mlst_load_reference": (C.c_int, [H, u8p, u64p, u32p, u32p, i32p, C.c_uint32]),
         "mlst_submit_reads": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_int]),
         "mlst_submit_fastq": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
-        "mlst_submit_fastq_bgzf": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+        "mlst_submit_fastq_bgzf": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mlst_selftest_inflate": (C.c_int, [u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
         "mlst_submit_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_int]),
         "mlst_pack_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, u32p, u8p, u16p, C.c_uint32, C.c_uint32]),
@@ -192,9 +192,29 @@ class Engine:
         final marks the last chunk of the file.  Returns the number of records completed by this chunk."""
         buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
         n = C.c_uint64()
-        self._check(self.lib.mlst_submit_fastq_bgzf(self._h, _ptr(buf) if buf.size else None, buf.size, int(final), int(paired), C.byref(n)),
+        self._check(self.lib.mlst_submit_fastq_bgzf(self._h, _ptr(buf) if buf.size else None, buf.size, int(final), int(paired), C.byref(n), None),
                     "mlst_submit_fastq_bgzf")
         return int(n.value)
+
+    def submit_fastq_bgzf_file(self, path: str, paired: bool = False, chunk_bytes: int = 256 << 20) -> int:
+        """A whole bgzip'd FASTQ file: raw reads of chunk_bytes go to the library, which takes the whole blocks of each buffer
+        and says how many bytes that was; the cut-off block is passed again in front of the next read."""
+        total, carry = 0, b""
+        n, used = C.c_uint64(), C.c_uint64()
+        with open(path, "rb") as f:
+            block = f.read(chunk_bytes)
+            while True:
+                nxt = f.read(chunk_bytes) if block else b""
+                data = carry + block if carry else block
+                buf = np.frombuffer(data, dtype=np.uint8)
+                last = not nxt
+                self._check(self.lib.mlst_submit_fastq_bgzf(self._h, _ptr(buf) if buf.size else None, buf.size, int(last), int(paired),
+                                                            C.byref(n), None if last else C.byref(used)), "mlst_submit_fastq_bgzf")
+                total += int(n.value)
+                if last:
+                    return total
+                carry = data[int(used.value):]
+                block = nxt
 
     def submit_reads_device(self, d_bases: int, d_quals: int, d_off: int, n_reads: int, max_len: int, paired: bool = False):
         self._check(self.lib.mlst_submit_reads_device(self._h, d_bases, d_quals, d_off, n_reads, max_len, int(paired)),

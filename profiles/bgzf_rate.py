@@ -50,7 +50,7 @@ eng = Engine(0)
 eng.load_reference(idx)
 out = {"reads": N, "text_bytes": len(text), "bgzf_bytes": comp_bytes}
 for name, fn in (("host_inflate_gpu_parse", lambda: sum(eng.submit_fastq(c) for c in text_chunks(path))),
-                 ("gpu_inflate_gpu_parse", lambda: sum(eng.submit_fastq_bgzf(c, final=last) for c, last in bgzf_chunks(path)))):
+                 ("gpu_inflate_gpu_parse", lambda: eng.submit_fastq_bgzf_file(path))):
     ts, stats = [], None
     for _ in range(3):
         eng.reset_sample()

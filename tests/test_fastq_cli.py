@@ -182,6 +182,10 @@ def test_bgzf_fastq_inflated_on_the_gpu_equals_the_text_path():
         n = sum(eng.submit_fastq_bgzf(c, final=last) for c, last in chunks)
         assert n == len(recs) and (chunk_bytes > 1 << 20 or len(chunks) > 5)
         fx.assert_stats_equal(eng.stats(), want)
+    for chunk_bytes in (1 << 30, 70_001):       # raw reads of the file: the library takes the whole blocks of every buffer
+        eng.reset_sample()
+        assert eng.submit_fastq_bgzf_file(path, chunk_bytes=chunk_bytes) == len(recs)
+        fx.assert_stats_equal(eng.stats(), want)
     # a corrupt block, a chunk that is not whole blocks, a file that ends inside a record
     eng.reset_sample()
     bad = bytearray(b"".join(blocks[:3]))
