@@ -1,11 +1,12 @@
-// DEFLATE (RFC 1951) decoder for one raw stream, written for one GPU thread per stream: BGZF files (bgzip, BAM) are a
-// sequence of independent <= 64 KiB deflate streams, so a file inflates with one thread per block (k_inflate in
-// mlst_engine.hip).  The same code compiles for the host, where tests/test_inflate.py checks it against zlib through
-// mlst_selftest_inflate (the decoder's own test hook; the product path runs it on the device only).
+// DEFLATE (RFC 1951) decoder for one raw stream.  BGZF files (bgzip, BAM) are a sequence of independent <= 64 KiB
+// deflate streams, so a file inflates with one GPU wave per block (k_inflate in mlst_engine.hip: every lane runs this
+// code on the same stream, the output policy spreads the copies over the lanes).  The same code compiles for the host,
+// where tests/test_inflate.py checks it against zlib through mlst_selftest_inflate (the decoder's own test hook; the
+// product path runs it on the device only).
 //
-// Plain and small on purpose: canonical Huffman codes decoded bit by bit from (count per length, symbols in code order)
-// tables -- 700 bytes per stream (LDS in k_inflate), no look-up tables to build, every read and write bounds-checked,
-// every loop consumes input or output, so a corrupt block ends in an error code, never in a fault or a hang.
+// Canonical Huffman codes as (count per length, symbols in code order) + a look-up table over the next 8 (6) bits;
+// 1.3 KB of tables per stream, every read and write bounds-checked, every loop consumes input or output, so a corrupt
+// block ends in an error code, never in a fault or a hang.
 #pragma once
 #include <stdint.h>
 
@@ -27,31 +28,34 @@ struct Bits {
 // k_inflate waits a full memory latency for every dependent load): the bytes are ORed in above the cnt valid bits, the
 // position moves by the whole bytes that fit, and a byte that was ORed in only in part is ORed in again by the next
 // refill -- with the same bits, so nothing has to be masked.
-MLST_HD inline int take(Bits& b, int n, uint32_t& out) {
-    if (b.cnt < n) {
-        if (b.pos + 8 <= b.n) {
-            uint64_t w = 0;
-            for (int k = 0; k < 8; k++) w |= (uint64_t)b.in[b.pos + k] << (8 * k);
-            b.buf |= w << b.cnt;
-            b.pos += (uint64_t)((63 - b.cnt) >> 3);
-            b.cnt |= 56;
-        } else {
-            while (b.cnt <= 56 && b.pos < b.n) { b.buf |= (uint64_t)b.in[b.pos++] << b.cnt; b.cnt += 8; }
-            if (b.cnt < n) return E_INPUT;
-        }
+MLST_HD inline void refill(Bits& b) {
+    if (b.pos + 8 <= b.n) {
+        uint64_t w = 0;
+        for (int k = 0; k < 8; k++) w |= (uint64_t)b.in[b.pos + k] << (8 * k);
+        b.buf |= w << b.cnt;
+        b.pos += (uint64_t)((63 - b.cnt) >> 3);
+        b.cnt |= 56;
+    } else {
+        while (b.cnt <= 56 && b.pos < b.n) { b.buf |= (uint64_t)b.in[b.pos++] << b.cnt; b.cnt += 8; }
     }
+}
+MLST_HD inline int take(Bits& b, int n, uint32_t& out) {
+    if (b.cnt < n) { refill(b); if (b.cnt < n) return E_INPUT; }
     out = (uint32_t)(b.buf & ((1ull << n) - 1ull)); b.buf >>= n; b.cnt -= n;
     return OK;
 }
 
-struct Huff { uint16_t count[16]; uint16_t symbol[288]; };      // literal / length code (also the 19-symbol code-length code)
-struct HuffD { uint16_t count[16]; uint16_t symbol[30]; };      // distance code
-struct Tables { Huff lc; HuffD dc; };                           // 700 bytes per stream: LDS in k_inflate, the stack on the host
+// A code = (count per length, symbols in code order) + a look-up table over the next LB input bits for the codes of at
+// most LB bits: entry = (symbol << SH) | length, 0 = longer code (decoded bit by bit).
+struct Huff  { enum { LB = 8, SH = 4 }; uint16_t count[16]; uint16_t symbol[288]; uint16_t lut[1 << LB]; };   // literal / length code (also the code-length code)
+struct HuffD { enum { LB = 6, SH = 3 }; uint16_t count[16]; uint16_t symbol[30]; uint8_t lut[1 << LB]; };     // distance code
+struct Tables { Huff lc; HuffD dc; };                           // 1.3 KB per stream: LDS in k_inflate, the stack on the host
 
 // canonical code from code lengths; returns 0 for a complete code, > 0 for an incomplete one, < 0 for an over-subscribed one
 template <typename H>
 MLST_HD inline int build(H& h, const uint16_t* length, int n) {
     for (int l = 0; l <= 15; l++) h.count[l] = 0;
+    for (int i = 0; i < (1 << H::LB); i++) h.lut[i] = 0;
     for (int s = 0; s < n; s++) h.count[length[s]]++;
     if (h.count[0] == n) return 0;                 // no codes: complete, but decoding anything with it fails
     int left = 1;
@@ -59,10 +63,21 @@ MLST_HD inline int build(H& h, const uint16_t* length, int n) {
     uint16_t offs[16]; offs[1] = 0;
     for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + h.count[l]);
     for (int s = 0; s < n; s++) if (length[s] != 0) h.symbol[offs[length[s]]++] = (uint16_t)s;
+    // look-up table: the canonical code of the j-th symbol of length l is first(l) + j, sent most significant bit first
+    int code = 0, idx = 0;
+    for (int l = 1; l <= H::LB; l++) {
+        for (int j = 0; j < h.count[l]; j++, idx++) {
+            const int c = code + j; int rev = 0;
+            for (int k = 0; k < l; k++) rev |= ((c >> k) & 1) << (l - 1 - k);
+            const unsigned entry = ((unsigned)h.symbol[idx] << H::SH) | (unsigned)l;
+            for (int i = rev; i < (1 << H::LB); i += 1 << l) h.lut[i] = entry;
+        }
+        code = (code + h.count[l]) << 1;
+    }
     return left;
 }
 template <typename H>
-MLST_HD inline int decode(Bits& b, const H& h) {
+MLST_HD inline int decode_slow(Bits& b, const H& h) {
     int code = 0, first = 0, index = 0;
     for (int l = 1; l <= 15; l++) {
         uint32_t bit; if (take(b, 1, bit) != OK) return E_INPUT;
@@ -74,67 +89,83 @@ MLST_HD inline int decode(Bits& b, const H& h) {
     return E_SYMBOL;
 }
 
+template <typename H>
+MLST_HD inline int decode(Bits& b, const H& h) {
+    if (b.cnt < 15) refill(b);
+    const uint32_t e = h.lut[b.buf & ((1u << H::LB) - 1u)];
+    if (e) {
+        const int l = (int)(e & ((1u << H::SH) - 1u));
+        if (l > b.cnt) return E_INPUT;
+        b.buf >>= l; b.cnt -= l;
+        return (int)(e >> H::SH);
+    }
+    return decode_slow(b, h);
+}
+
+// Where the decoded bytes go.  OutSerial: one thread, one byte at a time (the host, the tests).  The engine's k_inflate
+// runs one WAVE per stream -- every lane decodes the same symbols, so the wave never diverges -- with its own policy
+// whose copies are spread over the lanes (mlst_engine.hip).  put / copy / raw are only called with room checked.
+struct OutSerial {
+    uint8_t* out; uint64_t op;
+    MLST_HD void put(uint8_t c) { out[op++] = c; }
+    MLST_HD void copy(uint32_t dist, uint32_t len) { for (uint32_t k = 0; k < len; k++) { out[op] = out[op - dist]; op++; } }
+    MLST_HD void raw(const uint8_t* src, uint32_t len) { for (uint32_t k = 0; k < len; k++) out[op++] = src[k]; }
+};
+
 // literal / length and distance codes until the end-of-block symbol
-MLST_HD inline int codes(Bits& b, const Huff& lc, const HuffD& dc, uint8_t* out, uint64_t cap, uint64_t& op) {
-    const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+template <typename Out>
+MLST_HD inline int codes(Bits& b, const Huff& lc, const HuffD& dc, Out& o, uint64_t cap) {
+    // base values and extra-bit counts of the length and distance symbols are computed, not looked up: a table in
+    // memory would be one more dependent load per match
     for (;;) {
         int sym = decode(b, lc);
         if (sym < 0) return sym;
         if (sym < 256) {
-            if (op >= cap) return E_OUTPUT;
-            out[op++] = (uint8_t)sym;
+            if (o.op >= cap) return E_OUTPUT;
+            o.put((uint8_t)sym);
         } else if (sym == 256) return OK;
         else {
             sym -= 257;
             if (sym >= 29) return E_SYMBOL;
-            uint32_t x; int rc = take(b, lext[sym], x); if (rc != OK) return rc;
-            const uint32_t len = lbase[sym] + x;
+            const int le = sym < 8 || sym == 28 ? 0 : (sym - 4) >> 2;
+            const uint32_t lb = sym < 8 ? 3u + (uint32_t)sym : (sym == 28 ? 258u : ((4u + ((uint32_t)sym & 3u)) << le) + 3u);
+            uint32_t x; int rc = take(b, le, x); if (rc != OK) return rc;
+            const uint32_t len = lb + x;
             const int ds = decode(b, dc);
             if (ds < 0) return ds;
             if (ds >= 30) return E_SYMBOL;
-            rc = take(b, dext[ds] > 8 ? 8 : dext[ds], x); if (rc != OK) return rc;       // up to 13 extra bits: two takes of <= 8
-            uint32_t dist = x;
-            if (dext[ds] > 8) { rc = take(b, dext[ds] - 8, x); if (rc != OK) return rc; dist |= x << 8; }
-            dist += dbase[ds];
-            if ((uint64_t)dist > op) return E_DISTANCE;
-            if (op + len > cap) return E_OUTPUT;
-            uint32_t left = len;
-            if (dist >= 8) {          // source and destination of a group of eight do not overlap: eight loads in one batch
-                while (left >= 8) {
-                    uint8_t t[8];
-                    for (int k = 0; k < 8; k++) t[k] = out[op - dist + k];
-                    for (int k = 0; k < 8; k++) out[op + k] = t[k];
-                    op += 8; left -= 8;
-                }
-            }
-            while (left--) { out[op] = out[op - dist]; op++; }
+            const int de = ds < 4 ? 0 : (ds - 2) >> 1;
+            const uint32_t db = ds < 4 ? 1u + (uint32_t)ds : ((2u + ((uint32_t)ds & 1u)) << de) + 1u;
+            rc = take(b, de, x); if (rc != OK) return rc;                                // up to 13 extra bits
+            const uint32_t dist = db + x;
+            if ((uint64_t)dist > o.op) return E_DISTANCE;
+            if (o.op + len > cap) return E_OUTPUT;
+            o.copy(dist, len);
         }
     }
 }
 
-// one raw deflate stream -> out[0 .. cap); *produced = bytes written.  The stream has to fill exactly what the caller
-// expects only if it says so: the caller compares *produced with the size it knows (ISIZE of the BGZF block).
-MLST_HD inline int inflate_raw(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced, Tables* tb) {
+// one raw deflate stream -> at most cap bytes through o (o.op = bytes written, also after an error).  Whether the stream
+// filled what the caller expected is the caller's check (ISIZE of the BGZF block).
+template <typename Out>
+MLST_HD inline int inflate_stream(const uint8_t* in, uint64_t n_in, Out& o, uint64_t cap, Tables* tb) {
     Bits b; b.in = in; b.n = n_in; b.pos = 0; b.buf = 0; b.cnt = 0;
-    uint64_t op = 0;
+    uint64_t& op = o.op;
     Huff& lc = tb->lc; HuffD& dc = tb->dc;
     uint16_t lengths[320];
     for (;;) {
         uint32_t last, type; int rc;
-        if ((rc = take(b, 1, last)) != OK || (rc = take(b, 2, type)) != OK) { *produced = op; return rc; }
+        if ((rc = take(b, 1, last)) != OK || (rc = take(b, 2, type)) != OK) return rc;
         if (type == 0) {
             b.pos -= (uint64_t)(b.cnt >> 3); b.buf = 0; b.cnt = 0;   // stored: back to the byte boundary (whole bytes still in the buffer are unread)
-            if (b.pos + 4 > b.n) { *produced = op; return E_INPUT; }
+            if (b.pos + 4 > b.n) return E_INPUT;
             const uint32_t len = (uint32_t)b.in[b.pos] | ((uint32_t)b.in[b.pos + 1] << 8);
             const uint32_t nlen = (uint32_t)b.in[b.pos + 2] | ((uint32_t)b.in[b.pos + 3] << 8);
             b.pos += 4;
-            if (len != (~nlen & 0xFFFFu)) { *produced = op; return E_STORED; }
-            if (b.pos + len > b.n) { *produced = op; return E_INPUT; }
-            if (op + len > cap) { *produced = op; return E_OUTPUT; }
-            for (uint32_t k = 0; k < len; k++) out[op++] = b.in[b.pos++];
+            if (len != (~nlen & 0xFFFFu)) return E_STORED;
+            if (b.pos + len > b.n) return E_INPUT;
+            if (op + len > cap) return E_OUTPUT;
+            o.raw(b.in + b.pos, len); b.pos += len;
         } else if (type == 1) {
             for (int s = 0; s < 144; s++) lengths[s] = 8;
             for (int s = 144; s < 256; s++) lengths[s] = 9;
@@ -143,47 +174,53 @@ MLST_HD inline int inflate_raw(const uint8_t* in, uint64_t n_in, uint8_t* out, u
             build(lc, lengths, 288);
             for (int s = 0; s < 30; s++) lengths[s] = 5;
             build(dc, lengths, 30);
-            rc = codes(b, lc, dc, out, cap, op);
-            if (rc != OK) { *produced = op; return rc; }
+            rc = codes(b, lc, dc, o, cap);
+            if (rc != OK) return rc;
         } else if (type == 2) {
             const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             uint32_t nlen, ndist, ncode;
-            if ((rc = take(b, 5, nlen)) != OK || (rc = take(b, 5, ndist)) != OK || (rc = take(b, 4, ncode)) != OK) { *produced = op; return rc; }
+            if ((rc = take(b, 5, nlen)) != OK || (rc = take(b, 5, ndist)) != OK || (rc = take(b, 4, ncode)) != OK) return rc;
             nlen += 257; ndist += 1; ncode += 4;
-            if (nlen > 286 || ndist > 30) { *produced = op; return E_LENGTHS; }
+            if (nlen > 286 || ndist > 30) return E_LENGTHS;
             for (int i = 0; i < 19; i++) lengths[i] = 0;
-            for (uint32_t i = 0; i < ncode; i++) { uint32_t x; if ((rc = take(b, 3, x)) != OK) { *produced = op; return rc; } lengths[order[i]] = (uint16_t)x; }
-            if (build(lc, lengths, 19) != 0) { *produced = op; return E_LENGTHS; }      // the code-length code must be complete
+            for (uint32_t i = 0; i < ncode; i++) { uint32_t x; if ((rc = take(b, 3, x)) != OK) return rc; lengths[order[i]] = (uint16_t)x; }
+            if (build(lc, lengths, 19) != 0) return E_LENGTHS;      // the code-length code must be complete
             uint32_t idx = 0;
             while (idx < nlen + ndist) {
                 int sym = decode(b, lc);
-                if (sym < 0) { *produced = op; return sym; }
+                if (sym < 0) return sym;
                 if (sym < 16) lengths[idx++] = (uint16_t)sym;
                 else {
                     uint32_t rep, x; uint16_t val = 0;
                     if (sym == 16) {
-                        if (idx == 0) { *produced = op; return E_LENGTHS; }
+                        if (idx == 0) return E_LENGTHS;
                         val = lengths[idx - 1];
-                        if ((rc = take(b, 2, x)) != OK) { *produced = op; return rc; }
+                        if ((rc = take(b, 2, x)) != OK) return rc;
                         rep = 3 + x;
-                    } else if (sym == 17) { if ((rc = take(b, 3, x)) != OK) { *produced = op; return rc; } rep = 3 + x; }
-                    else { if ((rc = take(b, 7, x)) != OK) { *produced = op; return rc; } rep = 11 + x; }
-                    if (idx + rep > nlen + ndist) { *produced = op; return E_LENGTHS; }
+                    } else if (sym == 17) { if ((rc = take(b, 3, x)) != OK) return rc; rep = 3 + x; }
+                    else { if ((rc = take(b, 7, x)) != OK) return rc; rep = 11 + x; }
+                    if (idx + rep > nlen + ndist) return E_LENGTHS;
                     while (rep--) lengths[idx++] = val;
                 }
             }
-            if (lengths[256] == 0) { *produced = op; return E_LENGTHS; }                 // no end-of-block code
+            if (lengths[256] == 0) return E_LENGTHS;                 // no end-of-block code
             int e = build(lc, lengths, (int)nlen);
-            if (e < 0 || (e > 0 && nlen != (uint32_t)(lc.count[0] + lc.count[1]))) { *produced = op; return E_LENGTHS; }
+            if (e < 0 || (e > 0 && nlen != (uint32_t)(lc.count[0] + lc.count[1]))) return E_LENGTHS;
             e = build(dc, lengths + nlen, (int)ndist);
-            if (e < 0 || (e > 0 && ndist != (uint32_t)(dc.count[0] + dc.count[1]))) { *produced = op; return E_LENGTHS; }
-            rc = codes(b, lc, dc, out, cap, op);
-            if (rc != OK) { *produced = op; return rc; }
-        } else { *produced = op; return E_BLOCKTYPE; }
+            if (e < 0 || (e > 0 && ndist != (uint32_t)(dc.count[0] + dc.count[1]))) return E_LENGTHS;
+            rc = codes(b, lc, dc, o, cap);
+            if (rc != OK) return rc;
+        } else return E_BLOCKTYPE;
         if (last) break;
     }
-    *produced = op;
     return OK;
+}
+
+MLST_HD inline int inflate_raw(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced, Tables* tb) {
+    OutSerial o; o.out = out; o.op = 0;
+    const int rc = inflate_stream(in, n_in, o, cap, tb);
+    *produced = o.op;
+    return rc;
 }
 
 }  // namespace mlst_inflate

@@ -757,17 +757,37 @@ __global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ f
     }
 }
 
-// ------------------------------------------------------------------ BGZF -> text (one thread per <= 64 KiB deflate block)
+// ------------------------------------------------------------------ BGZF -> text (one wave per <= 64 KiB deflate block)
+// Every lane of the wave runs the decoder on the same stream, so control flow is wave-uniform (64 different streams in
+// one wave would each wait for the longest match copy of the others) and reads are broadcasts; what the lanes share out
+// is the copying: lane k moves byte k of a match or of a stored block.  A match may overlap its own output
+// (dist < len): source byte k is then byte k mod dist of the period, which lies entirely before the write position.
 struct BgzfBlk { u64 in_off, out_off; u32 in_len, out_len; };
+struct OutWave {
+    u8* out; uint64_t op; int lane;
+    uint64_t safe;        // bytes below this position were stored before the last fence
+    __device__ void put(u8 c) { if (lane == 0) out[op] = c; op++; }
+    __device__ void copy(u32 dist, u32 len) {
+        // source bytes that other lanes of this wave stored since the last fence have to be done before they are read
+        // back; most matches reach further back than that and need no wait
+        if (op - dist + (dist < len ? dist : len) > safe) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); safe = op; }
+        const u8* src = out + op - dist;
+        for (u32 k = (u32)lane; k < len; k += 64) out[op + k] = src[dist >= len ? k : k % dist];
+        op += len;
+    }
+    __device__ void raw(const u8* src, u32 len) { for (u32 k = (u32)lane; k < len; k += 64) out[op + k] = src[k]; op += len; }
+};
+__attribute__((amdgpu_waves_per_eu(6, 6)))      // the decoder is a chain of dependent loads: six waves per SIMD measured best (4: -10 %)
 __global__ __launch_bounds__(64) void k_inflate(const u8* __restrict__ comp, const BgzfBlk* __restrict__ blk, u32 n_blk, u8* __restrict__ out, u32* __restrict__ err /* [0] = 1 + first bad block, [1] = its code */) {
-    __shared__ mlst_inflate::Tables s_tb[64];     // Huffman tables of the 64 streams: LDS latency instead of scratch-memory latency per code bit
-    const u32 i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_blk) return;
-    const BgzfBlk B = blk[i];
-    uint64_t produced = 0;
-    int rc = mlst_inflate::inflate_raw(comp + B.in_off, B.in_len, out + B.out_off, B.out_len, &produced, &s_tb[threadIdx.x]);
-    if (rc == mlst_inflate::OK && produced != B.out_len) rc = mlst_inflate::E_SHORT;
-    if (rc != mlst_inflate::OK && atomicCAS(&err[0], 0u, i + 1u) == 0u) err[1] = (u32)(-rc);
+    __shared__ mlst_inflate::Tables s_tb;         // Huffman tables of the stream: LDS latency per code, not scratch-memory latency
+    for (u32 i = blockIdx.x; i < n_blk; i += gridDim.x) {     // wave-uniform
+        const BgzfBlk B = blk[i];
+        OutWave o; o.out = out + B.out_off; o.op = 0; o.lane = (int)threadIdx.x; o.safe = 0;
+        int rc = mlst_inflate::inflate_stream(comp + B.in_off, (uint64_t)B.in_len, o, (uint64_t)B.out_len, &s_tb);
+        if (rc == mlst_inflate::OK && o.op != B.out_len) rc = mlst_inflate::E_SHORT;
+        if (rc != mlst_inflate::OK && threadIdx.x == 0 && atomicCAS(&err[0], 0u, i + 1u) == 0u) err[1] = (u32)(-rc);
+        __syncthreads();                          // the tables are rebuilt for the next stream
+    }
 }
 // ------------------------------------------------------------------ FASTQ text -> packed reads (GPU parser)
 #define FQ_BLOCK 4096        // bytes of text per workgroup
@@ -834,27 +854,33 @@ __global__ __launch_bounds__(256) void k_fq_records(const u8* __restrict__ text,
 // pack from text: same output format as k_pack, reads addressed by separate sequence / quality offsets
 __global__ __launch_bounds__(256) void k_pack_text(const u8* __restrict__ text, const u64* __restrict__ seq_off, const u64* __restrict__ qual_off,
                                                     u16* __restrict__ lens, u64 n_reads, u32* __restrict__ packed, u8* __restrict__ qrows, u32 wpr, u32 qstride) {
-    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 total = packed_words(n_reads, wpr);
-    for (; gid < total; gid += (u64)gridDim.x * blockDim.x) {
-        u64 grp = gid / (64ull * wpr); u32 in = (u32)(gid - grp * 64ull * wpr);
-        u64 r = grp * 64 + ((in >> 1) & 63); u32 w = ((in >> 7) << 1) | (in & 1);
-        if (r >= n_reads) { packed[gid] = 0; continue; }
-        u64 so = seq_off[r], qo = qual_off[r]; u32 n = lens[r] & 0x7FFFu;
-        u32 word = 0; u32 anyn = 0;
+    // thread = one 16-base word of one read, consecutive threads = consecutive words of the same read: a wave reads its
+    // sequence and quality bytes from contiguous text and writes contiguous quality rows (four bytes at a time)
+    const u64 total = packed_words(n_reads, wpr);       // rows padded to a multiple of 64 reads
+    for (u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (u64)gridDim.x * blockDim.x) {
+        const u64 r = gid / wpr; const u32 w = (u32)(gid - r * wpr);
+        if (r >= n_reads) { packed[packed_index(r, wpr, w)] = 0; continue; }
+        const u64 so = seq_off[r], qo = qual_off[r]; const u32 n = lens[r] & 0x7FFFu;
+        u8 cs[16], cq[16];
+        #pragma unroll
+        for (int k = 0; k < 16; k++) { const u32 i = w * 16 + k; const bool in = i < n; cs[k] = in ? text[so + i] : (u8)'A'; cq[k] = in ? text[qo + i] : (u8)33; }
+        u32 word = 0, anyn = 0, qw[4] = {0, 0, 0, 0};
+        #pragma unroll
         for (int k = 0; k < 16; k++) {
-            u32 i = w * 16 + k;
+            const u32 i = w * 16 + k;
             if (i < n) {
-                u8 c = text[so + i]; u32 b; u32 isn = 0;
-                switch (c) { case 'A': case 'a': b = 0; break; case 'C': case 'c': b = 1; break;
-                             case 'G': case 'g': b = 2; break; case 'T': case 't': b = 3; break; default: b = 0; isn = 1; }
+                const u8 c = cs[k] & 0xDF;               // upper case
+                u32 b, isn = 0;
+                if (c == 'A') b = 0; else if (c == 'C') b = 1; else if (c == 'G') b = 2; else if (c == 'T') b = 3; else { b = 0; isn = 1; }
                 word |= b << (2 * k);
-                int q = (int)text[qo + i] - 33; q = q < 0 ? 0 : (q > 127 ? 127 : q);
-                if (i < qstride) qrows[r * qstride + i] = (u8)q | (u8)(isn << 7);
+                int q = (int)cq[k] - 33; q = q < 0 ? 0 : (q > 127 ? 127 : q);
+                qw[k >> 2] |= ((u32)q | (isn << 7)) << (8 * (k & 3));
                 anyn |= isn;
-            } else if (i < qstride) qrows[r * qstride + i] = 0;
+            }
         }
-        packed[gid] = word;
+        packed[packed_index(r, wpr, w)] = word;
+        #pragma unroll
+        for (int j = 0; j < 4; j++) if (w * 16 + 4 * j < qstride) reinterpret_cast<u32*>(qrows + r * qstride)[w * 4 + j] = qw[j];     // qstride is a multiple of 4
         if (anyn) atomicOr((u32*)(lens + (r & ~1ull)), (r & 1) ? 0x80000000u : 0x00008000u);
     }
 }
@@ -2722,7 +2748,7 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
         HIPCHK(h, hipMemcpyAsync(h->d_bgzf_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->stream));
         u32* d_err = reinterpret_cast<u32*>(h->d_fq_meta + 2);
         HIPCHK(h, hipMemsetAsync(d_err, 0, 8, h->stream));
-        hipLaunchKernelGGL(k_inflate, dim3((u32)((blks.size() + 63) / 64)), dim3(64), 0, h->stream, h->d_bgzf, (const BgzfBlk*)h->d_bgzf_blk, (u32)blks.size(), h->d_fq_text, d_err);
+        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(blks.size(), 1u << 20)), dim3(64), 0, h->stream, h->d_bgzf, (const BgzfBlk*)h->d_bgzf_blk, (u32)blks.size(), h->d_fq_text, d_err);
         u32 err[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));      // also: blks / data may be released by the caller after this
