@@ -862,8 +862,12 @@ __global__ __launch_bounds__(256) void k_pack_text(const u8* __restrict__ text, 
         if (r >= n_reads) { packed[packed_index(r, wpr, w)] = 0; continue; }
         const u64 so = seq_off[r], qo = qual_off[r]; const u32 n = lens[r] & 0x7FFFu;
         u8 cs[16], cq[16];
-        #pragma unroll
-        for (int k = 0; k < 16; k++) { const u32 i = w * 16 + k; const bool in = i < n; cs[k] = in ? text[so + i] : (u8)'A'; cq[k] = in ? text[qo + i] : (u8)33; }
+        if (w * 16 + 16 <= n) {      // whole word inside the read: two 16-byte copies (the compiler picks the widest loads the target allows unaligned)
+            __builtin_memcpy(cs, text + so + w * 16, 16); __builtin_memcpy(cq, text + qo + w * 16, 16);
+        } else {
+            #pragma unroll
+            for (int k = 0; k < 16; k++) { const u32 i = w * 16 + k; const bool in = i < n; cs[k] = in ? text[so + i] : (u8)'A'; cq[k] = in ? text[qo + i] : (u8)33; }
+        }
         u32 word = 0, anyn = 0, qw[4] = {0, 0, 0, 0};
         #pragma unroll
         for (int k = 0; k < 16; k++) {
