@@ -1246,7 +1246,7 @@ __device__ inline u32 ld_row(GP<const u32>::G* row, u32 byte_off) {
 // gap-trigger policy needs it, and only for pairs with many mismatches).  Value-identical to ungapped<>.
 // rl/rh/od/rn = read planes, non-default-penalty mask and N mask, block-uniform (scalar registers); s_pen stays in LDS
 // because they are needed only for reads with N / for the rare non-default penalty.
-template <int NB, bool TRACK>
+template <int NB, bool TRACK, bool HASN>
 __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, const LocusDev& L, u32 a_local, int m, int n, int d,
                                       const u32 (&rl)[NB], const u32 (&rh)[NB], const u32 (&od)[NB], const u32 (&rn)[NB], const u8* s_pen,
                                       int pen_def, bool read_has_n, int& mm_total, int& bs, int& be) {
@@ -1268,10 +1268,10 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
         A[2 * t] = ld_row(pbase, rowoff + aoff);
         A[2 * t + 1] = ld_row(pbase, rowoff + L.n_pad * 4u + aoff);
         AW[t] = 0;
-        if (L.has_n) AW[t] = ld_row(nbase, qc * (L.n_pad * 4u) + aoff);
+        if (HASN) AW[t] = ld_row(nbase, qc * (L.n_pad * 4u) + aoff);
     }
     tie_all<2 * (NB + 1)>(A);
-    if (L.has_n) tie_all<NB + 1>(AW);
+    if (HASN) tie_all<NB + 1>(AW);
     // m (the caller's allele_len load) is first needed here, behind the batch: one round trip, not two.  An allele
     // that does not overlap the read (i1 <= i0) falls out of the masks: M = 0 and the final value is <= P0.
     const int i1 = (m - d) < n ? (m - d) : n;                  // per allele
@@ -1284,16 +1284,20 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
         M[w] = (lo ^ rl[w]) | (hi ^ rh[w]);
         M[w] |= rn[w];                                          // read N mask (zero for reads without N), scalar
         AN[w] = 0;
-        if (L.has_n) { AN[w] = __builtin_amdgcn_alignbit(AW[w + 1], AW[w], r); M[w] |= AN[w]; }
+        if (HASN) { AN[w] = __builtin_amdgcn_alignbit(AW[w + 1], AW[w], r); M[w] |= AN[w]; }
         int lo_i = i0 - 32 * w; lo_i = lo_i < 0 ? 0 : (lo_i > 32 ? 32 : lo_i);            // uniform: scalar unit
         int hi_u = n - 32 * w; hi_u = hi_u < 0 ? 0 : (hi_u > 32 ? 32 : hi_u);
         M[w] &= (hi_u >= 32 ? 0xFFFFFFFFu : ((1u << hi_u) - 1u)) & ~(lo_i >= 32 ? 0xFFFFFFFFu : ((1u << lo_i) - 1u));
-        if (lane_mask) {
+    }
+    if (lane_mask) {                                           // one branch for all blocks
+        #pragma unroll
+        for (int w = 0; w < NB; w++) {
             int hi_i = i1 - 32 * w; hi_i = hi_i < 0 ? 0 : (hi_i > 32 ? 32 : hi_i);
             M[w] &= hi_i >= 32 ? 0xFFFFFFFFu : ((1u << hi_i) - 1u);
         }
-        mm_total += __popc(M[w]);
     }
+    #pragma unroll
+    for (int w = 0; w < NB; w++) mm_total += __popc(M[w]);
     const int PD = (pen_def << MLST_P_SHIFT) + 1;
     if (!TRACK) {
         // g = cur - last*MA, so the running value just before column i is g + i*MA; gw = g + 32*w*MA is the same with
@@ -1432,14 +1436,16 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
 #endif
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
-            int best = ungapped_planes<NB, false>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
+            int best = L.has_n ? ungapped_planes<NB, false, true>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be)
+                               : ungapped_planes<NB, false, false>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
 #ifdef EXP_NO_KADANE
             mm = 0;
 #endif
             int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
             bool need_dp = P.trig < 0;
             if (!need_dp && mm > P.trig && score >= floor_n) {       // rare: the policy needs the aligned span
-                ungapped_planes<NB, true>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
+                if (L.has_n) ungapped_planes<NB, true, true>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
+                else ungapped_planes<NB, true, false>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
                 need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
             }
             u32 r = pack_result(score, xm, xo);
