@@ -1306,14 +1306,18 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
         // three-operand add.
         int gw = P0 - i0 * MA, best = P0;
         const int negMA = -MA;
+        // does any mismatch of this wave sit on a column with a non-default penalty?  decided once for all words
+        u32 spany = 0;
         #pragma unroll
-        for (int w = 0; w < NB; w++) {
-            u32 Mw = M[w];
+        for (int w = 0; w < NB; w++) spany |= M[w] & (od[w] | AN[w]);
+        if (__any(spany != 0)) {
+            #pragma unroll
+            for (int w = 0; w < NB; w++) {
+                u32 Mw = M[w];
 #ifdef EXP_NO_KADANE
-            Mw = 0;
+                Mw = 0;
 #endif
-            const u32 special = od[w] | AN[w];
-            if (__any((Mw & special) != 0)) {                  // some mismatch of this wave has a non-default penalty
+                const u32 special = od[w] | AN[w];
                 while (Mw) {
                     const int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
                     const int t = mad24(bit, MA, gw);
@@ -1323,7 +1327,15 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
                     int dd = P0 - t; dd = dd > -dec ? dd : -dec;       // (value after the mismatch, floored at P0) - t
                     gw = add3(gw, negMA, dd);
                 }
-            } else {
+                gw += 32 * MA;
+            }
+        } else {
+            #pragma unroll
+            for (int w = 0; w < NB; w++) {
+                u32 Mw = M[w];
+#ifdef EXP_NO_KADANE
+                Mw = 0;
+#endif
                 while (Mw) {
                     const int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
                     const int t = mad24(bit, MA, gw);
@@ -1331,8 +1343,8 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
                     int dd = P0 - t; dd = dd > -PD ? dd : -PD;         // (value after the mismatch, floored at P0) - t
                     gw = add3(gw, negMA, dd);
                 }
+                gw += 32 * MA;
             }
-            gw += 32 * MA;
         }
         const int t = gw + (i1 - 32 * NB) * MA;
         return t > best ? t : best;
