@@ -10,9 +10,10 @@ extension against every allele -> hit accumulation -> allele choice -> pileup ->
 its own 10 M-read shard of the same isolate (weak scaling), the two all-reduces of
 metamlst_amd/dist.py run over RCCL, and rank 0 runs the host tail.
 
-By default three engines (three HIP streams, three sets of sample state) work on the same resident batch
-in turn (--pipeline 3): while the host types step k (.nfo line, ST call) the GPU already runs the passes of
-steps k+1 and k+2, and the small latency-bound kernels of one step overlap the streaming kernels of another.
+By default four engines (four HIP streams, four sets of sample state) work on the same resident batch
+in turn (--pipeline 4; measured: 2 / 3 / 4 / 5 / 6 engines -> 22.9 / 27.4 / 31.0 / 26.1 / 26.2 Greads/s): while the host
+types step k (.nfo line, ST call) the GPU already runs the passes of the next steps, and the small latency-bound
+kernels of one step overlap the streaming kernels of another.
 At N=1 the allele choice, pileup and consensus are queued on the device right behind pass 1
 (mlst_typing_enqueue), so a step has a single host round trip.  Every step is still one complete pass and
 the timed region holds exactly K of them; `serial_ms_per_step` reports the strictly serial step
@@ -53,7 +54,7 @@ def parse_args():
     ap.add_argument("--genome", type=int, default=4_600_000)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
     ap.add_argument("--st-row", type=int, default=11)
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=4,
                     help="engines per GPU: with more than one, the GPU already works on the next steps while the host types "
                          "step k (multiple buffering; every step is still a complete pass); 1 = strictly serial steps")
     ap.add_argument("--calibrate", action="store_true",
