@@ -251,7 +251,8 @@ typedef struct mlst_item {     /* one (read, locus, strand, diagonal) unit of ex
 int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint64_t* n);
 
 /* Per-kernel device time measured with HIP events on the engine's stream.
- * which: 0=sieve 1=seed 2=extend 3=banded-SW 4=accumulate 5=pileup 6=pack (events bracket the launch on the engine's
+ * which: 0=sieve (all its kernels) 1=seed 2=extend 3=banded-SW 4=accumulate 5=pileup 6=pack; 9 = k_route and 10 =
+ * k_route_probe, the two kernels of the routed sieve (inside 0) (events bracket the launch on the engine's
  * stream, so with several engines on one GPU they include the time a kernel queues behind another stream's kernel);
  * 7 = the sieve's execution window measured inside the kernel (wall clock at the first workgroup's start and the last
  * one's end; one submission per sample), added up when the sample's statistics are fetched;
@@ -272,6 +273,11 @@ int mlst_reset_kernel_time(mlst_handle* h);
 /* Bytes of the device-resident index structures: [0]=allele arena [1]=sieve [2]=seed table;
  * [3]=fill of the LDS first-level bitmap in parts per million (0 when the plain sieve kernel is in use) */
 int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]);
+/* The seed sieve chosen for the loaded database: [0] = kind (0 = half-seed bitmaps in LDS, 1 = hashed bitmap in global
+ * memory, 2 = XCD-binned Bloom filters, 3 = CU-routed filter slices in LDS; chosen by database size, MLST_SIEVE=lds /
+ * global / binned / routed forces one), [1] = distinct canonical seeds, [2] = longest overflow walk of a key in the
+ * fingerprint sieve (the kernels follow a chain for 64 buckets; the build keeps it <= 32), [3] = sieve buckets. */
+int mlst_get_sieve_info(mlst_handle* h, uint64_t out[4]);
 /* Block until all work queued on the engine's stream is done. */
 int mlst_synchronize(mlst_handle* h);
 

@@ -49,6 +49,12 @@ def _type_parser(sub):
     p.add_argument("--debug", action="store_true")
     p.add_argument("--presorted", action="store_true")
     p.add_argument("--device", default=0, type=int)
+    p.add_argument("--gpus", default=1, type=int,
+                   help="type the sample on N GPUs of this node: one process per GPU, FASTQ chunks dealt to the ranks, the statistics "
+                        "and pileup counts all-reduced over RCCL (plain or .gz FASTQ; the .nfo is byte-identical to --gpus 1)")
+    p.add_argument("--max-retained", default=0, type=int, metavar="READS", help="capacity of the on-locus read store (default 4 M)")
+    p.add_argument("--max-items", default=0, type=int, metavar="ITEMS", help="capacity of the (read, locus, strand) work-item list (default 8 M)")
+    p.add_argument("--max-pair-results", default=0, type=int, metavar="PAIRS", help="capacity of the (item, allele) result arena (default 256 M)")
     return p
 
 
@@ -99,7 +105,19 @@ def run_index(a) -> int:
     return 0
 
 
-def run_type(a) -> int:
+def run_type(a, argv=None) -> int:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world == 1:
+        if a.alignments or a.contigs:
+            print("--gpus applies to FASTQ input")
+            return 1
+        from .multigpu import launch_ranks
+        return launch_ranks(a.gpus, list(argv if argv is not None else sys.argv[1:]))      # before this process touches a GPU
+    rank, device = 0, None
+    if world > 1:
+        from .multigpu import init_from_env
+        rank, world, device = init_from_env()
+        a.device = device.index
     try:
         database = mdb.metaMLST_db(a.database)
         idx = load_index(a.database, a.filter.split(",") if a.filter else None)
@@ -108,6 +126,7 @@ def run_type(a) -> int:
         return 1
     prm = default_params()
     prm.minscore, prm.max_xm, prm.min_read_len = a.minscore, a.max_xM, a.min_read_len
+    prm.max_retained_reads, prm.max_items, prm.max_pair_results = a.max_retained, a.max_items, a.max_pair_results
     eng = Engine(a.device, prm)
     eng.load_reference(idx)
     targs = TypingArgs(penalty=a.penalty, minscore=a.minscore, max_xM=a.max_xM, min_read_len=a.min_read_len,
@@ -121,13 +140,28 @@ def run_type(a) -> int:
         for chunk in tile_fasta(a.READS, read_len, stride, a.min_read_len):
             eng.submit_fastq(chunk, paired=False)
         return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)
+    chunk_bytes = int(os.environ.get("MLST_FASTQ_CHUNK", str(256 << 20)))
+    if world > 1:      # this rank's chunks, then the two all-reduces; rank 0 writes (metamlst_amd/multigpu.py)
+        from .multigpu import submit_fastq_shard, type_sharded
+        submit_fastq_shard(eng, [a.READS] + ([a.mates] if a.mates else []), rank, world, chunk_bytes)
+        fileName = sample_name(a.READS)
+        if rank == 0 and not os.path.isdir(a.o):
+            os.mkdir(a.o)
+        log_path = (a.o + "/" + fileName + "_" + str(int(time.time())) + ".out") if a.log else None
+        results = type_sharded(eng, idx, database, targs, rank, world, device, fileName, a.o, log_path, a.READS)
+        if rank == 0 and not a.quiet:
+            _print_results(a, results)
+        database.closeConnection()
+        import torch.distributed as dist
+        dist.destroy_process_group()
+        return 0
     # FASTQ text goes to the GPU as is and is parsed there (mlst_submit_fastq).  Mates are unpaired reads for this
     # pipeline (bowtie2 -U), so a second file is simply submitted after the first.
     for path in [a.READS] + ([a.mates] if a.mates else []):
         if is_bgzf(path):      # bgzip'd FASTQ: the compressed blocks go to the GPU and are inflated there
             eng.submit_fastq_bgzf_file(path, paired=False)
             continue
-        for chunk in text_chunks(path):
+        for chunk in text_chunks(path, chunk_bytes):
             eng.submit_fastq(chunk, paired=False)
     return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)
 
@@ -141,18 +175,22 @@ def _finish_type(a, idx, database, targs, st, pileup_fn) -> int:
             f.write(log_table(idx, st, targs, a.READS))
     results = type_sample(idx, st, pileup_fn, database, fileName, targs, out_dir=a.o)
     if not a.quiet:
-        for r in results:
-            print(" %-18s Detected Loci: %s" % (r.species, ", ".join(r.detected)))
-            if r.missing:
-                print(" " * 20 + "Missing Loci : " + ", ".join(r.missing))
-            for g, (avg, hits, alleles, cov) in sorted(r.closest.items()):
-                print("  %-7s%15s%7s%6s  %s" % (g, cov, avg, hits, ",".join(alleles[:5]) + ("... (%d more)" % len(alleles) if len(alleles) > 5 else "")))
-            for l in r.loci_report:
-                print("  %-7s%-7s%7s%7s%7s%15s%10s" % (l["locus"], l["ref"], l["length"], l["ns"], l["snps"], l["confidence"], l["notes"]))
-            print("  -> " + ("Reconstruction Successful [WRITE]" if r.written else
-                             ("Accuracy lower than %s%% [SKIP]" % round(a.min_accuracy * 100, 2) if r.passed_nloci else "not enough loci [SKIP]")))
+        _print_results(a, results)
     database.closeConnection()
     return 0
+
+
+def _print_results(a, results) -> None:
+    for r in results:
+        print(" %-18s Detected Loci: %s" % (r.species, ", ".join(r.detected)))
+        if r.missing:
+            print(" " * 20 + "Missing Loci : " + ", ".join(r.missing))
+        for g, (avg, hits, alleles, cov) in sorted(r.closest.items()):
+            print("  %-7s%15s%7s%6s  %s" % (g, cov, avg, hits, ",".join(alleles[:5]) + ("... (%d more)" % len(alleles) if len(alleles) > 5 else "")))
+        for l in r.loci_report:
+            print("  %-7s%-7s%7s%7s%7s%15s%10s" % (l["locus"], l["ref"], l["length"], l["ns"], l["snps"], l["confidence"], l["notes"]))
+        print("  -> " + ("Reconstruction Successful [WRITE]" if r.written else
+                         ("Accuracy lower than %s%% [SKIP]" % round(a.min_accuracy * 100, 2) if r.passed_nloci else "not enough loci [SKIP]")))
 
 
 def run_merge(a) -> int:
@@ -174,7 +212,9 @@ def main(argv=None) -> int:
     _merge_parser(sub)
     _index_parser(sub)
     a = ap.parse_args(argv)
-    return {"type": run_type, "merge": run_merge, "index": run_index}[a.cmd](a)
+    if a.cmd == "type":
+        return run_type(a, argv)
+    return {"merge": run_merge, "index": run_index}[a.cmd](a)
 
 
 if __name__ == "__main__":

@@ -17,7 +17,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mlst.h"
@@ -133,6 +137,11 @@ struct KParams {
 // prove that they point to global memory and would emit flat_* accesses -- slower, and they count on lgkmcnt as
 // well as vmcnt, which ties every LDS wait to the outstanding global loads.  On the device the accessor
 // round-trips through address space 1, from which the address-space inference makes every use a global_* access.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define GLOBAL_AS                  /* host pass: device functions are only type-checked */
+#endif
 template <typename T> struct GP {
     T* p;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -730,6 +739,261 @@ __global__ __launch_bounds__(256) void k_bin_probe(const u32* __restrict__ packe
         }
     }
     drain(true);
+    if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
+}
+
+// ------------------------------------------------------------------ K1c: CU-routed sieve (databases beyond the LDS half-seed bitmaps)
+// A filter for millions of seeds needs ~16 MiB.  The only on-chip memories of that aggregate size are the eight L2s
+// (4 MiB each, ~270 G random requests/s in all -- what k_bin_probe is bound by: 450 M seeds of a 50 M-read batch are 1.7 ms
+// of L2 requests alone) and the 256 LDS (128 KiB usable each, 32 lanes per clock per CU: ~60 x the L2 request rate).  So
+// the filter is cut into 256 slices by key hash, one slice per CU, and every seed is ROUTED to the CU that owns its slice:
+//   k_route        streams the reads once (1024-thread workgroup = tile of 16 groups of 64 reads); per seed the canonical
+//                  key and ONE 32-bit hash: top 8 bits = owner, low 24 bits = filter address.  The tile's seeds are
+//                  counting-sorted by (owner, wave) in LDS and each owner's run is appended to the region
+//                  (owner, this workgroup) of the arena -- contiguous stores of ~150 bytes that the L2 merges into whole
+//                  lines (the open lines of an XCD's workgroups are ~2 MiB).  A 4-byte entry = first-of-(owner, wave)
+//                  flag | valid | lane | 24 hash bits; the read index is implied by the position in the region: the
+//                  consumer counts the flags (every (owner, wave) pair of a tile contributes at least a dummy entry).
+//   k_route_probe  one workgroup per owner holds the owner's 128 KiB filter slice in LDS (two bits of one 32-bit word per
+//                  key: ~1 % of foreign seeds pass), streams the owner's regions 16 bytes per lane, and sends the
+//                  entries that pass the exact way: the read's seeds are re-hashed, the one(s) equal to the entry's hash
+//                  probe the fingerprint sieve, a hit sets the read's candidate flag.
+//   k_flag_compact candidate flags -> candidate list.
+// A tile that would overflow a region or the sort buffer (only degenerate data: low-complexity reads crowd one owner) is
+// not routed at all: its reads become candidates outright (k_seed looks every candidate up exactly), and the producer's
+// list of emitted tiles tells the consumer which tile a flag count belongs to.
+#define RT_OWNERS 256
+#define RT_FWORDS 32768                // 32-bit words of one owner's filter slice (128 KiB)
+#define RT_DUMMY_CAP 1024              // dummy entries a tile may hold (empty (owner, wave) pairs: ~400 of 4096 at nine seeds per read)
+#define RT_FLAG  0x80000000u
+#define RT_VALID 0x40000000u
+__host__ __device__ inline u32 rt_hash(u32 lo, u32 hi) { return table_hash(lo, hi); }       // owner = h >> 24, filter address = h & 0xFFFFFF
+__host__ __device__ inline void rt_filter_addr(u32 h24, u32& word, u32& mask) {
+    word = h24 >> 9;
+    const u32 b1 = (h24 >> 4) & 31u, b2 = (b1 + 1u + (h24 & 15u)) & 31u;      // two different bits of the word
+    mask = (1u << b1) | (1u << b2);
+}
+struct RouteDev {
+    GP<u32> arena;                   // [owner][producer][cap] entries
+    GP<u32> counts;                  // [owner][producer] entries written
+    GP<u32> emitted;                 // [producer][1 + tiles_max]: number of tiles routed, then their iteration numbers
+    GP<const u32> filter;            // [owner][RT_FWORDS]
+    GP<u32> flags;                   // candidate flag per read (zeroed per submission)
+    u32 cap, n_prod, tiles_max;
+};
+template <int WPR>
+__global__ __launch_bounds__(1024) void k_route(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
+                                                const RouteDev R, Counters* __restrict__ ctr) {
+    constexpr int NT = WPR - 1;
+    constexpr u32 SCAP = 1024u * NT + RT_DUMMY_CAP;
+    __shared__ u32 s_cnt[16][RT_OWNERS];          // per (wave, owner): count, later the start of the run in s_sorted
+    __shared__ u32 s_sorted[SCAP];
+    __shared__ u32 s_off[RT_OWNERS + 1];          // start of each owner's segment in s_sorted
+    __shared__ u32 s_cur[RT_OWNERS];              // entries written so far to region (owner, this workgroup)
+    __shared__ u32 s_wsum[4]; __shared__ u32 s_over;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 p = blockIdx.x, P = gridDim.x;
+    if (tid == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());
+    #pragma unroll
+    for (int j = 0; j < 4; j++) s_cnt[(tid >> 8) * 4 + j][tid & 255] = 0;
+    if (tid < RT_OWNERS) s_cur[tid] = 0;
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    const u64 n_groups = (n_reads + 63) >> 6, n_tiles = (n_reads + 1023) >> 10;
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    v2u xn[WPR / 2]; u16 len_raw = 0;
+    {
+        const u64 g0 = (u64)p * 16 + wave, gc = g0 < n_groups ? g0 : 0, r0 = gc * 64 + lane;
+        const v2u* row = reinterpret_cast<const v2u*>(packed) + gc * (32 * WPR) + lane;
+        #pragma unroll
+        for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
+        len_raw = lens[r0 < n_reads ? r0 : 0];
+    }
+    u32 n_emit = 0, k = 0;                        // tiles routed so far (thread 0 keeps the list), iteration number
+    for (u64 tile = p; tile < n_tiles; tile += P, k++) {
+        const u64 g = tile * 16 + wave, r = g * 64 + lane;
+        const bool live = g < n_groups && r < n_reads;
+        u32 w[WPR]; u32 len_cur;
+        #pragma unroll
+        for (int t2 = 0; t2 < WPR / 2; t2++) {     // register copies free xn[] for the loads below (see k_sieve_q)
+            asm volatile("v_mov_b32 %0, %1" : "=v"(w[2 * t2]) : "v"(xn[t2].x));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(w[2 * t2 + 1]) : "v"(xn[t2].y));
+        }
+        asm volatile("v_mov_b32 %0, %1" : "=v"(len_cur) : "v"((u32)len_raw));
+        {
+            const u64 gn = (tile + P) * 16 + wave, gc = gn < n_groups ? gn : 0, rn = gc * 64 + lane;
+            const v2u* row = reinterpret_cast<const v2u*>(packed) + gc * (32 * WPR) + lane;
+            #pragma unroll
+            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
+            len_raw = lens[rn < n_reads ? rn : 0];
+            asm volatile("" ::: "memory");
+        }
+        const u32 n = live ? (len_cur & 0x7FFFu) : 0u;
+        const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
+        // ---- hash every seed, count per (wave, owner); the returned count is the seed's rank inside its run
+        u32 hv[NT], rk[NT];
+        #pragma unroll
+        for (int t = 0; t < NT; t++) {
+            hv[t] = 0; rk[t] = 0xFFFFFFFFu;
+            if (t < nseeds) {
+                u32 fl; const u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl);
+                hv[t] = rt_hash((u32)c, (u32)(c >> 32));
+                rk[t] = atomicAdd(&s_cnt[wave][hv[t] >> 24], 1u);
+            }
+        }
+        __syncthreads();
+        // ---- 256 threads, one per owner: run lengths (an empty run holds one dummy), exclusive scan over the owners
+        u32 tot = 0, pre = 0;
+        if (tid < RT_OWNERS) {
+            #pragma unroll
+            for (int v = 0; v < 16; v++) { const u32 c = s_cnt[v][tid]; tot += c ? c : 1u; }
+            u32 wt; pre = wave_excl_scan_u32(tot, wt);
+            if (lane == 63) s_wsum[wave] = wt;
+        }
+        __syncthreads();
+        if (tid < RT_OWNERS) {
+            u32 off = pre;
+            for (int v = 0; v < wave; v++) off += s_wsum[v];
+            s_off[tid] = off;
+            if (tid == RT_OWNERS - 1) s_off[RT_OWNERS] = off + tot;
+            const bool over = s_cur[tid] + tot > R.cap || off + tot > SCAP;
+            if (over) s_over = 1;
+            #pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const u32 c = s_cnt[v][tid];
+                s_cnt[v][tid] = off;
+                if (c == 0) { if (off < SCAP) s_sorted[off] = RT_FLAG; off += 1; }      // dummy: flag without RT_VALID
+                else off += c;
+            }
+        }
+        __syncthreads();
+        if (s_over) {      // block-uniform: the tile is not routed, its reads are candidates
+            if (tid < 32) {
+                const u64 wi = tile * 32 + tid, first = wi * 32;
+                if (first < n_reads) { const u64 left = n_reads - first; R.flags[wi] = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u); }
+            }
+            #pragma unroll
+            for (int j = 0; j < 4; j++) s_cnt[(tid >> 8) * 4 + j][tid & 255] = 0;
+            __syncthreads();
+            if (tid == 0) s_over = 0;
+            __syncthreads();
+            continue;
+        }
+        // ---- scatter into (owner, wave) order
+        #pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (rk[t] != 0xFFFFFFFFu)
+                s_sorted[s_cnt[wave][hv[t] >> 24] + rk[t]] = (rk[t] == 0 ? RT_FLAG : 0u) | RT_VALID | ((u32)lane << 24) | (hv[t] & 0xFFFFFFu);
+        }
+        __syncthreads();
+        // ---- append every owner's segment to its region; wave v serves owners 16 v .. 16 v + 15
+        #pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const u32 o = (u32)wave * 16 + i;
+            const u32 b = s_off[o], e = s_off[o + 1], cur = s_cur[o];
+            auto dst = R.arena.g() + ((u64)o * P + p) * R.cap + cur;
+            for (u32 j = b + lane; j < e; j += 64) dst[j - b] = s_sorted[j];
+            if (lane == 0) s_cur[o] = cur + (e - b);
+        }
+        #pragma unroll
+        for (int j = 0; j < 4; j++) s_cnt[(tid >> 8) * 4 + j][tid & 255] = 0;
+        if (tid == 0) { R.emitted[(u64)p * (R.tiles_max + 1) + 1 + n_emit] = k; n_emit++; }
+        __syncthreads();
+    }
+    if (tid < RT_OWNERS) R.counts[(u64)tid * P + p] = s_cur[tid];
+    if (tid == 0) R.emitted[(u64)p * (R.tiles_max + 1)] = n_emit;
+}
+
+// examine up to 64 parked survivors of one wave: re-hash the read's seeds, probe the fingerprint sieve with those whose
+// hash is the entry's
+__device__ inline void rt_examine(const u64* q, u32 cnt, int lane, u32 owner, const u32* __restrict__ packed, const u16* __restrict__ lens, u32 wpr,
+                                  const uint4* __restrict__ sieve, u32 smask, u32 sshift, u32* flags) {
+    if ((u32)lane >= cnt) return;
+    const u64 e = q[lane];
+    const u64 rr = e & 0xFFFFFFFFull; const u32 want = (owner << 24) | (u32)(e >> 32);
+    const u32 n = lens[rr] & 0x7FFFu;
+    const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
+    bool hit = false;
+    u32 w0 = nseeds ? packed[packed_index(rr, wpr, 0)] : 0u;
+    for (int t = 0; t < nseeds && !hit; t++) {
+        const u32 w1 = packed[packed_index(rr, wpr, (u32)t + 1)];
+        u32 fl; const u64 c = canon40((u64)w0 | ((u64)(w1 & 0xFFu) << 32), fl);
+        if (rt_hash((u32)c, (u32)(c >> 32)) == want) hit = bin_exact(w0, w1, sieve, smask, sshift);
+        w0 = w1;
+    }
+    if (hit) atomicOr(&flags[rr >> 5], 1u << (rr & 31));
+}
+__global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ packed, const u16* __restrict__ lens, u32 wpr, u64 n_reads,
+                                                      const uint4* __restrict__ sieve, u32 smask, const RouteDev R, Counters* __restrict__ ctr) {
+    __shared__ __attribute__((aligned(16))) u32 s_f[RT_FWORDS];
+    __shared__ u64 s_q[16][128];                  // per-wave queue of entries that passed the filter: read | hash << 32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 owner = blockIdx.x, P = R.n_prod;
+    const u32 sshift = (u32)__clz((int)smask);
+    {
+        const v4u* g4 = reinterpret_cast<const v4u*>(R.filter.p + (u64)owner * RT_FWORDS); v4u* s4 = reinterpret_cast<v4u*>(s_f);
+        #pragma unroll
+        for (int j = 0; j < RT_FWORDS / 4 / 1024; j++) s4[tid + 1024 * j] = g4[tid + 1024 * j];
+    }
+    __syncthreads();
+    const u64 n_tiles = (n_reads + 1023) >> 10;
+    u64* const q = s_q[wave]; u32 qn = 0;          // wave-uniform
+    const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (u32 p = (u32)wave; p < P; p += 16) {      // this wave's regions
+        const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)R.counts[(u64)owner * P + p]);
+        const auto emit = R.emitted.g() + (u64)p * (R.tiles_max + 1);
+        const u32 n_mine = p < n_tiles ? (u32)((n_tiles - p + P - 1) / P) : 0u;      // tiles the producer was dealt
+        const bool ident = (u32)__builtin_amdgcn_readfirstlane((int)emit[0]) == n_mine;      // every one of them was routed
+        const auto ent = R.arena.g() + ((u64)owner * P + p) * R.cap;
+        int seq = -1;                               // flags seen so far - 1 = sequence number of the current (tile, wave) run
+        v4u en = (u32)lane * 4 < n ? __builtin_nontemporal_load(reinterpret_cast<const v4u GLOBAL_AS*>(ent) + lane) : v4u{0u, 0u, 0u, 0u};
+        for (u32 i0 = 0; i0 < n; i0 += 256) {
+            u32 ev[4];
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ev[0]) : "v"(en.x)); asm volatile("v_mov_b32 %0, %1" : "=v"(ev[1]) : "v"(en.y));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ev[2]) : "v"(en.z)); asm volatile("v_mov_b32 %0, %1" : "=v"(ev[3]) : "v"(en.w));
+            {
+                const u32 i1 = i0 + 256 + (u32)lane * 4;
+                en = i1 < n ? __builtin_nontemporal_load(reinterpret_cast<const v4u GLOBAL_AS*>(ent) + (i1 >> 2)) : v4u{0u, 0u, 0u, 0u};
+                asm volatile("" ::: "memory");
+            }
+            bool lv[4], fg[4]; u64 B[4]; u32 before = 0;
+            #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                lv[j] = i0 + (u32)lane * 4 + j < n;
+                fg[j] = lv[j] && (ev[j] & RT_FLAG);
+                B[j] = __ballot(fg[j]);
+                before += (u32)__popcll(B[j] & lt);
+            }
+            int run = seq + (int)before;
+            #pragma unroll
+            for (int j = 0; j < 4; j++) {
+                run += fg[j] ? 1 : 0;
+                bool pass = false;
+                if (lv[j] && (ev[j] & RT_VALID)) { u32 wd, mk; rt_filter_addr(ev[j] & 0xFFFFFFu, wd, mk); pass = (s_f[wd] & mk) == mk; }
+                u64 rr = 0;
+                if (pass) {
+                    const u32 jt = (u32)run >> 4, wv = (u32)run & 15u;
+                    const u32 kk = ident ? jt : emit[1 + jt];
+                    rr = (((u64)p + (u64)kk * P) * 16 + wv) * 64 + ((ev[j] >> 24) & 63u);
+                    pass = rr < n_reads;
+                }
+                const u64 pm = __ballot(pass);
+                if (pm) {
+                    if (pass) q[qn + (u32)__popcll(pm & lt)] = rr | ((u64)(ev[j] & 0xFFFFFFu) << 32);
+                    qn += (u32)__popcll(pm);
+                    if (qn >= 64) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        rt_examine(q + (qn - 64), 64, lane, owner, packed, lens, wpr, sieve, smask, sshift, R.flags.p);
+                        qn -= 64;
+                    }
+                }
+            }
+            seq += (int)(__popcll(B[0]) + __popcll(B[1]) + __popcll(B[2]) + __popcll(B[3]));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    rt_examine(q, qn, lane, owner, packed, lens, wpr, sieve, smask, sshift, R.flags.p);
+    __syncthreads();
     if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
 }
 
@@ -1784,6 +2048,7 @@ __global__ void k_advance(Counters* c, u64 n_reads) {
     c->cnt[MLST_CNT_CANDIDATES] += c->n_cand;
     c->cnt[MLST_CNT_READS_SEEN] += n_reads;
     c->items_done = ni; c->dp_done = nd; c->n_cand = 0;
+    c->n_res = 0;        // the result rows of a submission have been consumed by k_accumulate: the arena is reused by the next one
     for (int q = 0; q < EXT_Q; q++) c->ext_q[q][0] = 0;
 }
 
@@ -2040,6 +2305,10 @@ struct mlst_handle {
     u32* d_cand = nullptr; u64 cap_cand = 0;
     // XCD-binned sieve (big databases): per-owner Bloom filters (reference) and the per-submission arena
     u64* d_bloom = nullptr; u32 bloom_blk_bits = 0; bool binned = false;
+    // CU-routed sieve (K1c): filter slices (reference) and the per-submission arena
+    int sieve_kind = 0; u32 sieve_chain = 0; u64 n_keys = 0;
+    u32* d_rfilter = nullptr; u32* d_rt_arena = nullptr; u64 cap_rt_arena = 0; u32* d_rt_counts = nullptr; u32* d_rt_emitted = nullptr; u64 cap_rt_emitted = 0;
+    u32 rt_prod = 0, rt_cap = 0, rt_tiles_max = 0;
     u64* d_bin_arena = nullptr; u64 cap_bin_arena = 0; u32* d_bin_counts = nullptr; u32* d_bin_next = nullptr; u32* d_bin_flags = nullptr; u64 cap_bin_flags = 0;
     u32 bin_pw = 0, bin_blocks = 0; u64 bin_cap = 0;
     u8* d_in_bases = nullptr; u8* d_in_quals = nullptr; u64* d_in_off = nullptr; u64 cap_in_bytes = 0, cap_in_reads = 0;
@@ -2071,7 +2340,7 @@ struct mlst_handle {
     GraphSlot g_submit, g_typing; bool use_graphs = true;
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool;
-    double k_ms[9] = {0}; u64 k_n[9] = {0};
+    double k_ms[12] = {0}; u64 k_n[12] = {0};      // see mlst_get_kernel_time
     double wall_khz = 100000.0;                  // wall_clock64 rate (hipDeviceAttributeWallClockRate)
 };
 
@@ -2176,6 +2445,7 @@ static void free_ref(mlst_handle* h) {
     hipFree(h->d_sieve); hipFree(h->d_bitmap); h->d_bitmap = nullptr; hipFree(h->d_gbitmap); h->d_gbitmap = nullptr; hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
     hipFree(h->d_ascii); hipFree(h->d_aoff);
     hipFree(h->d_bloom); h->d_bloom = nullptr; h->binned = false;
+    hipFree(h->d_rfilter); h->d_rfilter = nullptr;
     hipFree(h->d_allele_no); hipFree(h->d_auto_chosen); hipFree(h->d_fixed_colbase); hipFree(h->d_auto_counts); hipFree(h->d_auto_letters);
     if (h->h_auto) { hipHostFree(h->h_auto); h->h_auto = nullptr; }
     h->d_allele_no = h->d_auto_chosen = nullptr; h->d_fixed_colbase = nullptr; h->d_auto_counts = nullptr; h->d_auto_letters = nullptr; h->auto_pending = false;
@@ -2187,6 +2457,8 @@ static void free_state(mlst_handle* h) {
     EngineDev& E = h->E;
     hipFree(h->d_bin_arena); hipFree(h->d_bin_counts); hipFree(h->d_bin_next); hipFree(h->d_bin_flags);
     h->d_bin_arena = nullptr; h->d_bin_counts = nullptr; h->d_bin_next = nullptr; h->d_bin_flags = nullptr; h->cap_bin_arena = 0; h->cap_bin_flags = 0; h->bin_pw = 0;
+    hipFree(h->d_rt_arena); hipFree(h->d_rt_counts); hipFree(h->d_rt_emitted);
+    h->d_rt_arena = nullptr; h->d_rt_counts = nullptr; h->d_rt_emitted = nullptr; h->cap_rt_arena = 0; h->cap_rt_emitted = 0; h->rt_prod = 0;
     hipFree(h->d_E); h->d_E = nullptr;
     hipFree(h->d_stats); h->d_stats = nullptr; if (h->h_stats) { hipHostFree(h->h_stats); h->h_stats = nullptr; }
     hipFree(E.ret_bases); hipFree(E.ret_quals); hipFree(E.ret_len); hipFree(E.ret_ridx); hipFree(E.ret_nrec);
@@ -2227,83 +2499,133 @@ static int reset_sample_state(mlst_handle* h) {
 }
 
 // Build the device-resident reference: transposed 2-bit allele arena, N masks, seed sieve and exact seed table.
-extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const uint64_t* off, const uint32_t* locus_id,
-                                   const uint32_t* species_id, const int32_t* allele_no, uint32_t n_alleles) {
-    if (!h || !off || !locus_id) return fail(h, MLST_E_INVALID, "NULL argument");
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
-    free_ref(h); free_state(h);
-    for (auto* g : {&h->g_submit, &h->g_typing}) { if (g->exec) { hipGraphExecDestroy(g->exec); g->exec = nullptr; } g->sig.clear(); }
-    h->n_alleles = n_alleles;
+// ---- host-side index (everything of mlst_load_reference that does not depend on the device)
+struct HostIndex {
+    std::vector<LocusDev> loci; std::vector<u16> alen;
+    std::vector<u32> arena, nmask, planes;
+    std::vector<u64> tkeys; std::vector<u32> tvals, posts; u32 tmask = 0;
+    std::vector<u16> sv; u64 nb = 0; u32 smask = 0, sieve_chain = 0;      // fingerprint sieve; longest overflow walk of any key
+    std::vector<u32> bitmap; double bitmap_fill = 0.0;                   // LDS half-seed bitmaps (small databases)
+    std::vector<u32> gbitmap; u32 gbits = 0;                             // hashed global bitmap (MLST_SIEVE=global)
+    std::vector<u64> bloom; u32 blk_bits = 0;                            // XCD-binned Bloom filters (MLST_SIEVE=binned)
+    std::vector<u32> rfilter;                                            // CU-routed filter slices (big databases)
+    u64 n_keys = 0; u32 n_loci = 0; int kind = 0;                        // kind: MLST_SIEVE_* below
+    std::string err; int err_code = 0;
+};
+enum { MLST_SIEVE_LDS = 0, MLST_SIEVE_GLOBAL = 1, MLST_SIEVE_BINNED = 2, MLST_SIEVE_ROUTED = 3 };
+struct KP { u64 key; u32 post; };
+
+static u64 fnv1a(const void* p, u64 n, u64 hsh) {       // eight bytes at a time (a cache key, not a checksum of record)
+    const u8* b = (const u8*)p; u64 i = 0;
+    for (; i + 8 <= n; i += 8) { u64 v; memcpy(&v, b + i, 8); hsh = (hsh ^ v) * 0x100000001B3ull; hsh ^= hsh >> 29; }
+    for (; i < n; i++) hsh = (hsh ^ b[i]) * 0x100000001B3ull;
+    return hsh;
+}
+
+// Builds the index.  The alleles of a locus repeat most of their seeds (they differ by a few SNPs) and a posting names
+// (locus, strand, position), so seeds are made unique locus by locus -- loci on as many host threads as there are -- and
+// an allele only emits the windows in which it differs from the allele before it (alleles arrive in similarity order);
+// the one sort of the whole index then handles ~4 % of the raw pairs of a many-species database.
+static std::shared_ptr<HostIndex> build_host_index(const uint8_t* ascii, const uint64_t* off, const uint32_t* locus_id,
+                                                   const uint32_t* species_id, uint32_t n_alleles, int want_kind) {
+    auto H = std::make_shared<HostIndex>();
+    auto bad = [&](int code, const char* fmt, ...) { char buf[256]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); H->err = buf; H->err_code = code; return H; };
     // ---- locus table
     u32 n_loci = 0;
     for (u32 a = 0; a < n_alleles; a++) {
-        if (locus_id[a] > MLST_MAX_LOCI) return fail(h, MLST_E_LIMIT, "locus id %u exceeds %d", locus_id[a], MLST_MAX_LOCI);
+        if (locus_id[a] > MLST_MAX_LOCI) return bad(MLST_E_LIMIT, "locus id %u exceeds %d", locus_id[a], MLST_MAX_LOCI);
         n_loci = std::max(n_loci, locus_id[a] + 1);
-        if (off[a + 1] - off[a] > MLST_MAX_ALLELE_LEN) return fail(h, MLST_E_LIMIT, "allele %u longer than %d", a, MLST_MAX_ALLELE_LEN);
+        if (off[a + 1] - off[a] > MLST_MAX_ALLELE_LEN) return bad(MLST_E_LIMIT, "allele %u longer than %d", a, MLST_MAX_ALLELE_LEN);
     }
-    h->n_loci = n_loci;
-    std::vector<LocusDev> loci(n_loci); for (auto& L : loci) memset(&L, 0, sizeof L);
+    H->n_loci = n_loci;
+    std::vector<LocusDev>& loci = H->loci; loci.resize(n_loci); for (auto& L : loci) memset(&L, 0, sizeof L);
     std::vector<char> seen(n_loci, 0);
     for (u32 a = 0; a < n_alleles; a++) {
         LocusDev& L = loci[locus_id[a]];
         if (!seen[locus_id[a]]) { seen[locus_id[a]] = 1; L.a_begin = a; L.species = species_id ? species_id[a] : 0; }
-        else if (L.a_begin + L.n_alleles != a) return fail(h, MLST_E_INVALID, "alleles of locus %u are not contiguous", locus_id[a]);
+        else if (L.a_begin + L.n_alleles != a) return bad(MLST_E_INVALID, "alleles of locus %u are not contiguous", locus_id[a]);
         L.n_alleles++; L.max_len = std::max(L.max_len, (u32)(off[a + 1] - off[a]));
     }
     u64 arena_words = 0, nmask_words = 0, plane_words = 0;
-    std::vector<u16> alen(n_alleles); h->allele_locus.assign(locus_id, locus_id + n_alleles);
-    for (u32 a = 0; a < n_alleles; a++) {
-        alen[a] = (u16)(off[a + 1] - off[a]);
-        for (u64 i = off[a]; i < off[a + 1]; i++) if (base_code(ascii[i]) > 3) { loci[locus_id[a]].has_n = 1; break; }
-    }
+    std::vector<u16>& alen = H->alen; alen.resize(n_alleles);
+    for (u32 a = 0; a < n_alleles; a++) alen[a] = (u16)(off[a + 1] - off[a]);
     for (auto& L : loci) {
-        if (L.n_alleles >= (1u << 20)) return fail(h, MLST_E_LIMIT, "locus with %u alleles exceeds 2^20", L.n_alleles);
+        if (L.n_alleles >= (1u << 20)) return bad(MLST_E_LIMIT, "locus with %u alleles exceeds 2^20", L.n_alleles);
         L.n_pad = (L.n_alleles + 63) & ~63u; L.words = (L.max_len + 15) / 16 + 2; L.nwords = (L.max_len + 31) / 32 + 1;
-        if ((u64)L.words * L.n_pad * 4 >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "a locus arena exceeds 4 GB");
+        if ((u64)L.words * L.n_pad * 4 >= (1ull << 32)) return bad(MLST_E_LIMIT, "a locus arena exceeds 4 GB");
         L.arena_off = arena_words; arena_words += (u64)L.words * L.n_pad;
         L.pblocks = (L.max_len + 31) / 32 + 1; L.plane_off = plane_words; plane_words += (u64)L.pblocks * 2 * L.n_pad;
-        if (L.has_n) { L.nmask_off = nmask_words; nmask_words += (u64)L.nwords * L.n_pad; }
     }
-    std::vector<u32> arena(arena_words ? arena_words : 1, 0), nmask(nmask_words ? nmask_words : 1, 0), planes(plane_words ? plane_words : 1, 0);
-    // ---- arena fill + seed pairs
-    struct KP { u64 key; u32 post; };
+    // N-mask rows only for loci that hold a non-ACGT character: found per locus below, laid out afterwards
+    std::vector<u32>& arena = H->arena; std::vector<u32>& planes = H->planes;
+    arena.assign(arena_words ? arena_words : 1, 0); planes.assign(plane_words ? plane_words : 1, 0);
+    if (planes.size() * 4 >= (1ull << 32)) return bad(MLST_E_LIMIT, "allele bit-plane arena exceeds 4 GB (32-bit offsets in k_extend)");
+    // ---- per locus, in parallel: arena rows, seed pairs (unique within the locus)
+    std::vector<std::vector<KP>> lkp(n_loci);
+    std::vector<std::vector<std::pair<u32, u32>>> lnpos(n_loci);      // (allele, position) of non-ACGT characters
+    {
+        unsigned nthr = std::thread::hardware_concurrency(); if (nthr < 1) nthr = 1; if (nthr > 64) nthr = 64; if (nthr > n_loci) nthr = n_loci ? n_loci : 1;
+        std::atomic<u32> next(0);
+        auto work = [&]() {
+            std::vector<u8> code; std::vector<u64> prev;
+            for (;;) {
+                const u32 l = next.fetch_add(1); if (l >= n_loci) break;
+                const LocusDev& L = loci[l]; std::vector<KP>& out = lkp[l];
+                prev.assign(L.max_len + 1, ~0ull);
+                for (u32 a = L.a_begin; a < L.a_begin + L.n_alleles; a++) {
+                    const u32 al = a - L.a_begin, len = alen[a];
+                    code.resize(len);
+                    for (u32 i = 0; i < len; i++) {
+                        const int c = base_code(ascii[off[a] + i]); code[i] = (u8)c;
+                        if (c < 4) {
+                            arena[L.arena_off + (u64)(i >> 4) * L.n_pad + al] |= (u32)c << (2 * (i & 15));
+                            planes[L.plane_off + (u64)((i >> 5) * 2) * L.n_pad + al] |= (u32)(c & 1) << (i & 31);
+                            planes[L.plane_off + (u64)((i >> 5) * 2 + 1) * L.n_pad + al] |= (u32)(c >> 1) << (i & 31);
+                        } else lnpos[l].push_back({al, i});
+                    }
+                    if (len < MLST_SEED_LEN) continue;
+                    // rolling forward key and reverse-complement key of the window [p, p+20)
+                    int badw = 0; u64 fk = 0, rk = 0; const u64 mask40 = (1ull << 40) - 1;
+                    for (u32 i = 0; i < len; i++) {
+                        int c = code[i];
+                        if (c > 3) { badw = MLST_SEED_LEN; c = 0; } else if (badw) badw--;
+                        fk = (fk >> 2) | ((u64)c << 38);                 // base t of the window at bits 2t
+                        rk = ((rk << 2) | (u64)(3 - c)) & mask40;        // rc base t = 3 - code[p+19-t]
+                        if (i + 1 >= MLST_SEED_LEN) {
+                            const u32 p = i + 1 - MLST_SEED_LEN;
+                            if (badw) { prev[p] = ~0ull; continue; }
+                            if (prev[p] == fk) continue;                  // the allele before this one had the same window here
+                            prev[p] = fk;
+                            // canonical entry: flag = 1 when the reverse complement is the smaller (canonical) form
+                            const u64 ck = fk < rk ? fk : rk; const u32 fl = rk < fk ? 1u : 0u;
+                            out.push_back({ck, (l << 13) | (fl << 12) | p});
+                            if (fk == rk) out.push_back({ck, (l << 13) | (1u << 12) | p});   // palindrome: both strands
+                        }
+                    }
+                    for (u32 pz = len >= MLST_SEED_LEN ? len - MLST_SEED_LEN + 1 : 0; pz < prev.size(); pz++) prev[pz] = ~0ull;   // windows this allele does not have
+                    if (out.size() > (1u << 18)) {
+                        std::sort(out.begin(), out.end(), [](const KP& x, const KP& y) { return x.key != y.key ? x.key < y.key : x.post < y.post; });
+                        out.erase(std::unique(out.begin(), out.end(), [](const KP& x, const KP& y) { return x.key == y.key && x.post == y.post; }), out.end());
+                    }
+                }
+                std::sort(out.begin(), out.end(), [](const KP& x, const KP& y) { return x.key != y.key ? x.key < y.key : x.post < y.post; });
+                out.erase(std::unique(out.begin(), out.end(), [](const KP& x, const KP& y) { return x.key == y.key && x.post == y.post; }), out.end());
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; t++) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+    }
+    for (u32 l = 0; l < n_loci; l++) if (!lnpos[l].empty()) { loci[l].has_n = 1; loci[l].nmask_off = nmask_words; nmask_words += (u64)loci[l].nwords * loci[l].n_pad; }
+    std::vector<u32>& nmask = H->nmask; nmask.assign(nmask_words ? nmask_words : 1, 0);
+    if (nmask.size() * 4 >= (1ull << 32)) return bad(MLST_E_LIMIT, "N-mask arena exceeds 4 GB (32-bit offsets in k_extend)");
+    for (u32 l = 0; l < n_loci; l++) for (auto& ap : lnpos[l]) nmask[loci[l].nmask_off + (u64)(ap.second >> 5) * loci[l].n_pad + ap.first] |= 1u << (ap.second & 31);
     std::vector<KP> kp;
-    { u64 tot = 0; for (u32 a = 0; a < n_alleles; a++) if (alen[a] >= MLST_SEED_LEN) tot += 2ull * (alen[a] - MLST_SEED_LEN + 1); kp.reserve(tot); }
-    std::vector<u8> code;
-    for (u32 a = 0; a < n_alleles; a++) {
-        const LocusDev& L = loci[locus_id[a]]; u32 al = a - L.a_begin; u32 len = alen[a];
-        code.resize(len);
-        for (u32 i = 0; i < len; i++) {
-            int c = base_code(ascii[off[a] + i]); code[i] = (u8)c;
-            if (c < 4) {
-                arena[L.arena_off + (u64)(i >> 4) * L.n_pad + al] |= (u32)c << (2 * (i & 15));
-                planes[L.plane_off + (u64)((i >> 5) * 2) * L.n_pad + al] |= (u32)(c & 1) << (i & 31);
-                planes[L.plane_off + (u64)((i >> 5) * 2 + 1) * L.n_pad + al] |= (u32)(c >> 1) << (i & 31);
-            }
-            else nmask[L.nmask_off + (u64)(i >> 5) * L.n_pad + al] |= 1u << (i & 31);
-        }
-        if (len < MLST_SEED_LEN) continue;
-        // rolling forward key and reverse-complement key of the window [p, p+20)
-        int bad = 0; u64 fk = 0, rk = 0; const u64 mask40 = (1ull << 40) - 1;
-        for (u32 i = 0; i < len; i++) {
-            int c = code[i];
-            if (c > 3) { bad = MLST_SEED_LEN; c = 0; } else if (bad) bad--;
-            fk = (fk >> 2) | ((u64)c << 38);                 // base t of the window at bits 2t
-            rk = ((rk << 2) | (u64)(3 - c)) & mask40;        // rc base t = 3 - code[p+19-t]
-            if (i + 1 >= MLST_SEED_LEN && !bad) {
-                u32 p = i + 1 - MLST_SEED_LEN;
-                // canonical entry: flag = 1 when the reverse complement is the smaller (canonical) form
-                u64 ck = fk < rk ? fk : rk; u32 fl = rk < fk ? 1u : 0u;
-                kp.push_back({ck, (locus_id[a] << 13) | (fl << 12) | p});
-                if (fk == rk) kp.push_back({ck, (locus_id[a] << 13) | (1u << 12) | p});   // palindrome: both strands
-            }
-        }
-    }
+    { u64 tot = 0; for (auto& v : lkp) tot += v.size(); kp.reserve(tot); for (auto& v : lkp) { kp.insert(kp.end(), v.begin(), v.end()); std::vector<KP>().swap(v); } }
     std::sort(kp.begin(), kp.end(), [](const KP& x, const KP& y) { return x.key != y.key ? x.key < y.key : x.post < y.post; });
-    kp.erase(std::unique(kp.begin(), kp.end(), [](const KP& x, const KP& y) { return x.key == y.key && x.post == y.post; }), kp.end());
     // group, drop repetitive seeds
-    std::vector<u64> ukeys; std::vector<u32> uval; std::vector<u32> posts;
+    std::vector<u64> ukeys; std::vector<u32> uval; std::vector<u32>& posts = H->posts;
     for (size_t i = 0; i < kp.size();) {
         size_t j = i; while (j < kp.size() && kp[j].key == kp[i].key) j++;
         size_t cnt = j - i;
@@ -2311,7 +2633,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
             ukeys.push_back(kp[i].key);
             if (cnt == 1) uval.push_back(0x80000000u | kp[i].post);
             else {
-                if (posts.size() >= (1ull << 26)) return fail(h, MLST_E_LIMIT, "posting list exceeds 2^26 entries");
+                if (posts.size() >= (1ull << 26)) return bad(MLST_E_LIMIT, "posting list exceeds 2^26 entries");
                 uval.push_back(((u32)posts.size() << 5) | (u32)cnt);
                 for (size_t t = i; t < j; t++) posts.push_back(kp[t].post);
             }
@@ -2319,40 +2641,49 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         i = j;
     }
     std::vector<KP>().swap(kp);
-    const u64 nk = ukeys.size();
+    const u64 nk = ukeys.size(); H->n_keys = nk;
     // ---- exact table: open addressing, load <= 0.5
     u64 tcap = 1024; while (tcap < 2 * nk) tcap <<= 1;
-    if (tcap > (1ull << 32)) return fail(h, MLST_E_LIMIT, "seed table too large");
-    std::vector<u64> tkeys(tcap, KEY_EMPTY); std::vector<u32> tvals(tcap, 0);
-    u32 tmask = (u32)(tcap - 1);
+    if (tcap > (1ull << 32)) return bad(MLST_E_LIMIT, "seed table too large");
+    std::vector<u64>& tkeys = H->tkeys; std::vector<u32>& tvals = H->tvals; tkeys.assign(tcap, KEY_EMPTY); tvals.assign(tcap, 0);
+    const u32 tmask = (u32)(tcap - 1); H->tmask = tmask;
     for (u64 i = 0; i < nk; i++) {
         u32 lo = (u32)ukeys[i], hi = (u32)(ukeys[i] >> 32);
         u32 hh = table_hash(lo, hi) & tmask;
         while (tkeys[hh] != KEY_EMPTY) hh = (hh + 1) & tmask;
         tkeys[hh] = ukeys[i]; tvals[hh] = uval[i];
     }
-    // ---- sieve: 16-byte buckets of eight 16-bit fingerprints, mean fill <= 4
+    // ---- sieve: 16-byte buckets of eight 16-bit fingerprints, mean fill <= 4.  A key whose home bucket is full moves on
+    // to the next one; the kernels follow such a chain for at most 64 buckets, so the build checks the longest walk and
+    // doubles the sieve until it is far below that (it never is in practice: mean fill <= 4 of 8 slots).
     u64 nb = 256; while (nb * 4 < nk) nb <<= 1;
-    if (nb > (1ull << 31)) return fail(h, MLST_E_LIMIT, "sieve too large");
-    std::vector<u16> sv(nb * 8, 0); u32 smask = (u32)(nb - 1);
-    u32 sshift_h = 32; for (u64 t = nb; t > 1; t >>= 1) sshift_h--;      // nb = 2^(32 - sshift_h)
-    for (u64 i = 0; i < nk; i++) {
-        u32 lo = (u32)ukeys[i], hi = (u32)(ukeys[i] >> 32);
-        u32 fp = sieve_fp(lo, hi); u32 b = sieve_bucket_hash(lo, hi) >> sshift_h;
-        for (u64 step = 0; step < nb; step++) {
-            u16* B = &sv[(u64)b * 8]; int k; bool done = false;
-            for (k = 0; k < 8; k++) { if (B[k] == fp) { done = true; break; } if (B[k] == 0) { B[k] = (u16)fp; done = true; break; } }
-            if (done) break;
-            b = (b + 1) & smask;
+    for (;;) {
+        if (nb > (1ull << 31)) return bad(MLST_E_LIMIT, "sieve too large");
+        std::vector<u16>& sv = H->sv; sv.assign(nb * 8, 0); const u32 smask = (u32)(nb - 1);
+        u32 sshift_h = 32; for (u64 t = nb; t > 1; t >>= 1) sshift_h--;      // nb = 2^(32 - sshift_h)
+        u32 longest = 0;
+        for (u64 i = 0; i < nk; i++) {
+            u32 lo = (u32)ukeys[i], hi = (u32)(ukeys[i] >> 32);
+            u32 fp = sieve_fp(lo, hi); u32 b = sieve_bucket_hash(lo, hi) >> sshift_h;
+            for (u64 step = 0; step < nb; step++) {
+                u16* B = &sv[(u64)b * 8]; int k; bool done = false;
+                for (k = 0; k < 8; k++) { if (B[k] == fp) { done = true; break; } if (B[k] == 0) { B[k] = (u16)fp; done = true; break; } }
+                if (done) { if ((u32)step > longest) longest = (u32)step; break; }
+                b = (b + 1) & smask;
+            }
         }
+        H->nb = nb; H->smask = smask; H->sieve_chain = longest;
+        if (longest <= 32) break;
+        nb <<= 1;
     }
-    // ---- first-level bitmap (LDS resident in k_sieve_q<., true>): only when it is selective
-    std::vector<u32> bitmap;
-    {
+    // ---- first-level filter.  Small databases: two half-seed bitmaps kept in LDS by k_sieve_q<., true>, used when they
+    // turn out at most half full.  Everything else: the CU-routed filter slices (K1c).  MLST_SIEVE = lds / routed /
+    // binned / global forces a kind (tests, A/B measurements; "lds" still falls back when the bitmaps are not selective).
+    int kind = want_kind;
+    if (kind < 0 || kind == MLST_SIEVE_LDS) {
         const u64 nbits = 1ull << BITMAP_BITS;
-        const char* off_sw = getenv("MLST_NO_LDS_SIEVE");   // test / tuning switch: force the plain sieve kernel
-        if (nk <= 4 * nbits && !(off_sw && off_sw[0] == '1')) {       // kept only if it turns out at most half full
-            bitmap.assign(nbits / 32, 0);
+        if (nk <= 4 * nbits) {
+            std::vector<u32>& bitmap = H->bitmap; bitmap.assign(nbits / 32, 0);
             u64 set = 0;
             for (u64 i = 0; i < nk; i++) {      // both orientations of every seed (see k_sieve_q)
                 for (int o = 0; o < 2; o++) {
@@ -2362,39 +2693,89 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
                     if (!((bitmap[R >> 5] >> (R & 31)) & 1u)) { bitmap[R >> 5] |= 1u << (R & 31); set++; }
                 }
             }
-            h->bitmap_fill = (double)set / (double)nbits;       // mean fill of the two halves; a seed passes with ~fill^2
-            if (set * 2 > nbits) { bitmap.clear(); h->bitmap_fill = 0.0; }   // more than half full: not selective, use the plain kernel
+            H->bitmap_fill = (double)set / (double)nbits;       // mean fill of the two halves; a seed passes with ~fill^2
+            if (set * 2 > nbits) { bitmap.clear(); H->bitmap_fill = 0.0; }   // more than half full: not selective
         }
+        kind = H->bitmap.empty() ? MLST_SIEVE_ROUTED : MLST_SIEVE_LDS;
     }
-    // ---- larger first-level bitmap in global memory when the LDS one is not used (big databases)
-    std::vector<u32> gbitmap; u32 gbits = 0;
-    if (bitmap.empty() && nk > 0) {
+    if (nk == 0) kind = H->bitmap.empty() ? MLST_SIEVE_GLOBAL : MLST_SIEVE_LDS;      // nothing to look up: the plain kernel with no first level
+    if (kind == MLST_SIEVE_GLOBAL && nk > 0) {
         const char* gsw = getenv("MLST_GBM_BITS");            // tuning switch: 0 disables, default 25 (4 MiB)
-        gbits = gsw ? (u32)atoi(gsw) : 25u;
+        u32 gbits = gsw ? (u32)atoi(gsw) : 25u;
         if (gbits >= 16 && gbits <= 31 && nk <= (1ull << gbits)) {      // keep the expected fill below ~63 %
-            gbitmap.assign((1ull << gbits) / 32, 0);
-            for (u64 i = 0; i < nk; i++) { u32 bi = bitmap_hash_bits((u32)ukeys[i], (u32)(ukeys[i] >> 32), gbits); gbitmap[bi >> 5] |= 1u << (bi & 31); }
-        } else gbits = 0;
-    }
-    // ---- XCD-binned sieve (big databases): one blocked Bloom filter per owner (key range), 2 MiB each so that it stays
-    // in the owner XCD's L2 beside the entry stream; built whenever the LDS first level is not in use
-    std::vector<u64> bloom; u32 blk_bits = 0;
-    {
-        // worth it once the shared first-level bitmap is crowded (cfg3 size: 12.7 M seeds, 5.8 -> 4.2 ms; at 4.2 M seeds the
-        // single kernel is still 10 % ahead).  MLST_BINNED=1 / 0 forces it on / off (tests, tuning).
-        const char* bsw = getenv("MLST_BINNED");
-        const bool want = bsw ? bsw[0] == '1' : nk >= 8000000ull;
-        if (bitmap.empty() && nk > 0 && want) {
-            const char* bb = getenv("MLST_BLOOM_BITS"); blk_bits = bb ? (u32)atoi(bb) : 18u;     // 2^18 blocks x 8 B = 2 MiB per owner (swept 17..20 on cfg3)
-            if (blk_bits < 10 || blk_bits > 22) blk_bits = 18;
-            bloom.assign((u64)BIN_OWNERS << blk_bits, 0ull);
-            for (u64 i = 0; i < nk; i++) {
-                u32 owner, bi; u64 h36, m; bin_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32), owner, h36);
-                bin_bloom_addr(h36, blk_bits, bi, m);
-                bloom[((u64)owner << blk_bits) + bi] |= m;
-            }
+            H->gbitmap.assign((1ull << gbits) / 32, 0); H->gbits = gbits;
+            for (u64 i = 0; i < nk; i++) { u32 bi = bitmap_hash_bits((u32)ukeys[i], (u32)(ukeys[i] >> 32), gbits); H->gbitmap[bi >> 5] |= 1u << (bi & 31); }
         }
     }
+    if (kind == MLST_SIEVE_BINNED) {
+        const char* bb = getenv("MLST_BLOOM_BITS"); u32 blk_bits = bb ? (u32)atoi(bb) : 18u;     // 2^18 blocks x 8 B = 2 MiB per owner
+        if (blk_bits < 10 || blk_bits > 22) blk_bits = 18;
+        H->blk_bits = blk_bits; H->bloom.assign((u64)BIN_OWNERS << blk_bits, 0ull);
+        for (u64 i = 0; i < nk; i++) {
+            u32 owner, bi; u64 h36, m; bin_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32), owner, h36);
+            bin_bloom_addr(h36, blk_bits, bi, m);
+            H->bloom[((u64)owner << blk_bits) + bi] |= m;
+        }
+    }
+    if (kind == MLST_SIEVE_ROUTED) {
+        H->rfilter.assign((u64)RT_OWNERS * RT_FWORDS, 0u);
+        for (u64 i = 0; i < nk; i++) {
+            const u32 hh = rt_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32)); u32 wd, mk; rt_filter_addr(hh & 0xFFFFFFu, wd, mk);
+            H->rfilter[(u64)(hh >> 24) * RT_FWORDS + wd] |= mk;
+        }
+    }
+    H->kind = kind;
+    return H;
+}
+
+// The last host index built in this process: a second engine that loads the same database (several engines per GPU,
+// several GPUs per process) uploads it without building it again.
+static std::mutex g_index_mu;
+static std::shared_ptr<HostIndex> g_index_last; static u64 g_index_key[3] = {0, 0, 0};
+
+static int sieve_kind_from_env() {
+    const char* s = getenv("MLST_SIEVE");
+    if (!s || !s[0]) return -1;
+    if (!strcmp(s, "lds")) return MLST_SIEVE_LDS;
+    if (!strcmp(s, "global")) return MLST_SIEVE_GLOBAL;
+    if (!strcmp(s, "binned")) return MLST_SIEVE_BINNED;
+    if (!strcmp(s, "routed")) return MLST_SIEVE_ROUTED;
+    return -1;
+}
+
+// Build the device-resident reference: transposed 2-bit allele arena, N masks, seed sieve and exact seed table.
+extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const uint64_t* off, const uint32_t* locus_id,
+                                   const uint32_t* species_id, const int32_t* allele_no, uint32_t n_alleles) {
+    if (!h || !off || !locus_id) return fail(h, MLST_E_INVALID, "NULL argument");
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    free_ref(h); free_state(h);
+    for (auto* g : {&h->g_submit, &h->g_typing}) { if (g->exec) { hipGraphExecDestroy(g->exec); g->exec = nullptr; } g->sig.clear(); }
+    h->n_alleles = n_alleles;
+    const int want_kind = sieve_kind_from_env();
+    std::shared_ptr<HostIndex> HI;
+    {
+        u64 key[3];
+        key[0] = fnv1a(off, ((u64)n_alleles + 1) * 8, 0xCBF29CE484222325ull ^ n_alleles);
+        key[1] = fnv1a(ascii, off[n_alleles], fnv1a(locus_id, (u64)n_alleles * 4, 0x9E3779B97F4A7C15ull));
+        key[2] = (u64)(want_kind + 2);
+        for (const char* v : {"MLST_GBM_BITS", "MLST_BLOOM_BITS"}) { const char* e = getenv(v); if (e) key[2] = fnv1a(e, strlen(e), key[2]); }
+        if (species_id) key[2] = fnv1a(species_id, (u64)n_alleles * 4, key[2]);
+        std::lock_guard<std::mutex> lk(g_index_mu);
+        if (g_index_last && g_index_key[0] == key[0] && g_index_key[1] == key[1] && g_index_key[2] == key[2]) HI = g_index_last;
+        else {
+            HI = build_host_index(ascii, off, locus_id, species_id, n_alleles, want_kind);
+            if (HI->err_code) return fail(h, HI->err_code, "%s", HI->err.c_str());
+            g_index_last = HI; g_index_key[0] = key[0]; g_index_key[1] = key[1]; g_index_key[2] = key[2];
+        }
+    }
+    const u32 n_loci = HI->n_loci; h->n_loci = n_loci;
+    const std::vector<LocusDev>& loci = HI->loci; const std::vector<u16>& alen = HI->alen;
+    const std::vector<u32>&arena = HI->arena, &nmask = HI->nmask, &planes = HI->planes, &posts = HI->posts, &tvals = HI->tvals, &bitmap = HI->bitmap, &gbitmap = HI->gbitmap;
+    const std::vector<u64>&tkeys = HI->tkeys, &bloom = HI->bloom; const std::vector<u16>& sv = HI->sv;
+    const u64 tcap = tkeys.size(), nb = HI->nb; const u32 tmask = HI->tmask, smask = HI->smask, gbits = HI->gbits, blk_bits = HI->blk_bits;
+    h->allele_locus.assign(locus_id, locus_id + n_alleles);
+    h->sieve_kind = HI->kind; h->sieve_chain = HI->sieve_chain; h->n_keys = HI->n_keys;
     // ---- tables derived from the parameters
     std::vector<int> floor_tab(MLST_MAX_READ_LEN + 1);
     for (int n = 0; n <= MLST_MAX_READ_LEN; n++) {
@@ -2405,7 +2786,6 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     for (int q = 0; q < 256; q++) { int qq = q > 40 ? 40 : q; pen_tab[q] = (u8)(h->prm.mm_min + ((h->prm.mm_max - h->prm.mm_min) * qq) / 40); }
     // ---- upload
     HIPCHK(h, dmalloc(&h->d_arena, arena.size())); HIPCHK(h, hipMemcpy(h->d_arena, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
-    if (planes.size() * 4 >= (1ull << 32) || nmask.size() * 4 >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "allele bit-plane arena exceeds 4 GB (32-bit offsets in k_extend)");
     HIPCHK(h, dmalloc(&h->d_planes, planes.size())); HIPCHK(h, hipMemcpy(h->d_planes, planes.data(), planes.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_nmask, nmask.size())); HIPCHK(h, hipMemcpy(h->d_nmask, nmask.data(), nmask.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_allele_len, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_len, alen.data(), (u64)n_alleles * 2, hipMemcpyHostToDevice));
@@ -2414,6 +2794,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_sieve, nb)); HIPCHK(h, hipMemcpy(h->d_sieve, sv.data(), nb * 16, hipMemcpyHostToDevice));
     if (!bitmap.empty()) { HIPCHK(h, dmalloc(&h->d_bitmap, (u64)bitmap.size())); HIPCHK(h, hipMemcpy(h->d_bitmap, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice)); }
     if (!bloom.empty()) { HIPCHK(h, dmalloc(&h->d_bloom, (u64)bloom.size())); HIPCHK(h, hipMemcpy(h->d_bloom, bloom.data(), bloom.size() * 8, hipMemcpyHostToDevice)); h->bloom_blk_bits = blk_bits; h->binned = true; }
+    if (!HI->rfilter.empty()) { HIPCHK(h, dmalloc(&h->d_rfilter, (u64)HI->rfilter.size())); HIPCHK(h, hipMemcpy(h->d_rfilter, HI->rfilter.data(), HI->rfilter.size() * 4, hipMemcpyHostToDevice)); }
     if (!gbitmap.empty()) { HIPCHK(h, dmalloc(&h->d_gbitmap, (u64)gbitmap.size())); HIPCHK(h, hipMemcpy(h->d_gbitmap, gbitmap.data(), gbitmap.size() * 4, hipMemcpyHostToDevice)); }
     HIPCHK(h, dmalloc(&h->d_keys, tcap)); HIPCHK(h, hipMemcpy(h->d_keys, tkeys.data(), tcap * 8, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_vals, tcap)); HIPCHK(h, hipMemcpy(h->d_vals, tvals.data(), tcap * 4, hipMemcpyHostToDevice));
@@ -2423,7 +2804,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     u64 abytes = off[n_alleles];
     HIPCHK(h, dmalloc(&h->d_ascii, abytes)); if (abytes) HIPCHK(h, hipMemcpy(h->d_ascii, ascii, abytes, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_aoff, (u64)n_alleles + 1)); HIPCHK(h, hipMemcpy(h->d_aoff, off, ((u64)n_alleles + 1) * 8, hipMemcpyHostToDevice));
-    h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4 + bloom.size() * 8; h->bytes_table = tcap * 12 + posts.size() * 4;
+    h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4 + bloom.size() * 8 + HI->rfilter.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
     h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
     {   // device-side typing: allele numbers, one slot of max_len columns per locus
         HIPCHK(h, dmalloc(&h->d_allele_no, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_no, allele_no, (u64)n_alleles * 4, hipMemcpyHostToDevice));
@@ -2438,6 +2819,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     // ---- sample state
     EngineDev& E = h->E;
     E.arena = h->d_arena; E.planes = h->d_planes; E.nmask = h->d_nmask; E.allele_len = h->d_allele_len; E.allele_locus = h->d_allele_locus; E.loci = h->d_loci;
+    h->bitmap_fill = HI->bitmap_fill;
     E.sieve = h->d_sieve; E.sieve_mask = smask; E.bitmap = h->d_bitmap; E.gbitmap = h->d_gbitmap; E.gbitmap_bits = gbitmap.empty() ? 0 : gbits; E.keys = h->d_keys; E.vals = h->d_vals; E.posts = h->d_posts; E.table_mask = tmask;
     E.floor_tab = h->d_floor; E.pen_tab = h->d_pen; E.n_alleles = n_alleles; E.n_loci = n_loci;
     E.cap_ret = h->prm.max_retained_reads; E.cap_items = h->prm.max_items; E.cap_res = h->prm.max_pair_results; E.cap_dp = h->prm.max_items * 4;
@@ -2531,6 +2913,31 @@ static int ensure_bin_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     return MLST_OK;
 }
 
+// arena / list buffers of the CU-routed sieve for a batch of n_reads (grow-only; must run outside stream capture)
+static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
+    const u64 n_tiles = (n_reads + 1023) >> 10;
+    u32 prod = wpr <= 10 ? 512u : 256u;                 // two workgroups per CU while the sort buffer allows it
+    { const char* e = getenv("MLST_ROUTE_BLOCKS"); if (e && atoi(e) > 0) prod = (u32)atoi(e); }
+    if (prod > n_tiles) prod = (u32)(n_tiles ? n_tiles : 1);
+    const u64 tiles_max = (n_tiles + prod - 1) / prod;
+    // expected entries per (owner, tile): 1024 * seeds / 256 + ~2 dummies; 25 % and a constant on top
+    u64 cap = (u64)((double)tiles_max * (4.0 * (wpr - 1) + 2.0) * 1.25) + 256; cap = (cap + 3) & ~3ull;
+    if (cap >= (1ull << 31)) return fail(h, MLST_E_LIMIT, "batch too large for the routed sieve");
+    const u64 need = (u64)RT_OWNERS * prod * cap;
+    if (h->cap_rt_arena < need || h->rt_prod != prod || h->rt_cap != (u32)cap) {
+        hipStreamSynchronize(h->stream);
+        if (h->cap_rt_arena < need) { hipFree(h->d_rt_arena); h->d_rt_arena = nullptr; HIPCHK(h, dmalloc(&h->d_rt_arena, need)); h->cap_rt_arena = need; }
+        hipFree(h->d_rt_counts); h->d_rt_counts = nullptr; HIPCHK(h, dmalloc(&h->d_rt_counts, (u64)RT_OWNERS * prod));
+        h->rt_prod = prod; h->rt_cap = (u32)cap;
+    }
+    const u64 need_e = (u64)prod * (tiles_max + 1);
+    if (h->cap_rt_emitted < need_e) { hipStreamSynchronize(h->stream); hipFree(h->d_rt_emitted); h->d_rt_emitted = nullptr; HIPCHK(h, dmalloc(&h->d_rt_emitted, need_e)); h->cap_rt_emitted = need_e; }
+    h->rt_tiles_max = (u32)tiles_max;
+    const u64 n_flag_words = (n_reads + 31) >> 5;
+    if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words; }
+    return MLST_OK;
+}
+
 extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packed, const uint8_t* d_qrows, const uint16_t* d_lens,
                                          uint64_t n_reads, uint32_t wpr, uint32_t qstride, int paired) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
@@ -2544,19 +2951,35 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     (void)paired;   // mates are typed independently; they share a QNAME only for the coverage figure
     if (h->cap_cand < n_reads) { hipStreamSynchronize(h->stream); hipFree(h->d_cand); h->d_cand = nullptr; HIPCHK(h, dmalloc(&h->d_cand, n_reads)); h->cap_cand = n_reads; }
     EngineDev& E = h->E;
-    if (!E.bitmap && h->binned) { int rc = ensure_bin_buffers(h, n_reads, wpr); if (rc) return rc; }
+    if (h->sieve_kind == MLST_SIEVE_BINNED) { int rc = ensure_bin_buffers(h, n_reads, wpr); if (rc) return rc; }
+    if (h->sieve_kind == MLST_SIEVE_ROUTED) { int rc = ensure_route_buffers(h, n_reads, wpr); if (rc) return rc; }
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
                                                (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand, (u64)(uintptr_t)h->d_bin_arena,
-                                               (u64)(uintptr_t)h->d_bin_flags, h->bin_cap});
+                                               (u64)(uintptr_t)h->d_bin_flags, h->bin_cap, (u64)(uintptr_t)h->d_rt_arena, (u64)(uintptr_t)h->d_rt_counts,
+                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod});
     if (gs == 1) { h->reads_seen += n_reads; return MLST_OK; }
     { Prof pf(h, 0);
-      if (E.bitmap) {      // LDS first level: one 1024-thread workgroup per CU
+      if (h->sieve_kind == MLST_SIEVE_LDS) {      // LDS first level: one 1024-thread workgroup per CU
         dim3 grid(grid_for((n_reads + 1023) / 1024, 1, 256)), block(1024);
 #define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, true>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.bitmap, 0u, h->d_cand, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
-      } else if (h->binned) {      // big database: seeds routed to the XCD that owns their key range (K1b)
+      } else if (h->sieve_kind == MLST_SIEVE_ROUTED) {      // seeds routed to the CU that owns their filter slice (K1c)
+        const u64 n_flag_words = (n_reads + 31) >> 5;
+        HIPCHK(h, hipMemsetAsync(h->d_bin_flags, 0, n_flag_words * 4, h->stream));
+        RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags;
+        R.cap = h->rt_cap; R.n_prod = h->rt_prod; R.tiles_max = h->rt_tiles_max;
+        { Prof pa(h, 9);
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_route<W>, dim3(h->rt_prod), dim3(1024), 0, h->stream, d_packed, d_lens, (u64)n_reads, R, E.ctr); break;
+        switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
+                       SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
+#undef SIEVE_CASE
+        }
+        { Prof pb(h, 10);
+          hipLaunchKernelGGL(k_route_probe, dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, d_lens, wpr, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); }
+        hipLaunchKernelGGL(k_flag_compact, dim3(grid_for(n_flag_words, 1024, 256)), dim3(1024), 0, h->stream, h->d_bin_flags, (u64)n_reads, h->d_cand, E.ctr);
+      } else if (h->sieve_kind == MLST_SIEVE_BINNED) {      // seeds routed to the XCD that owns their key range (K1b)
         const u32 blocks = h->bin_blocks, n_pw = blocks * 4; const u64 cap = h->bin_cap, n_flag_words = (n_reads + 31) >> 5;
         HIPCHK(h, hipMemsetAsync(h->d_bin_flags, 0, n_flag_words * 4, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_bin_next, 0, BIN_OWNERS * 4, h->stream));
@@ -3130,15 +3553,19 @@ extern "C" int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint
 
 extern "C" int mlst_set_profiling(mlst_handle* h, int on) { if (!h) return MLST_E_INVALID; drain_events(h); h->profiling = on == 1; h->window = on != 0; return MLST_OK; }
 extern "C" int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms, uint64_t* launches) {
-    if (!h || which < 0 || which >= 9) return MLST_E_INVALID;
+    if (!h || which < 0 || which >= 12) return MLST_E_INVALID;
     hipSetDevice(h->device); drain_events(h);
     if (total_ms) *total_ms = h->k_ms[which];
     if (launches) *launches = h->k_n[which];
     return MLST_OK;
 }
-extern "C" int mlst_reset_kernel_time(mlst_handle* h) { if (!h) return MLST_E_INVALID; drain_events(h); for (int i = 0; i < 9; i++) { h->k_ms[i] = 0; h->k_n[i] = 0; } return MLST_OK; }
+extern "C" int mlst_reset_kernel_time(mlst_handle* h) { if (!h) return MLST_E_INVALID; drain_events(h); for (int i = 0; i < 12; i++) { h->k_ms[i] = 0; h->k_n[i] = 0; } return MLST_OK; }
 extern "C" int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]) {
     if (!h || !out) return MLST_E_INVALID;
     out[0] = h->bytes_arena; out[1] = h->bytes_sieve; out[2] = h->bytes_table; out[3] = (u64)(h->bitmap_fill * 1e6); return MLST_OK;
+}
+extern "C" int mlst_get_sieve_info(mlst_handle* h, uint64_t out[4]) {
+    if (!h || !out || !h->have_ref) return fail(h, MLST_E_INVALID, "no reference loaded");
+    out[0] = (u64)h->sieve_kind; out[1] = h->n_keys; out[2] = h->sieve_chain; out[3] = (u64)h->E.sieve_mask + 1; return MLST_OK;
 }
 extern "C" int mlst_synchronize(mlst_handle* h) { if (!h) return MLST_E_INVALID; hipSetDevice(h->device); HIPCHK(h, hipStreamSynchronize(h->stream)); return MLST_OK; }

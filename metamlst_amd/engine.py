@@ -19,7 +19,9 @@ LIB_PATH = os.environ.get("MLST_LIB", os.path.join(_HERE, "libmlst_hip.so"))   #
 
 MLST_CNT_N = 8
 CNT_TOTAL_RECORDS, CNT_IGNORED, CNT_READS_SEEN, CNT_CANDIDATES, CNT_RETAINED, CNT_ITEMS, CNT_DP_PAIRS = range(7)
-KERNELS = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup", "pack", "sieve_inkernel", "sieve_wg_longest")
+KERNELS = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup", "pack", "sieve_inkernel", "sieve_wg_longest",
+           "sieve_route", "sieve_probe")
+SIEVE_KINDS = ("lds", "global", "binned", "routed")
 
 
 class MlstParams(C.Structure):
@@ -118,6 +120,7 @@ def load_library(path: str | None = None):
         "mlst_get_kernel_time": (C.c_int, [H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "mlst_reset_kernel_time": (C.c_int, [H]),
         "mlst_get_index_bytes": (C.c_int, [H, C.POINTER(C.c_uint64)]),
+        "mlst_get_sieve_info": (C.c_int, [H, C.POINTER(C.c_uint64)]),
         "mlst_synchronize": (C.c_int, [H]),
     }
     for name, (res, args) in sig.items():
@@ -404,6 +407,12 @@ class Engine:
         out = (C.c_uint64 * 4)()
         self._check(self.lib.mlst_get_index_bytes(self._h, out), "mlst_get_index_bytes")
         return [int(x) for x in out]
+
+    def sieve_info(self) -> dict:
+        """{kind, n_seeds, longest_chain, buckets} of the loaded database's seed sieve."""
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.mlst_get_sieve_info(self._h, out), "mlst_get_sieve_info")
+        return {"kind": SIEVE_KINDS[int(out[0])], "n_seeds": int(out[1]), "longest_chain": int(out[2]), "buckets": int(out[3])}
 
     def synchronize(self):
         self._check(self.lib.mlst_synchronize(self._h), "mlst_synchronize")

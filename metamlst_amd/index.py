@@ -54,42 +54,38 @@ class AlleleIndex:
 
 
 def similarity_order(seqs: list[bytes]) -> list[int]:
-    """Order the alleles of one locus so that neighbours are similar (greedy nearest-neighbour chain on
-    Hamming distance over 2-bit packed sequences).  The engine extends a read against the alleles of a
-    locus 64 at a time (one per lane); lanes with similar mismatch patterns diverge less.  Purely a
-    layout choice: every output is keyed by alleleVariant, not by position in the index."""
+    """Order the alleles of one locus so that neighbours are similar.  The engine extends a read against the alleles
+    of a locus 64 at a time (one per lane); lanes with similar mismatch patterns diverge less.  Purely a layout
+    choice: every output is keyed by alleleVariant, not by position in the index.
+
+    Sub-quadratic (real PubMLST loci hold > 10 k alleles): the alleles are compared with the column-wise majority
+    sequence, the variant columns are ranked by how many alleles differ there, and the alleles are sorted
+    lexicographically on their differences read in that rank order -- alleles that share the locus' common variants
+    (a clade) end up adjacent, then split by the next most common variant, and so on: O(n L) to build the keys and
+    one sort.  Ties (identical difference patterns cannot occur for distinct equal-length alleles; alleles of other
+    lengths differ in the tail) keep the input order."""
     n = len(seqs)
     if n <= 2:
         return list(range(n))
     L = max(len(s) for s in seqs)
-    W = (L + 31) // 32
-    code = np.zeros(256, np.uint64)
-    for k, c in enumerate(b"ACGT"):
-        code[c] = k
-        code[c + 32] = k
-    packed = np.zeros((n, W), np.uint64)
-    other = np.zeros((n, W), np.uint64)          # non-ACGT or past-the-end positions count as differences
+    mat = np.full((n, L), ord("-"), np.uint8)
     for i, s in enumerate(seqs):
-        a = np.frombuffer(s, np.uint8)
-        c = np.zeros(W * 32, np.uint64)
-        c[:len(a)] = code[a]
-        ok = np.zeros(W * 32, bool)
-        ok[:len(a)] = np.isin(a, np.frombuffer(b"ACGTacgt", np.uint8))
-        sh = (np.arange(W * 32, dtype=np.uint64) % np.uint64(32)) * np.uint64(2)
-        packed[i] = np.bitwise_or.reduce((c << sh).reshape(W, 32), axis=1)
-        other[i] = np.bitwise_or.reduce(((~ok).astype(np.uint64) << sh).reshape(W, 32), axis=1)
-    m55 = np.uint64(0x5555555555555555)
-    order, left = [0], np.ones(n, bool)
-    left[0] = False
-    cur = 0
-    for _ in range(n - 1):
-        x = packed ^ packed[cur]
-        d = np.bitwise_count(((x | (x >> np.uint64(1))) & m55) | other | other[cur]).sum(axis=1).astype(np.int64)
-        d[~left] = np.iinfo(np.int64).max
-        cur = int(d.argmin())
-        order.append(cur)
-        left[cur] = False
-    return order
+        mat[i, :len(s)] = np.frombuffer(s, np.uint8)
+    mat &= 0xDF                                    # upper case ('-' becomes 0x0D: still a distinct symbol)
+    # majority symbol per column among the five that matter; everything else counts as a difference
+    cnt = np.stack([(mat == c).sum(axis=0) for c in b"ACGT"])
+    major = np.frombuffer(b"ACGT", np.uint8)[cnt.argmax(axis=0)]
+    diff = mat != major[None, :]
+    freq = diff.sum(axis=0)
+    cols = np.argsort(-freq, kind="stable")
+    cols = cols[freq[cols] > 0]
+    if len(cols) == 0:
+        return list(range(n))
+    # key = the differing symbol (0 where the allele has the majority base) per ranked column: not just "differs",
+    # so that the alleles of a multi-allelic site split by base
+    key = np.where(diff[:, cols], mat[:, cols], 0).astype(np.uint8)
+    rows = np.ascontiguousarray(key).view(np.dtype((np.void, key.shape[1]))).ravel()
+    return [int(i) for i in np.argsort(rows, kind="stable")]
 
 
 def load_index(db_path: str, species_filter: list[str] | None = None, cluster: bool = True) -> AlleleIndex:

@@ -225,3 +225,144 @@ def ragged_reads(reads: list[bytes], quals: list[bytes]) -> tuple[np.ndarray, np
     b = np.frombuffer(b"".join(reads), dtype=np.uint8).copy() if reads else np.zeros(0, np.uint8)
     q = np.frombuffer(b"".join(quals), dtype=np.uint8).copy() if quals else np.zeros(0, np.uint8)
     return b, q, off
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Resident batches made on the GPU (bench.py, the BASELINE-sized GPU tests).  torch is imported by the callers: this
+# module stays importable without it.
+
+def synth_reads_gpu(eng, torch, device, genome: np.ndarray, n_reads: int, L: int, seed: int, chunk: int = 1 << 19):
+    """Reads of SURVEY.md 8(d) made on the GPU: uniform starts over `genome`, both strands, Phred 40 except 0.1 %
+    substitution errors at Phred 15; packed with the engine's own pack kernel (mlst_pack_reads_device).
+    Returns (packed int32 tensor in the resident group-transposed layout, qrows uint8, lens int16, wpr, qstride)."""
+    wpr = (L + 15) // 16
+    wpr += wpr & 1
+    qstride = (L + 7) & ~7
+    g = torch.from_numpy(genome).to(device)
+    comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    code = torch.zeros(256, dtype=torch.int64, device=device)
+    for k, a in enumerate(b"ACGT"):
+        code[a] = k
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    packed = torch.zeros((n_reads + 63) // 64 * 64 * wpr + 4, dtype=torch.int32, device=device)   # whole groups of 64 rows (mlst.h)
+    qrows = torch.zeros(n_reads * qstride, dtype=torch.uint8, device=device)
+    lens = torch.zeros(n_reads + 2, dtype=torch.int16, device=device)
+    ar = torch.arange(L, device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    for c0 in range(0, n_reads, chunk):
+        n = min(chunk, n_reads - c0)
+        start = torch.randint(0, len(genome) - L + 1, (n,), generator=gen, device=device)
+        b = g[start[:, None] + ar[None, :]]
+        rev = torch.rand(n, generator=gen, device=device) < 0.5
+        b = torch.where(rev[:, None], comp[b.flip(1).long()], b)
+        err = torch.rand((n, L), generator=gen, device=device) < 0.001
+        sub = acgt[(code[b.long()] + torch.randint(1, 4, (n, L), generator=gen, device=device)) % 4]
+        b = torch.where(err, sub, b).contiguous()
+        q = torch.where(err, torch.tensor(15 + 33, dtype=torch.uint8, device=device),
+                        torch.tensor(40 + 33, dtype=torch.uint8, device=device)).contiguous()
+        off = (torch.arange(n + 1, device=device, dtype=torch.int64) * L).contiguous()
+        torch.cuda.synchronize(device)
+        eng.pack_reads_device(b.data_ptr(), q.data_ptr(), off.data_ptr(), n, packed.data_ptr() + c0 * wpr * 4,
+                              qrows.data_ptr() + c0 * qstride, lens.data_ptr() + c0 * 2, wpr, qstride)
+        eng.synchronize()
+        del b, q, err, sub, start, rev, off
+    return packed, qrows, lens, wpr, qstride
+
+
+def tiled_to_rows(packed, n_reads: int, wpr: int):
+    """Resident 2-bit rows (groups of 64 reads, transposed in 8-byte units, include/mlst.h) -> plain [n_reads, wpr] rows."""
+    g = (n_reads + 63) // 64
+    return packed[:g * 64 * wpr].view(g, wpr // 2, 64, 2).permute(0, 2, 1, 3).reshape(g * 64, wpr)[:n_reads]
+
+
+def rows_to_tiled(rows, torch):
+    """Plain [n, wpr] rows -> the resident group-transposed layout (+4 words of slack)."""
+    n, wpr = rows.shape
+    g = (n + 63) // 64
+    pad = torch.zeros((g * 64, wpr), dtype=rows.dtype, device=rows.device)
+    pad[:n] = rows
+    t = pad.view(g, 64, wpr // 2, 2).permute(0, 2, 1, 3).contiguous().view(-1)
+    return torch.cat([t, torch.zeros(4, dtype=rows.dtype, device=rows.device)])
+
+
+def metagenome_plan(sdb: SynthDB, n_genomes: int, seed: int = 5):
+    """cfg3 of SURVEY.md 8(d): which species are in the mixture, their log-normal abundances and the ST planted in
+    each.  -> [(species, abundance fraction, st_row)]; the same for every batch and rank (pure function of the seed)."""
+    rng = np.random.default_rng(seed)
+    chosen = list(rng.choice(len(sdb.species), size=min(n_genomes, len(sdb.species)), replace=False))
+    ab = rng.lognormal(0.0, 1.0, size=len(chosen))
+    ab /= ab.sum()
+    return [(sdb.species[int(si)], float(fr), k % len(sdb.profiles[sdb.species[int(si)]])) for k, (si, fr) in enumerate(zip(chosen, ab))]
+
+
+def make_metagenome_gpu(eng, torch, device, sdb: SynthDB, plan, n_reads: int, genome_size: int, seed: int, read_len: int = 150,
+                        genomes: dict | None = None):
+    """One resident batch of the mixed metagenome: every genome of `plan` contributes its share of n_reads, the reads
+    are shuffled.  `genomes` caches the isolate genomes between batches.  -> (packed, qrows, lens, wpr, qstride, n_total)."""
+    rows_all, q_all, l_all = [], [], []
+    wpr = qstride = None
+    for k, (sp, frac, st_row) in enumerate(plan):
+        if genomes is not None and sp in genomes:
+            g = genomes[sp]
+        else:
+            g, _ = make_genome(sdb, sp, sdb.profiles[sp][st_row], size=genome_size, seed=1000 + k)
+            if genomes is not None:
+                genomes[sp] = g
+        n = max(1000, int(n_reads * frac))
+        p, q, l, wpr, qstride = synth_reads_gpu(eng, torch, device, g, n, read_len, seed=seed * 1000 + k)
+        rows_all.append(tiled_to_rows(p, n, wpr).clone())
+        q_all.append(q[:n * qstride])
+        l_all.append(l[:n])
+        del p
+    n_total = sum(int(x.shape[0]) for x in l_all)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    perm = torch.randperm(n_total, device=device, generator=gen)
+    packed = rows_to_tiled(torch.cat(rows_all)[perm].contiguous(), torch)
+    del rows_all
+    qrows = torch.cat(q_all).view(n_total, qstride)[perm].contiguous().view(-1)
+    del q_all
+    lens = torch.cat([torch.cat(l_all)[perm], torch.zeros(2, dtype=torch.int16, device=device)])
+    return packed, qrows, lens, wpr, qstride, n_total
+
+
+def resident_to_host_reads(packed, qrows, n_reads: int, wpr: int, qstride: int, first: int, count: int, read_len: int = 150):
+    """A slice of a resident batch back as ASCII (bases[count, L], quals Phred+33 [count, L]) numpy arrays on the host
+    (for the CPU oracle: the parity checks of bench.py and the tests run it on the very reads the engine saw)."""
+    pk = tiled_to_rows(packed, n_reads, wpr)[first:first + count].cpu().numpy().view(np.uint32).reshape(count, wpr)
+    qr = qrows[first * qstride:(first + count) * qstride].cpu().numpy().reshape(count, qstride)
+    codes = np.zeros((count, wpr * 16), np.uint8)
+    for k in range(16):
+        codes[:, k::16] = (pk >> np.uint32(2 * k)) & np.uint32(3)
+    bases = _ACGT[codes[:, :read_len]]
+    bases[(qr[:, :read_len] & 0x80) != 0] = ord("N")
+    quals = ((qr[:, :read_len] & 0x7F) + 33).astype(np.uint8)
+    return bases, quals
+
+
+def resident_to_fastq_text(torch, packed, qrows, n_reads: int, wpr: int, qstride: int, first: int, count: int, read_len: int = 150):
+    """A slice of a resident batch as FASTQ text (flat uint8 tensor on the GPU): 4-line records named '@r' + nine digits.
+    Record = 12 + L + 3 + L + 1 bytes: '@r#########' LF, L bases LF, '+' LF, L qualities LF."""
+    dev, L = packed.device, read_len
+    pk = tiled_to_rows(packed, n_reads, wpr)[first:first + count]
+    sh = (torch.arange(16, device=dev, dtype=torch.int32) * 2)[None, None, :]
+    codes = ((pk[:, :, None] >> sh) & 3).reshape(count, wpr * 16)[:, :L].long()
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    qr = qrows[first * qstride:(first + count) * qstride].view(count, qstride)[:, :L]
+    rec = torch.empty((count, 16 + 2 * L), dtype=torch.uint8, device=dev)
+    rec[:, 0] = ord("@")
+    rec[:, 1] = ord("r")
+    ids = torch.arange(first, first + count, device=dev, dtype=torch.int64)
+    for d in range(9):
+        rec[:, 2 + d] = ((ids // (10 ** (8 - d))) % 10 + 48).to(torch.uint8)
+    rec[:, 11] = 10
+    rec[:, 12:12 + L] = torch.where((qr & 0x80) != 0, torch.tensor(ord("N"), dtype=torch.uint8, device=dev), acgt[codes])
+    rec[:, 12 + L] = 10
+    rec[:, 13 + L] = ord("+")
+    rec[:, 14 + L] = 10
+    rec[:, 15 + L:15 + 2 * L] = (qr & 0x7F) + 33
+    rec[:, 15 + 2 * L] = 10
+    return rec.view(-1)

@@ -115,19 +115,43 @@ orc_ref* orc_ref_build(const uint8_t* ascii_concat, const uint64_t* off, const u
         else if (r->locus_begin[l] + r->locus_count[l] != a) { orc_ref_free(r); return NULL; } /* not contiguous */
         r->locus_count[l]++;
     }
-    kp_t* kp = (kp_t*)malloc((n_pairs_max + 1) * sizeof(kp_t)); uint64_t np = 0;
-    uint8_t rc[K];
-    for (uint32_t a = 0; a < n_alleles; a++) {
-        uint32_t L = r->len[a]; if (L < K) continue;
-        for (uint32_t p = 0; p + K <= L; p++) {
-            uint64_t key;
-            if (!kmer_key(r->code[a] + p, &key)) continue;
-            kp[np].key = key; kp[np].post = (r->locus_of[a] << 13) | (0u << 12) | p; np++;
-            for (int t = 0; t < K; t++) rc[t] = 3 - r->code[a][p + K - 1 - t];
-            kmer_key(rc, &key);
-            kp[np].key = key; kp[np].post = (r->locus_of[a] << 13) | (1u << 12) | p; np++;
+    /* A posting is (locus, strand, position): the alleles of a locus repeat most of them (they differ by a few SNPs),
+     * and the index keeps each distinct (key, posting) pair once.  So the pairs are made unique locus by locus
+     * (a posting names its locus: pairs of different loci never coincide) -- loci in parallel, each a small sort --
+     * before the one sort of the whole index.  A many-species database has 25 x fewer distinct pairs than pairs. */
+    (void)n_pairs_max;
+    kp_t** lkp = (kp_t**)calloc(n_loci ? n_loci : 1, sizeof(kp_t*));
+    uint64_t* lnp = (uint64_t*)calloc(n_loci ? n_loci : 1, sizeof(uint64_t));
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t l = 0; l < (int64_t)n_loci; l++) {
+        uint64_t cap = 0;
+        for (uint32_t a = r->locus_begin[l]; a < r->locus_begin[l] + r->locus_count[l]; a++) if (r->len[a] >= K) cap += 2ull * (r->len[a] - K + 1);
+        kp_t* v = (kp_t*)malloc((cap + 1) * sizeof(kp_t)); uint64_t n = 0;
+        uint8_t rc[K];
+        for (uint32_t a = r->locus_begin[l]; a < r->locus_begin[l] + r->locus_count[l]; a++) {
+            uint32_t L = r->len[a]; if (L < K) continue;
+            for (uint32_t p = 0; p + K <= L; p++) {
+                uint64_t key;
+                if (!kmer_key(r->code[a] + p, &key)) continue;
+                v[n].key = key; v[n].post = ((uint32_t)l << 13) | (0u << 12) | p; n++;
+                for (int t = 0; t < K; t++) rc[t] = 3 - r->code[a][p + K - 1 - t];
+                kmer_key(rc, &key);
+                v[n].key = key; v[n].post = ((uint32_t)l << 13) | (1u << 12) | p; n++;
+            }
+            if (n > (1u << 16) || a + 1 == r->locus_begin[l] + r->locus_count[l]) {   /* keep the working set small: unique as we go */
+                qsort(v, n, sizeof(kp_t), kp_cmp);
+                uint64_t u = 0;
+                for (uint64_t i = 0; i < n; i++) if (i == 0 || kp_cmp(&v[i], &v[i - 1]) != 0) v[u++] = v[i];
+                n = u;
+            }
         }
+        lkp[l] = v; lnp[l] = n;
     }
+    uint64_t np = 0;
+    for (uint32_t l = 0; l < n_loci; l++) np += lnp[l];
+    kp_t* kp = (kp_t*)malloc((np + 1) * sizeof(kp_t)); np = 0;
+    for (uint32_t l = 0; l < n_loci; l++) { memcpy(kp + np, lkp[l], lnp[l] * sizeof(kp_t)); np += lnp[l]; free(lkp[l]); }
+    free(lkp); free(lnp);
     qsort(kp, np, sizeof(kp_t), kp_cmp);
     /* unique pairs, group by key, drop repetitive keys */
     uint64_t nu = 0;

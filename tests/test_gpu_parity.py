@@ -222,18 +222,19 @@ def test_sharded_engines_reduce_to_the_single_engine_result():
     assert letters == b"".join(whole.consensus(chosen)[a] for a in chosen)
 
 
-@pytest.mark.parametrize("binned", ["0", "1"])
-def test_big_database_sieves_on_a_small_database(monkeypatch, binned):
-    """Large databases skip the LDS first-level bitmap; force those paths on a small one: the single-kernel sieve with
-    the global bitmap (MLST_BINNED=0) and the XCD-binned sieve (k_bin -> k_bin_probe -> k_flag_compact, MLST_BINNED=1),
-    the latter also with Bloom filters so small that nearly every seed goes the exact way."""
-    monkeypatch.setenv("MLST_NO_LDS_SIEVE", "1")
-    monkeypatch.setenv("MLST_BINNED", binned)
+@pytest.mark.parametrize("kind", ["global", "binned", "routed"])
+def test_big_database_sieves_on_a_small_database(monkeypatch, kind):
+    """Large databases skip the LDS first-level bitmap; force those paths on a small one (MLST_SIEVE): the single-kernel
+    sieve with the global bitmap, the XCD-binned sieve (k_bin -> k_bin_probe -> k_flag_compact; also with Bloom filters so
+    small that nearly every seed goes the exact way) and the CU-routed sieve (k_route -> k_route_probe -> k_flag_compact:
+    the one databases beyond the LDS bitmaps get by default)."""
+    monkeypatch.setenv("MLST_SIEVE", kind)
     db, idx = fx.ecoli_small(80)
     fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 8, n_reads=9000)
-    for bloom_bits in (("18", "10") if binned == "1" else ("18",)):
+    for bloom_bits in (("18", "10") if kind == "binned" else ("18",)):
         monkeypatch.setenv("MLST_BLOOM_BITS", bloom_bits)
         eng, orc = both(idx)
+        assert eng.sieve_info()["kind"] == kind
         s, _ = run_both(eng, orc, fb, fq, off)
         check_pileup(eng, orc, idx, s)
         # ragged lengths (fewer seeds than slots, reads shorter than a seed) and N bases through the same path
@@ -362,7 +363,7 @@ def test_plain_sieve_with_global_bitmap_and_without(monkeypatch):
     (forced small so that it is selective) and with it disabled."""
     db, idx = fx.ecoli_small(80)
     fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 8, n_reads=9000)
-    monkeypatch.setenv("MLST_NO_LDS_SIEVE", "1")
+    monkeypatch.setenv("MLST_SIEVE", "global")
     for bits in ("18", "25", "0"):
         monkeypatch.setenv("MLST_GBM_BITS", bits)
         eng, orc = both(idx)
@@ -488,14 +489,12 @@ def test_dense_on_locus_reads_overflow_the_sieve_queue():
             r = r[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
         reads.append(r); quals.append(bytes([40 + 33]) * L)
     fb, fq, off = synth.ragged_reads(reads, quals)
-    for env, binned in (("0", "0"), ("1", "0"), ("1", "1")):
-        os.environ["MLST_NO_LDS_SIEVE"] = env
-        os.environ["MLST_BINNED"] = binned
+    for kind in ("lds", "global", "binned", "routed"):
+        os.environ["MLST_SIEVE"] = kind
         try:
             eng, orc = both(idx)
             s, so = run_both(eng, orc, fb, fq, off)
             assert int(s.counters[4]) == 6000          # every read retained
             check_pileup(eng, orc, idx, s)
         finally:
-            os.environ.pop("MLST_NO_LDS_SIEVE", None)
-            os.environ.pop("MLST_BINNED", None)
+            os.environ.pop("MLST_SIEVE", None)
