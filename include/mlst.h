@@ -274,8 +274,7 @@ int mlst_reset_kernel_time(mlst_handle* h);
  * [3]=fill of the LDS first-level bitmap in parts per million (0 when the plain sieve kernel is in use) */
 int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]);
 /* The seed sieve chosen for the loaded database: [0] = kind (0 = half-seed bitmaps in LDS, 1 = hashed bitmap in global
- * memory, 2 = XCD-binned Bloom filters, 3 = CU-routed filter slices in LDS; chosen by database size, MLST_SIEVE=lds /
- * global / binned / routed forces one), [1] = distinct canonical seeds, [2] = longest overflow walk of a key in the
+ * memory, 3 = CU-routed filter slices in LDS; chosen by database size, MLST_SIEVE=lds / global / routed forces one), [1] = distinct canonical seeds, [2] = longest overflow walk of a key in the
  * fingerprint sieve (the kernels follow a chain for 64 buckets; the build keeps it <= 32), [3] = sieve buckets. */
 int mlst_get_sieve_info(mlst_handle* h, uint64_t out[4]);
 /* Block until all work queued on the engine's stream is done. */

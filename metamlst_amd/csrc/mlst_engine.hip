@@ -487,6 +487,13 @@ __global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __res
     if (tid == 0) { const u64 t1 = (u64)wall_clock64(); atomicMax(&ctr->sv_t1, t1); atomicMax(&ctr->sv_wgmax, t1 - wg_t0); }
 }
 
+// ---- DPP lane moves (gfx9 encodings).  update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): a lane whose
+// source is out of range, or whose row is masked off, keeps `old`.
+#define DPP_ROW_SHR(n)  (0x110 + (n))
+#define DPP_WAVE_SHL1   0x130      /* lane i <- lane i+1 */
+#define DPP_WAVE_SHR1   0x138      /* lane i <- lane i-1 */
+#define DPP_ROW_BCAST15 0x142      /* lane 15 of each 16-lane row -> every lane of the next row */
+#define DPP_ROW_BCAST31 0x143      /* lane 31 -> every lane of rows 2 and 3 */
 // ------------------------------------------------------------------ wave helpers
 __device__ inline u32 wave_excl_scan_u32(u32 v, u32& total) {      // exclusive prefix sum over the 64 lanes
     int lane = threadIdx.x & 63; u32 x = v;
@@ -498,41 +505,6 @@ __device__ inline u32 wave_excl_scan_u32(u32 v, u32& total) {      // exclusive 
 __device__ inline u64 wave_sum_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
 __device__ inline u64 wave_min_u64(u64 v) { for (int o = 32; o > 0; o >>= 1) { u64 w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
 __device__ inline u32 wave_sum_u32(u32 v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-// ------------------------------------------------------------------ K1b: XCD-binned sieve for big databases
-// With millions of seeds no first-level filter fits LDS, and a filter that all 8 XCDs probe is served at ~80 G random
-// requests/s (16 MiB table; profiles/microbench/xcd_probe.hip) -- while probes that stay inside ONE XCD's 4 MiB L2 run at
-// ~270 G/s.  So the seeds are routed to the XCD that owns their key range:
-//   k_bin        streams the reads once; per seed the canonical key, a 39-bit hash of it (3 bits = owner, 36 bits =
-//                Bloom address), and an 8-byte entry appended to the owner's queue (LDS ring per wave and owner, flushed
-//                in coalesced 512-byte pieces into the wave's own region of the owner's arena -- no global atomics; a
-//                read whose seeds crowd one ring, or whose region is full, simply becomes a candidate);
-//   k_bin_probe  workgroups read which XCD they run on (HW_REG_XCC_ID) and drain that owner's arena: one 8-byte probe
-//                per entry into the owner's blocked Bloom filter (2 MiB per owner, L2 resident); the ~1 % that pass
-//                go the exact way: seed re-read from the read's row, canonical key, fingerprint sieve, candidate flag;
-//                a workgroup whose arena is drained helps the others (completeness never depends on the placement);
-//   k_flag_compact  candidate flags -> candidate list.
-#define BIN_OWNERS 8
-#define BIN_RING 128                 // entries per (wave, owner) LDS ring (flushed twice per tile)
-__host__ __device__ inline void bin_hash(u32 lo, u32 hi, u32& owner, u64& h36) {
-    u32 a = table_hash(lo, hi);                                         // also the exact table's hash: well mixed
-    u32 b = (lo ^ (hi * 0x9E3779B1u)) * 0x85EBCA6Bu; b ^= b >> 13;
-    owner = a >> 29;
-    h36 = ((u64)(a & 0x1FFFFFFFu) << 7) | (u64)(b >> 25);              // 29 + 7 bits
-}
-// Bloom address of a 36-bit hash inside an owner's filter of 2^blk_bits 8-byte blocks: block index + three bit positions
-__host__ __device__ inline void bin_bloom_addr(u64 h36, u32 blk_bits, u32& block, u64& mask) {
-    block = (u32)(h36 >> 7) & ((1u << blk_bits) - 1u);
-    u32 m = (u32)h36 * 0xC2B2AE35u; m ^= m >> 15; m *= 0x27D4EB2Fu; m ^= m >> 13;
-    mask = (1ull << (m & 63)) | (1ull << ((m >> 6) & 63)) | (1ull << ((m >> 12) & 63));
-}
-struct BinDev {                      // device-resident description of one binned submission
-    GP<u64> arena;                   // [owner][producer wave][cap] entries
-    GP<u32> counts;                  // [producer wave][owner] entries written
-    GP<u32> next;                    // [owner] work-queue cursor of k_bin_probe (zeroed per submission)
-    GP<const u64> bloom;             // [owner][1 << blk_bits] blocks
-    GP<u32> flags;                   // candidate flag per read (zeroed per submission)
-    u64 cap; u32 n_pw, blk_bits;
-};
 // exact check of one seed: canonical key -> fingerprint sieve; true = candidate
 __device__ inline bool bin_exact(u32 w0, u32 w1, const uint4* __restrict__ sieve, u32 smask, u32 sshift) {
     u32 fl; const u64 c = canon40((u64)w0 | ((u64)(w1 & 0xFFu) << 32), fl);
@@ -546,215 +518,20 @@ __device__ inline bool bin_exact(u32 w0, u32 w1, const uint4* __restrict__ sieve
     }
     return false;
 }
-template <int WPR>
-__global__ __launch_bounds__(256) void k_bin(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
-                                             const BinDev B, Counters* __restrict__ ctr) {
-    __shared__ u64 s_ring[4][BIN_OWNERS][BIN_RING];            // 32 KiB
-    __shared__ u32 s_tail[4][BIN_OWNERS], s_head[4][BIN_OWNERS];
-    constexpr int NT = WPR - 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());
-    if (lane < BIN_OWNERS) { s_tail[wave][lane] = 0; s_head[wave][lane] = 0; }
-    const u32 pw = blockIdx.x * 4 + wave;                       // producer wave
-    const u64 n_groups = (n_reads + 63) >> 6;
-    u32 head[BIN_OWNERS], written[BIN_OWNERS];                  // wave-uniform
-    #pragma unroll
-    for (int o = 0; o < BIN_OWNERS; o++) { head[o] = 0; written[o] = 0; }
-    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-    // Whole 64-entry pieces of every owner's ring go out after seeds 0..4 and after the last seed.  Two things that
-    // random-looking keys never do are answered conservatively, by making the read a candidate outright (k_seed looks
-    // every candidate up exactly, so a superfluous one costs time, never correctness): a tile whose seeds crowd one key
-    // range (poly-A reads) overflows the ring, and a batch that does so throughout fills the owner's region.
-    auto flush = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        #pragma unroll
-        for (int o = 0; o < BIN_OWNERS; o++) {
-            u32 tl = (u32)__builtin_amdgcn_readfirstlane((int)s_tail[wave][o]);
-            if (tl - head[o] > BIN_RING) { tl = head[o] + BIN_RING; if (lane == 0) s_tail[wave][o] = tl; }
-            bool moved = false;
-            while (tl - head[o] >= 64) {
-                const u64 e = s_ring[wave][o][(head[o] + lane) & (BIN_RING - 1)];
-                if (written[o] + 64 <= B.cap) { B.arena[((u64)o * B.n_pw + pw) * B.cap + written[o] + lane] = e; written[o] += 64; }
-                else {
-                    const u64 rr = ((u64)pw + (u64)((u32)(e >> 6) & 0x3FFFFu) * B.n_pw) * 64 + ((u32)e & 63u);
-                    atomicOr(&B.flags[rr >> 5], 1u << (rr & 31));
-                }
-                head[o] += 64; moved = true;
-            }
-            if (moved && lane == 0) s_head[wave][o] = head[o];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    };
-    u32 k = 0;
-    v2u xn[WPR / 2]; u16 len_raw = 0;                          // rows of the NEXT group are requested a group ahead
-    {
-        const u64 g0 = pw < n_groups ? pw : 0, r0 = g0 * 64 + lane;
-        const v2u* row = reinterpret_cast<const v2u*>(packed) + g0 * (32 * WPR) + lane;
-        #pragma unroll
-        for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
-        len_raw = lens[r0 < n_reads ? r0 : 0];
-    }
-    for (u64 g = pw; g < n_groups; g += B.n_pw, k++) {
-        const u64 r = g * 64 + lane;
-        const bool live = r < n_reads;
-        u32 w[WPR]; u32 len_cur;
-        #pragma unroll
-        for (int t2 = 0; t2 < WPR / 2; t2++) {
-            asm volatile("v_mov_b32 %0, %1" : "=v"(w[2 * t2]) : "v"(xn[t2].x));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(w[2 * t2 + 1]) : "v"(xn[t2].y));
-        }
-        asm volatile("v_mov_b32 %0, %1" : "=v"(len_cur) : "v"((u32)len_raw));
-        {
-            const u64 gn = g + B.n_pw < n_groups ? g + B.n_pw : g, rn = gn * 64 + lane;
-            const v2u* row = reinterpret_cast<const v2u*>(packed) + gn * (32 * WPR) + lane;
-            #pragma unroll
-            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
-            len_raw = lens[rn < n_reads ? rn : 0];
-            asm volatile("" ::: "memory");
-        }
-        const u32 n = live ? (len_cur & 0x7FFFu) : 0u;
-        const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-        bool crowded = false;
-        #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            if (t < nseeds) {
-                u32 fl; const u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl);
-                u32 owner; u64 h36; bin_hash((u32)c, (u32)(c >> 32), owner, h36);
-                const u32 pos = atomicAdd(&s_tail[wave][owner], 1u);            // LDS atomic: slot in the owner's ring
-                if (pos - s_head[wave][owner] < BIN_RING)
-                    s_ring[wave][owner][pos & (BIN_RING - 1)] = (h36 << 28) | ((u64)t << 24) | ((u64)(k & 0x3FFFFu) << 6) | (u64)lane;
-                else crowded = true;
-            }
-            if (t == 4 || t == NT - 1) flush();
-        }
-        if (crowded) atomicOr(&B.flags[r >> 5], 1u << (r & 31));
-    }
-    // the remainders (< 64 per owner), then the counts
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    #pragma unroll
-    for (int o = 0; o < BIN_OWNERS; o++) {
-        u32 tl = (u32)__builtin_amdgcn_readfirstlane((int)s_tail[wave][o]);
-        if (tl - head[o] > BIN_RING) tl = head[o] + BIN_RING;
-        const u32 rem = tl - head[o];
-        if ((u32)lane < rem) {
-            const u64 e = s_ring[wave][o][(head[o] + lane) & (BIN_RING - 1)];
-            if (written[o] + rem <= B.cap) B.arena[((u64)o * B.n_pw + pw) * B.cap + written[o] + lane] = e;
-            else {
-                const u64 rr = ((u64)pw + (u64)((u32)(e >> 6) & 0x3FFFFu) * B.n_pw) * 64 + ((u32)e & 63u);
-                atomicOr(&B.flags[rr >> 5], 1u << (rr & 31));
-            }
-        }
-        if (written[o] + rem <= B.cap) written[o] += rem;
-        if (lane == 0) B.counts[(u64)pw * BIN_OWNERS + o] = written[o];
-    }
-}
-
-__device__ inline u32 hw_xcc_id() { u32 v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xFu; }
-
-__global__ __launch_bounds__(256) void k_bin_probe(const u32* __restrict__ packed, u32 wpr, u64 n_reads, const uint4* __restrict__ sieve,
-                                                   u32 smask, const BinDev B, Counters* __restrict__ ctr) {
-    // Entries that pass the Bloom filter (a few per thousand) are not examined where they are found -- one lane going the
-    // exact way (two random row reads and a sieve probe) would hold its whole wave for microseconds -- but parked in an
-    // LDS queue and examined 256 at a time, every lane busy.
-    constexpr u32 QCAP = 2048; constexpr int EPT = 4;      // entries per thread and iteration (independent loads in flight)
-    __shared__ u32 s_region, s_qn;
-    __shared__ u64 s_q[QCAP];                                   // read index | seed slot << 40
-    const int tid = threadIdx.x;
-    const u32 sshift = (u32)__clz((int)smask);
-    const u32 home = hw_xcc_id() % BIN_OWNERS;
-    const u64 nblk = 1ull << B.blk_bits;
-    if (tid == 0) s_qn = 0;
-    __syncthreads();
-    auto drain = [&](bool all) {                                // block-uniform call sites
-        for (;;) {
-            __syncthreads();
-            const u32 qn = s_qn;
-            if (qn == 0 || (!all && qn < 256)) break;
-            const u32 take = qn < 256 ? qn : 256;
-            u64 q = 0;
-            if ((u32)tid < take) q = s_q[qn - take + tid];
-            __syncthreads();
-            if (tid == 0) s_qn = qn - take;
-            if ((u32)tid < take) {
-                const u64 rr = q & 0xFFFFFFFFFFull; const u32 tt = (u32)(q >> 40);
-                if (bin_exact(packed[packed_index(rr, wpr, tt)], packed[packed_index(rr, wpr, tt + 1)], sieve, smask, sshift))
-                    atomicOr(&B.flags[rr >> 5], 1u << (rr & 31));
-            }
-        }
-        __syncthreads();
-    };
-    for (u32 turn = 0; turn < BIN_OWNERS; turn++) {            // own arena first, then help the others
-        const u32 o = (home + turn) % BIN_OWNERS;
-        const auto bloom = B.bloom.g() + (u64)o * nblk;
-        for (;;) {
-            if (tid == 0) s_region = atomicAdd(&B.next[o], 1u);
-            __syncthreads();
-            const u32 reg = s_region;
-            __syncthreads();
-            if (reg >= B.n_pw) break;
-            const u32 cnt = B.counts[(u64)reg * BIN_OWNERS + o];
-            const auto ent = B.arena.g() + ((u64)o * B.n_pw + reg) * B.cap;
-            // the entries of the next iteration are requested before this iteration's Bloom probes: the stream from
-            // HBM and the probes into L2 overlap instead of alternating
-            u64 en[EPT];
-            #pragma unroll
-            for (int j = 0; j < EPT; j++) { const u32 i = j * 256 + tid; en[j] = i < cnt ? __builtin_nontemporal_load(&ent[i]) : 0ull; }
-            for (u32 i0 = 0; i0 < cnt; i0 += 256 * EPT) {
-                u64 e[EPT]; u64 blk[EPT]; u64 msk[EPT];
-                #pragma unroll
-                for (int j = 0; j < EPT; j++) {       // register copies free en[] for the loads below (see k_sieve_q)
-                    u32 lo = (u32)en[j], hi = (u32)(en[j] >> 32), lo2, hi2;
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(lo2) : "v"(lo));
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(hi2) : "v"(hi));
-                    e[j] = (u64)lo2 | ((u64)hi2 << 32);
-                }
-                #pragma unroll
-                for (int j = 0; j < EPT; j++) { u32 bi; bin_bloom_addr(e[j] >> 28, B.blk_bits, bi, msk[j]); blk[j] = bloom[bi]; }
-                {
-                    const u32 i1 = i0 + 256 * EPT;
-                    #pragma unroll
-                    for (int j = 0; j < EPT; j++) { const u32 i = i1 + j * 256 + tid; en[j] = i < cnt ? __builtin_nontemporal_load(&ent[i]) : 0ull; }
-                    asm volatile("" ::: "memory");
-                }
-                #pragma unroll
-                for (int j = 0; j < EPT; j++) {
-                    const u32 i = i0 + j * 256 + tid;
-                    if (i < cnt && (blk[j] & msk[j]) == msk[j]) {          // Bloom pass: park it
-                        const u32 tt = (u32)(e[j] >> 24) & 15u, ll = (u32)e[j] & 63u, kk = (u32)(e[j] >> 6) & 0x3FFFFu;
-                        const u64 rr = ((u64)reg + (u64)kk * B.n_pw) * 64 + ll;
-                        if (rr < n_reads) {
-                            const u32 at = atomicAdd(&s_qn, 1u);
-                            if (at < QCAP) s_q[at] = rr | ((u64)tt << 40);
-                            else {      // queue full (a filter that passes nearly everything): on the spot
-                                atomicSub(&s_qn, 1u);
-                                if (bin_exact(packed[packed_index(rr, wpr, tt)], packed[packed_index(rr, wpr, tt + 1)], sieve, smask, sshift))
-                                    atomicOr(&B.flags[rr >> 5], 1u << (rr & 31));
-                            }
-                        }
-                    }
-                }
-                drain(false);                                   // at most 256 * EPT entries were parked since the last look: QCAP holds them
-            }
-        }
-    }
-    drain(true);
-    if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
-}
-
 // ------------------------------------------------------------------ K1c: CU-routed sieve (databases beyond the LDS half-seed bitmaps)
 // A filter for millions of seeds needs ~16 MiB.  The only on-chip memories of that aggregate size are the eight L2s
-// (4 MiB each, ~270 G random requests/s in all -- what k_bin_probe is bound by: 450 M seeds of a 50 M-read batch are 1.7 ms
-// of L2 requests alone) and the 256 LDS (128 KiB usable each, 32 lanes per clock per CU: ~60 x the L2 request rate).  So
+// (4 MiB each, ~270 G random requests/s in all: the 450 M seeds of a 50 M-read batch are 1.7 ms of L2 requests alone --
+// round 1's XCD-binned sieve, 4.25 ms per 50 M reads, was bound by exactly that; profiles/microbench/xcd_probe.hip)
+// and the 256 LDS (128 KiB usable each, 32 lanes per clock per CU: ~60 x the L2 request rate).  So
 // the filter is cut into 256 slices by key hash, one slice per CU, and every seed is ROUTED to the CU that owns its slice:
 //   k_route        streams the reads once (1024-thread workgroup = tile of 16 groups of 64 reads); per seed the canonical
-//                  key and ONE 32-bit hash: top 8 bits = owner, low 24 bits = filter address.  The tile's seeds are
+//                  key and 33 hash bits: 8 choose the owner, 25 address the owner's filter.  The tile's seeds are
 //                  counting-sorted by (owner, wave) in LDS and each owner's run is appended to the region
 //                  (owner, this workgroup) of the arena -- contiguous stores of ~150 bytes that the L2 merges into whole
 //                  lines (the open lines of an XCD's workgroups are ~2 MiB).  A 4-byte entry = first-of-(owner, wave)
-//                  flag | valid | lane | 24 hash bits; the read index is implied by the position in the region: the
+//                  flag | lane | 25 hash bits; the read index is implied by the position in the region: the
 //                  consumer counts the flags (every (owner, wave) pair of a tile contributes at least a dummy entry).
-//   k_route_probe  one workgroup per owner holds the owner's 128 KiB filter slice in LDS (two bits of one 32-bit word per
+//   k_route_probe  one workgroup per owner holds the owner's 128 KiB filter slice in LDS (four bits of one 64-bit block per
 //                  key: ~1 % of foreign seeds pass), streams the owner's regions 16 bytes per lane, and sends the
 //                  entries that pass the exact way: the read's seeds are re-hashed, the one(s) equal to the entry's hash
 //                  probe the fingerprint sieve, a hit sets the read's candidate flag.
@@ -764,14 +541,30 @@ __global__ __launch_bounds__(256) void k_bin_probe(const u32* __restrict__ packe
 // list of emitted tiles tells the consumer which tile a flag count belongs to.
 #define RT_OWNERS 256
 #define RT_FWORDS 32768                // 32-bit words of one owner's filter slice (128 KiB)
-#define RT_DUMMY_CAP 1024              // dummy entries a tile may hold (empty (owner, wave) pairs: ~400 of 4096 at nine seeds per read)
-#define RT_FLAG  0x80000000u
-#define RT_VALID 0x40000000u
-__host__ __device__ inline u32 rt_hash(u32 lo, u32 hi) { return table_hash(lo, hi); }       // owner = h >> 24, filter address = h & 0xFFFFFF
-__host__ __device__ inline void rt_filter_addr(u32 h24, u32& word, u32& mask) {
-    word = h24 >> 9;
-    const u32 b1 = (h24 >> 4) & 31u, b2 = (b1 + 1u + (h24 & 15u)) & 31u;      // two different bits of the word
-    mask = (1u << b1) | (1u << b2);
+#define RT_DUMMY_CAP 2048              // dummy + padding entries a tile may hold (empty (owner, wave) runs: ~400 of 4096 at nine seeds per read; padding ~400)
+#define RT_MAXP  2048                  // most producer workgroups (regions per owner) a submission may use
+#define RT_FLAG  0x80000000u           // entry = RT_FLAG | lane << 25 | 25 hash bits; RT_DUMMY in the hash bits = "no seed here"
+#define RT_HMASK 0x01FFFFFFu
+#define RT_DUMMY 0x01FFFFFFu
+// 33 hash bits of a canonical key: 8 choose the owner, 25 travel in the entry (a real key that hashes to RT_DUMMY takes
+// the value below it -- in the filter build, in k_route and in the re-hash of k_route_probe alike).
+__host__ __device__ inline u32 rt_parity(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)__popc(x) & 1u;
+#else
+    return (u32)__builtin_popcount(x) & 1u;
+#endif
+}
+__host__ __device__ inline void rt_hash(u32 lo, u32 hi, u32& owner, u32& h25) {
+    const u32 a = table_hash(lo, hi);
+    owner = a >> 24;
+    h25 = ((a & 0xFFFFFFu) << 1) | rt_parity(lo ^ (lo >> 13) ^ (hi * 0x2Du));      // one more bit, taken from the key itself
+    if (h25 == RT_DUMMY) h25 = RT_DUMMY - 1u;
+}
+__host__ __device__ inline void rt_filter_addr(u32 h25, u32& block, u64& mask) {       // 2^14 blocks of 64 bits = 128 KiB, four bits per key
+    block = h25 >> 11;
+    const u32 m = h25 * 0x9E3779B1u;               // positions from a product of the whole hash (its top bits are the well mixed ones)
+    mask = (1ull << (m >> 26)) | (1ull << ((m >> 20) & 63u)) | (1ull << ((m >> 14) & 63u)) | (1ull << ((m >> 8) & 63u));
 }
 struct RouteDev {
     GP<u32> arena;                   // [owner][producer][cap] entries
@@ -779,31 +572,54 @@ struct RouteDev {
     GP<u32> emitted;                 // [producer][1 + tiles_max]: number of tiles routed, then their iteration numbers
     GP<const u32> filter;            // [owner][RT_FWORDS]
     GP<u32> flags;                   // candidate flag per read (zeroed per submission)
-    u32 cap, n_prod, tiles_max;
+    u32 cap, n_prod, tiles_max, nw;  // nw = waves per producer workgroup = groups of 64 reads per tile
 };
-template <int WPR>
-__global__ __launch_bounds__(1024) void k_route(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
-                                                const RouteDev R, Counters* __restrict__ ctr) {
+// inclusive prefix sum over the 64 lanes with DPP lane moves (no LDS traffic, unlike __shfl_up)
+__device__ inline u32 wave_incl_scan_dpp(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR(1), 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR(2), 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR(4), 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR(8), 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST15, 0xA, 0xF, false);      // rows 1 and 3 take the total of rows 0 and 2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, false);      // rows 2 and 3 take the total of the first half
+    return v;
+}
+// NW = waves per workgroup = groups of 64 reads per tile: 16 (one or two workgroups per CU) or 8 (up to four)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global-memory
+// operation of the wave (it is a workgroup-scope release): inside k_route's tile loop that would stall every barrier on
+// the prefetched rows of the next tile and on the stores of the segment write-out, which no other wave of the
+// workgroup ever reads.  What the waves share is LDS: lgkmcnt(0) before s_barrier makes a wave's LDS writes visible to
+// the waves that pass the barrier.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int WPR, int NW>
+__attribute__((amdgpu_waves_per_eu(WPR <= 10 ? 8 : 4, WPR <= 10 ? 8 : 4)))      // reads up to 160 bases: 64 VGPRs, so that the LDS decides how many workgroups share a CU
+__global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
+                                                   const RouteDev R, Counters* __restrict__ ctr) {
     constexpr int NT = WPR - 1;
-    constexpr u32 SCAP = 1024u * NT + RT_DUMMY_CAP;
-    __shared__ u32 s_cnt[16][RT_OWNERS];          // per (wave, owner): count, later the start of the run in s_sorted
-    __shared__ u32 s_sorted[SCAP];
-    __shared__ u32 s_off[RT_OWNERS + 1];          // start of each owner's segment in s_sorted
+    constexpr int QN = NW / 4;                    // thread slices of 256: slice q holds the runs of waves 4q .. 4q+3
+    constexpr u32 TILE = NW * 64u;
+    constexpr u32 SCAP = TILE * NT + (NW == 16 ? 2048u : 1536u);      // + dummy and padding entries (typically ~5 % + ~4..8 %)
+    constexpr int OPW = RT_OWNERS / NW;           // owners whose segments a wave writes out
+    __shared__ u32 s_cnt[NW][RT_OWNERS];          // per (wave, owner): count, later the start of the run in s_sorted
+    __shared__ __attribute__((aligned(16))) u32 s_sorted[SCAP + 4];      // + a spare word for slots without a seed
+    __shared__ u32 s_part[QN][RT_OWNERS];         // entries of an owner's runs per slice of the waves
+    __shared__ u32 s_off[RT_OWNERS + 1];          // start of each owner's segment in s_sorted (multiples of four)
     __shared__ u32 s_cur[RT_OWNERS];              // entries written so far to region (owner, this workgroup)
     __shared__ u32 s_wsum[4]; __shared__ u32 s_over;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // the wave number in a scalar register
     const u32 p = blockIdx.x, P = gridDim.x;
+    const u32 so = (u32)tid & 255u, sq = (u32)tid >> 8;
     if (tid == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());
     #pragma unroll
-    for (int j = 0; j < 4; j++) s_cnt[(tid >> 8) * 4 + j][tid & 255] = 0;
+    for (int v = 0; v < 4; v++) s_cnt[sq * 4 + v][so] = 0;
     if (tid < RT_OWNERS) s_cur[tid] = 0;
     if (tid == 0) s_over = 0;
     __syncthreads();
-    const u64 n_groups = (n_reads + 63) >> 6, n_tiles = (n_reads + 1023) >> 10;
+    const u64 n_groups = (n_reads + 63) >> 6, n_tiles = (n_reads + TILE - 1) / TILE;
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     v2u xn[WPR / 2]; u16 len_raw = 0;
     {
-        const u64 g0 = (u64)p * 16 + wave, gc = g0 < n_groups ? g0 : 0, r0 = gc * 64 + lane;
+        const u64 g0 = (u64)p * NW + wave, gc = g0 < n_groups ? g0 : 0, r0 = gc * 64 + lane;
         const v2u* row = reinterpret_cast<const v2u*>(packed) + gc * (32 * WPR) + lane;
         #pragma unroll
         for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
@@ -811,7 +627,22 @@ __global__ __launch_bounds__(1024) void k_route(const u32* __restrict__ packed, 
     }
     u32 n_emit = 0, k = 0;                        // tiles routed so far (thread 0 keeps the list), iteration number
     for (u64 tile = p; tile < n_tiles; tile += P, k++) {
-        const u64 g = tile * 16 + wave, r = g * 64 + lane;
+        // Per-thread addresses (LDS slots, rows, regions) are all functions of the thread index.  Left alone, the compiler
+        // computes dozens of them once, keeps them across the tile loop and spills them at 64 registers; every scratch
+        // reload then carries an s_waitcnt vmcnt(0), which (vmcnt is in order) also waits for the prefetched rows and for
+        // the segment stores.  The thread index is re-read through an opaque copy per tile instead: a few integer
+        // operations per phase, no spill.
+        int td = tid; asm volatile("" : "+v"(td));
+        const int ln = td & 63; const u32 so_ = (u32)td & 255u, sq_ = (u32)td >> 8;
+        auto prefetch_rows = [&](u64 tn) {          // rows of this workgroup's next tile into xn / len_raw
+            const u64 gn = tn * NW + wave, gc = gn < n_groups ? gn : 0, rn = gc * 64 + ln;
+            const v2u* row = reinterpret_cast<const v2u*>(packed) + gc * (32 * WPR) + ln;
+            #pragma unroll
+            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
+            len_raw = lens[rn < n_reads ? rn : 0];
+            asm volatile("" ::: "memory");
+        };
+        const u64 g = tile * NW + wave, r = g * 64 + ln;
         const bool live = g < n_groups && r < n_reads;
         u32 w[WPR]; u32 len_cur;
         #pragma unroll
@@ -820,113 +651,164 @@ __global__ __launch_bounds__(1024) void k_route(const u32* __restrict__ packed, 
             asm volatile("v_mov_b32 %0, %1" : "=v"(w[2 * t2 + 1]) : "v"(xn[t2].y));
         }
         asm volatile("v_mov_b32 %0, %1" : "=v"(len_cur) : "v"((u32)len_raw));
-        {
-            const u64 gn = (tile + P) * 16 + wave, gc = gn < n_groups ? gn : 0, rn = gc * 64 + lane;
-            const v2u* row = reinterpret_cast<const v2u*>(packed) + gc * (32 * WPR) + lane;
-            #pragma unroll
-            for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
-            len_raw = lens[rn < n_reads ? rn : 0];
-            asm volatile("" ::: "memory");
-        }
         const u32 n = live ? (len_cur & 0x7FFFu) : 0u;
         const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
-        // ---- hash every seed, count per (wave, owner); the returned count is the seed's rank inside its run
-        u32 hv[NT], rk[NT];
+        // ---- hash every seed, count per (wave, owner); the returned count is the seed's rank inside its run.
+        // canonical key = the smaller of the seed and its reverse complement.  Per word the bit-reversed swapped
+        // complement once (revc(x) base p = complement of x base 15-p); the reverse complement of the seed at word t
+        // is then two funnel shifts (bases 0..3 from word t+1, 4..19 from word t) -- the same 40 bits canon40() returns.
+        auto revc = [](u32 x) { return __brev(~(((x >> 1) & 0x55555555u) | ((x + x) & 0xAAAAAAAAu))); };
+        u32 hv[NT], rk[NT];                        // the 25 hash bits; owner << 16 | rank inside the (wave, owner) run
+        u32 rb_cur = revc(w[0]);
         #pragma unroll
         for (int t = 0; t < NT; t++) {
+            const u32 rb_nxt = revc(w[t + 1]);
             hv[t] = 0; rk[t] = 0xFFFFFFFFu;
-            if (t < nseeds) {
-                u32 fl; const u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl);
-                hv[t] = rt_hash((u32)c, (u32)(c >> 32));
-                rk[t] = atomicAdd(&s_cnt[wave][hv[t] >> 24], 1u);
+            if (t < nseeds) {      // (a branch per seed keeps the nine hashes from being scheduled side by side, which spills)
+                const u32 slo = w[t], shi = w[t + 1] & 0xFFu;
+                const u32 rlo = __builtin_amdgcn_alignbit(rb_cur, rb_nxt, 24), rhi = rb_cur >> 24;
+                const bool rc_less = rhi < shi || (rhi == shi && rlo < slo);
+                u32 ow, hh; rt_hash(rc_less ? rlo : slo, rc_less ? rhi : shi, ow, hh);
+                hv[t] = hh;
+                rk[t] = (ow << 16) | atomicAdd(&s_cnt[wave][ow], 1u);      // a run holds at most 64 * NT entries
+            }
+            rb_cur = rb_nxt;
+        }
+        lds_barrier();
+        // ---- run lengths and starts.  Thread (sq_, so_) owns the runs of waves 4 sq_ .. 4 sq_ + 3 for owner so_.  An empty run
+        // holds one dummy entry (the consumer counts runs); an owner's segment is padded to a multiple of four entries
+        // (16-byte stores, 16-byte aligned regions) with entries that are neither a seed nor a run start.
+        u32 c4[4], s4 = 0;
+        #pragma unroll
+        for (int v = 0; v < 4; v++) { c4[v] = s_cnt[sq_ * 4 + v][so_]; s4 += c4[v] ? c4[v] : 1u; }
+        s_part[sq_][so_] = s4;
+        lds_barrier();
+        u32 pq[QN], tot = 0;
+        #pragma unroll
+        for (int v = 0; v < QN; v++) { pq[v] = s_part[v][so_]; tot += pq[v]; }
+        const u32 tot4 = (tot + 3u) & ~3u;
+        const u32 inc = wave_incl_scan_dpp(tot4);          // every wave scans the 64 owners of its chunk (so_ >> 6)
+        if (sq_ == 0 && ln == 63) s_wsum[so_ >> 6] = inc;
+        lds_barrier();
+        {
+            u32 off = inc - tot4;
+            for (u32 v = 0; v < (so_ >> 6); v++) off += s_wsum[v];
+            if (sq_ == 0) {
+                s_off[so_] = off;
+                if (so_ == RT_OWNERS - 1) s_off[RT_OWNERS] = off + tot4;
+                if (s_cur[so_] + tot4 > R.cap || off + tot4 > SCAP) s_over = 1;
+            }
+            if (sq_ == QN - 1) for (u32 x = off + tot; x < off + tot4 && x < SCAP; x++) s_sorted[x] = RT_DUMMY;      // padding
+            #pragma unroll
+            for (int v = 0; v < QN; v++) off += (u32)v < sq_ ? pq[v] : 0u;
+            #pragma unroll
+            for (int v = 0; v < 4; v++) {
+                s_cnt[sq_ * 4 + v][so_] = off;
+                if (c4[v] == 0) { if (off < SCAP) s_sorted[off] = RT_FLAG | RT_DUMMY; off += 1; }      // dummy: the run exists, it holds no seed
+                else off += c4[v];
             }
         }
-        __syncthreads();
-        // ---- 256 threads, one per owner: run lengths (an empty run holds one dummy), exclusive scan over the owners
-        u32 tot = 0, pre = 0;
-        if (tid < RT_OWNERS) {
-            #pragma unroll
-            for (int v = 0; v < 16; v++) { const u32 c = s_cnt[v][tid]; tot += c ? c : 1u; }
-            u32 wt; pre = wave_excl_scan_u32(tot, wt);
-            if (lane == 63) s_wsum[wave] = wt;
-        }
-        __syncthreads();
-        if (tid < RT_OWNERS) {
-            u32 off = pre;
-            for (int v = 0; v < wave; v++) off += s_wsum[v];
-            s_off[tid] = off;
-            if (tid == RT_OWNERS - 1) s_off[RT_OWNERS] = off + tot;
-            const bool over = s_cur[tid] + tot > R.cap || off + tot > SCAP;
-            if (over) s_over = 1;
-            #pragma unroll
-            for (int v = 0; v < 16; v++) {
-                const u32 c = s_cnt[v][tid];
-                s_cnt[v][tid] = off;
-                if (c == 0) { if (off < SCAP) s_sorted[off] = RT_FLAG; off += 1; }      // dummy: flag without RT_VALID
-                else off += c;
-            }
-        }
-        __syncthreads();
+        lds_barrier();
         if (s_over) {      // block-uniform: the tile is not routed, its reads are candidates
-            if (tid < 32) {
-                const u64 wi = tile * 32 + tid, first = wi * 32;
+            if ((u32)td < TILE / 32) {
+                const u64 wi = tile * (TILE / 32) + td, first = wi * 32;
                 if (first < n_reads) { const u64 left = n_reads - first; R.flags[wi] = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u); }
             }
             #pragma unroll
-            for (int j = 0; j < 4; j++) s_cnt[(tid >> 8) * 4 + j][tid & 255] = 0;
-            __syncthreads();
-            if (tid == 0) s_over = 0;
-            __syncthreads();
+            for (int v = 0; v < 4; v++) s_cnt[sq_ * 4 + v][so_] = 0;
+            prefetch_rows(tile + P);
+            lds_barrier();
+            if (td == 0) s_over = 0;
+            lds_barrier();
             continue;
         }
         // ---- scatter into (owner, wave) order
-        #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            if (rk[t] != 0xFFFFFFFFu)
-                s_sorted[s_cnt[wave][hv[t] >> 24] + rk[t]] = (rk[t] == 0 ? RT_FLAG : 0u) | RT_VALID | ((u32)lane << 24) | (hv[t] & 0xFFFFFFu);
+        {   // the run starts of all seeds first (independent LDS reads), then the writes; a slot without a seed writes to a
+            // spare word behind the buffer
+            u32 st[NT];
+            #pragma unroll
+            for (int t = 0; t < NT; t++) st[t] = s_cnt[wave][(rk[t] >> 16) & 255u];
+            tie_all<NT>(st);
+            #pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const bool valid = rk[t] != 0xFFFFFFFFu;
+                s_sorted[valid ? st[t] + (rk[t] & 0xFFFFu) : SCAP] = ((rk[t] & 0xFFFFu) == 0 ? RT_FLAG : 0u) | ((u32)ln << 25) | hv[t];
+            }
         }
-        __syncthreads();
-        // ---- append every owner's segment to its region; wave v serves owners 16 v .. 16 v + 15
-        #pragma unroll 4
-        for (int i = 0; i < 16; i++) {
-            const u32 o = (u32)wave * 16 + i;
-            const u32 b = s_off[o], e = s_off[o + 1], cur = s_cur[o];
-            auto dst = R.arena.g() + ((u64)o * P + p) * R.cap + cur;
-            for (u32 j = b + lane; j < e; j += 64) dst[j - b] = s_sorted[j];
-            if (lane == 0) s_cur[o] = cur + (e - b);
+        lds_barrier();
+        prefetch_rows(tile + P);      // requested here, when the seeds' registers are free again; in flight during the write-out
+        // ---- append every owner's segment to its region; wave v serves owners OPW v .. OPW v + OPW - 1, four at a time:
+        // 16 lanes per owner, 16 bytes per ln (segments and regions are multiples of four entries)
+        {
+            constexpr int NI = 2;                 // owners-of-four handled together (OPW / 4 = 4 or 8 in all)
+            const u32 sub = (u32)ln & 15u, grp = (u32)ln >> 4;
+            // what two iterations need from LDS in two batches of independent reads (bounds and cursors, then the entries):
+            // one read after the other, this phase was a chain of ~20 LDS latencies
+            #pragma unroll
+            for (int i0 = 0; i0 < OPW / 4; i0 += NI) {
+                u32 oo[NI], sb[NI], se[NI], sc[NI];
+                #pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    oo[i] = (u32)wave * OPW + (u32)(i0 + i) * 4 + grp;
+                    asm volatile("" : "+v"(oo[i]));      // keeps the region addresses out of the loop-invariant (spilled) set
+                    sb[i] = s_off[oo[i]]; se[i] = s_off[oo[i] + 1]; sc[i] = s_cur[oo[i]];
+                }
+                tie_all<NI>(sb); tie_all<NI>(se); tie_all<NI>(sc);
+                v4u dv[NI];
+                #pragma unroll
+                for (int i = 0; i < NI; i++) { const u32 j = sb[i] + sub * 4; dv[i] = *reinterpret_cast<const v4u*>(&s_sorted[j < se[i] ? j : 0u]); }
+                #pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    auto dst = reinterpret_cast<v4u GLOBAL_AS*>(R.arena.g() + (((u64)oo[i] * P + p) * R.cap + sc[i]));
+                    if (sb[i] + sub * 4 < se[i]) dst[sub] = dv[i];
+                    for (u32 j = sb[i] + sub * 4 + 64; j < se[i]; j += 64) dst[(j - sb[i]) >> 2] = *reinterpret_cast<const v4u*>(&s_sorted[j]);      // segments beyond 64 entries: rare
+                    if (sub == 0) s_cur[oo[i]] = sc[i] + (se[i] - sb[i]);
+                }
+            }
         }
         #pragma unroll
-        for (int j = 0; j < 4; j++) s_cnt[(tid >> 8) * 4 + j][tid & 255] = 0;
-        if (tid == 0) { R.emitted[(u64)p * (R.tiles_max + 1) + 1 + n_emit] = k; n_emit++; }
-        __syncthreads();
+        for (int v = 0; v < 4; v++) s_cnt[sq_ * 4 + v][so_] = 0;
+        if (td == 0) { R.emitted[(u64)p * (R.tiles_max + 1) + 1 + n_emit] = k; n_emit++; }
+        lds_barrier();
     }
     if (tid < RT_OWNERS) R.counts[(u64)tid * P + p] = s_cur[tid];
     if (tid == 0) R.emitted[(u64)p * (R.tiles_max + 1)] = n_emit;
 }
 
 // examine up to 64 parked survivors of one wave: re-hash the read's seeds, probe the fingerprint sieve with those whose
-// hash is the entry's
-__device__ inline void rt_examine(const u64* q, u32 cnt, int lane, u32 owner, const u32* __restrict__ packed, const u16* __restrict__ lens, u32 wpr,
+// hash is the entry's.  Two dependent round trips (the whole row, the buckets), each a batch of independent loads: a lane
+// that walked its seeds one load at a time held its wave for a dozen memory latencies per survivor.  The read's length is
+// not fetched: rows hold zeros beyond the read, and a window of them that happened to reproduce the entry's 33 hash
+// bits AND sat in the fingerprint sieve would add a candidate, which k_seed looks up exactly like every other.
+template <int WPR>
+__device__ inline void rt_examine(const u64* q, u32 cnt, int lane, u32 owner, const u32* __restrict__ packed,
                                   const uint4* __restrict__ sieve, u32 smask, u32 sshift, u32* flags) {
+    constexpr int NT = WPR - 1;
     if ((u32)lane >= cnt) return;
     const u64 e = q[lane];
-    const u64 rr = e & 0xFFFFFFFFull; const u32 want = (owner << 24) | (u32)(e >> 32);
-    const u32 n = lens[rr] & 0x7FFFu;
-    const int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
+    const u64 rr = e & 0xFFFFFFFFull; const u32 want = (u32)(e >> 32);
+    const u32* row = packed + packed_index(rr, WPR, 0);      // word c of the row: row[(c >> 1) * 128 + (c & 1)]
+    u32 w[WPR];
+    #pragma unroll
+    for (int c = 0; c < WPR; c++) w[c] = row[(c >> 1) * 128 + (c & 1)];
+    tie_all<WPR>(w);
     bool hit = false;
-    u32 w0 = nseeds ? packed[packed_index(rr, wpr, 0)] : 0u;
-    for (int t = 0; t < nseeds && !hit; t++) {
-        const u32 w1 = packed[packed_index(rr, wpr, (u32)t + 1)];
-        u32 fl; const u64 c = canon40((u64)w0 | ((u64)(w1 & 0xFFu) << 32), fl);
-        if (rt_hash((u32)c, (u32)(c >> 32)) == want) hit = bin_exact(w0, w1, sieve, smask, sshift);
-        w0 = w1;
+    #pragma unroll
+    for (int t = 0; t < NT; t++) {
+        if (!hit) {
+            u32 fl; const u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl);
+            u32 ow, hh; rt_hash((u32)c, (u32)(c >> 32), ow, hh);
+            if (ow == owner && hh == want) hit = bin_exact(w[t], w[t + 1], sieve, smask, sshift);
+        }
     }
     if (hit) atomicOr(&flags[rr >> 5], 1u << (rr & 31));
 }
-__global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ packed, const u16* __restrict__ lens, u32 wpr, u64 n_reads,
+template <int WPR>
+__global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
                                                       const uint4* __restrict__ sieve, u32 smask, const RouteDev R, Counters* __restrict__ ctr) {
-    __shared__ __attribute__((aligned(16))) u32 s_f[RT_FWORDS];
+    __shared__ __attribute__((aligned(16))) u64 s_f[RT_FWORDS / 2];
     __shared__ u64 s_q[16][128];                  // per-wave queue of entries that passed the filter: read | hash << 32
+    constexpr int PF = 4;                         // 16-byte loads per lane in flight: 4 KiB per wave, 64 KiB per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 owner = blockIdx.x, P = R.n_prod;
     const u32 sshift = (u32)__clz((int)smask);
@@ -936,63 +818,84 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
         for (int j = 0; j < RT_FWORDS / 4 / 1024; j++) s4[tid + 1024 * j] = g4[tid + 1024 * j];
     }
     __syncthreads();
-    const u64 n_tiles = (n_reads + 1023) >> 10;
+    const u32 NWP = R.nw;                          // runs per tile in a region (one per producer wave)
+    const u64 n_tiles = (n_reads + (u64)NWP * 64 - 1) / ((u64)NWP * 64);
     u64* const q = s_q[wave]; u32 qn = 0;          // wave-uniform
     const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-    for (u32 p = (u32)wave; p < P; p += 16) {      // this wave's regions
-        const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)R.counts[(u64)owner * P + p]);
+    // the entry counts and routed-tile counts of this wave's regions (lane i: region wave + 16 i), fetched once: read
+    // region by region they cost two dependent round trips in front of every region's first load
+    u32 my_n[RT_MAXP / 1024], my_em[RT_MAXP / 1024];
+    #pragma unroll
+    for (int c = 0; c < RT_MAXP / 1024; c++) {
+        const u32 pp = (u32)wave + 16u * ((u32)lane + 64u * c);
+        my_n[c] = pp < P ? R.counts[(u64)owner * P + pp] : 0u;
+        my_em[c] = pp < P ? R.emitted[(u64)pp * (R.tiles_max + 1)] : 0u;
+    }
+    for (u32 p = (u32)wave, pi = 0; p < P; p += 16, pi++) {      // this wave's regions
+        u32 n = 0, em0 = 0;
+        #pragma unroll
+        for (int c = 0; c < RT_MAXP / 1024; c++) if ((pi >> 6) == (u32)c) { n = (u32)__shfl((int)my_n[c], (int)(pi & 63)); em0 = (u32)__shfl((int)my_em[c], (int)(pi & 63)); }
+        n = (u32)__builtin_amdgcn_readfirstlane((int)n);
         const auto emit = R.emitted.g() + (u64)p * (R.tiles_max + 1);
         const u32 n_mine = p < n_tiles ? (u32)((n_tiles - p + P - 1) / P) : 0u;      // tiles the producer was dealt
-        const bool ident = (u32)__builtin_amdgcn_readfirstlane((int)emit[0]) == n_mine;      // every one of them was routed
-        const auto ent = R.arena.g() + ((u64)owner * P + p) * R.cap;
+        const bool ident = (u32)__builtin_amdgcn_readfirstlane((int)em0) == n_mine;      // every one of them was routed
+        const auto ent4 = reinterpret_cast<const v4u GLOBAL_AS*>(R.arena.g() + ((u64)owner * P + p) * R.cap);
         int seq = -1;                               // flags seen so far - 1 = sequence number of the current (tile, wave) run
-        v4u en = (u32)lane * 4 < n ? __builtin_nontemporal_load(reinterpret_cast<const v4u GLOBAL_AS*>(ent) + lane) : v4u{0u, 0u, 0u, 0u};
-        for (u32 i0 = 0; i0 < n; i0 += 256) {
-            u32 ev[4];
-            asm volatile("v_mov_b32 %0, %1" : "=v"(ev[0]) : "v"(en.x)); asm volatile("v_mov_b32 %0, %1" : "=v"(ev[1]) : "v"(en.y));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(ev[2]) : "v"(en.z)); asm volatile("v_mov_b32 %0, %1" : "=v"(ev[3]) : "v"(en.w));
-            {
-                const u32 i1 = i0 + 256 + (u32)lane * 4;
-                en = i1 < n ? __builtin_nontemporal_load(reinterpret_cast<const v4u GLOBAL_AS*>(ent) + (i1 >> 2)) : v4u{0u, 0u, 0u, 0u};
-                asm volatile("" ::: "memory");
-            }
-            bool lv[4], fg[4]; u64 B[4]; u32 before = 0;
+        v4u en[PF];
+        #pragma unroll
+        for (int u = 0; u < PF; u++) { const u32 i = (u32)u * 256 + (u32)lane * 4; en[u] = i < n ? __builtin_nontemporal_load(ent4 + (i >> 2)) : v4u{0u, 0u, 0u, 0u}; }
+        for (u32 i0 = 0; i0 < n; i0 += 256 * PF) {
+            u32 ev[PF][4];
             #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                lv[j] = i0 + (u32)lane * 4 + j < n;
-                fg[j] = lv[j] && (ev[j] & RT_FLAG);
-                B[j] = __ballot(fg[j]);
-                before += (u32)__popcll(B[j] & lt);
+            for (int u = 0; u < PF; u++) {         // register copies free en[] for the loads below (see k_sieve_q)
+                asm volatile("v_mov_b32 %0, %1" : "=v"(ev[u][0]) : "v"(en[u].x)); asm volatile("v_mov_b32 %0, %1" : "=v"(ev[u][1]) : "v"(en[u].y));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(ev[u][2]) : "v"(en[u].z)); asm volatile("v_mov_b32 %0, %1" : "=v"(ev[u][3]) : "v"(en[u].w));
             }
-            int run = seq + (int)before;
             #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                run += fg[j] ? 1 : 0;
-                bool pass = false;
-                if (lv[j] && (ev[j] & RT_VALID)) { u32 wd, mk; rt_filter_addr(ev[j] & 0xFFFFFFu, wd, mk); pass = (s_f[wd] & mk) == mk; }
-                u64 rr = 0;
-                if (pass) {
-                    const u32 jt = (u32)run >> 4, wv = (u32)run & 15u;
-                    const u32 kk = ident ? jt : emit[1 + jt];
-                    rr = (((u64)p + (u64)kk * P) * 16 + wv) * 64 + ((ev[j] >> 24) & 63u);
-                    pass = rr < n_reads;
+            for (int u = 0; u < PF; u++) { const u32 i = i0 + 256 * PF + (u32)u * 256 + (u32)lane * 4; en[u] = i < n ? __builtin_nontemporal_load(ent4 + (i >> 2)) : v4u{0u, 0u, 0u, 0u}; }
+            asm volatile("" ::: "memory");
+            #pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const u32 ib = i0 + (u32)u * 256;
+                if (ib >= n) break;                 // wave-uniform
+                bool lv[4], fg[4]; u64 B[4]; u32 before = 0;
+                #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    lv[j] = ib + (u32)lane * 4 + j < n;
+                    fg[j] = lv[j] && (ev[u][j] & RT_FLAG);
+                    B[j] = __ballot(fg[j]);
+                    before += (u32)__popcll(B[j] & lt);
                 }
-                const u64 pm = __ballot(pass);
-                if (pm) {
-                    if (pass) q[qn + (u32)__popcll(pm & lt)] = rr | ((u64)(ev[j] & 0xFFFFFFu) << 32);
-                    qn += (u32)__popcll(pm);
-                    if (qn >= 64) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        rt_examine(q + (qn - 64), 64, lane, owner, packed, lens, wpr, sieve, smask, sshift, R.flags.p);
-                        qn -= 64;
+                int run = seq + (int)before;
+                #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    run += fg[j] ? 1 : 0;
+                    bool pass = false;
+                    if (lv[j] && (ev[u][j] & RT_HMASK) != RT_DUMMY) { u32 bk; u64 mk; rt_filter_addr(ev[u][j] & RT_HMASK, bk, mk); pass = (s_f[bk] & mk) == mk; }
+                    u64 rr = 0;
+                    if (pass) {
+                        const u32 jt = NWP == 16 ? (u32)run >> 4 : (u32)run >> 3, wv = (u32)run & (NWP - 1u);
+                        const u32 kk = ident ? jt : emit[1 + jt];
+                        rr = (((u64)p + (u64)kk * P) * NWP + wv) * 64 + ((ev[u][j] >> 25) & 63u);
+                        pass = rr < n_reads;
+                    }
+                    const u64 pm = __ballot(pass);
+                    if (pm) {
+                        if (pass) q[qn + (u32)__popcll(pm & lt)] = rr | ((u64)(ev[u][j] & RT_HMASK) << 32);
+                        qn += (u32)__popcll(pm);
+                        if (qn >= 64) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            rt_examine<WPR>(q + (qn - 64), 64, lane, owner, packed, sieve, smask, sshift, R.flags.p);
+                            qn -= 64;
+                        }
                     }
                 }
+                seq += (int)(__popcll(B[0]) + __popcll(B[1]) + __popcll(B[2]) + __popcll(B[3]));
             }
-            seq += (int)(__popcll(B[0]) + __popcll(B[1]) + __popcll(B[2]) + __popcll(B[3]));
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    rt_examine(q, qn, lane, owner, packed, lens, wpr, sieve, smask, sshift, R.flags.p);
+    rt_examine<WPR>(q, qn, lane, owner, packed, sieve, smask, sshift, R.flags.p);
     __syncthreads();
     if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
 }
@@ -1430,9 +1333,6 @@ __device__ inline int ungapped(const EngineDev& E, const KParams& P, const Locus
     for (int w = 0; w < NW / 2; w++) {
         if (w * 2 < nw) {
             u32 Mw = M[w];
-#ifdef EXP_NO_KADANE
-            Mw = 0;
-#endif
             const u32 special = s_odd[w] | AN[w];
             while (Mw) {
                 int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
@@ -1578,9 +1478,6 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
             #pragma unroll
             for (int w = 0; w < NB; w++) {
                 u32 Mw = M[w];
-#ifdef EXP_NO_KADANE
-                Mw = 0;
-#endif
                 const u32 special = od[w] | AN[w];
                 while (Mw) {
                     const int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
@@ -1597,9 +1494,6 @@ __device__ inline int ungapped_planes(const EngineDev& E, const KParams& P, cons
             #pragma unroll
             for (int w = 0; w < NB; w++) {
                 u32 Mw = M[w];
-#ifdef EXP_NO_KADANE
-                Mw = 0;
-#endif
                 while (Mw) {
                     const int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
                     const int t = mad24(bit, MA, gw);
@@ -1705,18 +1599,11 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
             rn[w] = read_has_n ? __builtin_amdgcn_readfirstlane(s_rn[w]) : 0u;
         }
         u32 nrec = 0, ndp = 0;
-#ifdef EXP_NO_ALLELES
-        for (u32 a = tid; a < 0; a += nthr) {
-#else
         for (u32 a = tid; res_ok && a < L.n_alleles; a += nthr) {
-#endif
             int m = (int)E.allele_len[L.a_begin + a];
             int mm, bs, be;
             int best = L.has_n ? ungapped_planes<NB, false, true>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be)
                                : ungapped_planes<NB, false, false>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
-#ifdef EXP_NO_KADANE
-            mm = 0;
-#endif
             int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
             bool need_dp = P.trig < 0;
             if (!need_dp && mm > P.trig && score >= floor_n) {       // rare: the policy needs the aligned span
@@ -1746,7 +1633,6 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
         if (tid == 0 && tot_rec) atomicAdd(&E.ret_nrec[it.ret], tot_rec);   // per-read record count (Q1)
         // Fused accumulation (metamlst.py:101-130) when everything about this read is known here:
         // it has a single work item and no pair is waiting for the banded SW.
-#ifndef EXP_NO_ACC
         if (res_ok && (state & IS_SINGLE) && tot_dp == 0) {
             bool use_xo = P.quirk && tot_rec == 1;
             u32 acc = 0, ign = 0;
@@ -1770,7 +1656,6 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                 E.item_state[ii] = (u8)(state | IS_DONE | (A ? IS_ACC : 0));
             }
         }
-#endif
         if (tid == 0) {
             u64 nx = begin + myq + (u64)EXT_Q * ticket;
             while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal(E, myq, begin, end); }
@@ -1791,12 +1676,6 @@ __attribute__((amdgpu_waves_per_eu(7, 7)))
 __global__ __launch_bounds__(1024) void k_extend_160(const EngineDev* __restrict__ Ep, KParams P) { extend_body<5>(Ep, P); }
 __global__ __launch_bounds__(1024) void k_extend_320(const EngineDev* __restrict__ Ep, KParams P) { extend_body<RW / 2>(Ep, P); }
 
-// ---- DPP lane moves (gfx9 encodings).  update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): a lane whose
-// source is out of range, or whose row is masked off, keeps `old`.
-#define DPP_ROW_SHR(n)  (0x110 + (n))
-#define DPP_WAVE_SHL1   0x130      /* lane i <- lane i+1 */
-#define DPP_WAVE_SHR1   0x138      /* lane i <- lane i-1 */
-#define DPP_ROW_BCAST15 0x142      /* lane 15 of each 16-lane row -> every lane of the next row */
 template <int CTRL, int ROW_MASK = 0xF> __device__ inline int dpp_i32(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
 }
@@ -2303,14 +2182,11 @@ struct mlst_handle {
     bool have_ref = false, have_state = false;
     // batch scratch
     u32* d_cand = nullptr; u64 cap_cand = 0;
-    // XCD-binned sieve (big databases): per-owner Bloom filters (reference) and the per-submission arena
-    u64* d_bloom = nullptr; u32 bloom_blk_bits = 0; bool binned = false;
     // CU-routed sieve (K1c): filter slices (reference) and the per-submission arena
     int sieve_kind = 0; u32 sieve_chain = 0; u64 n_keys = 0;
     u32* d_rfilter = nullptr; u32* d_rt_arena = nullptr; u64 cap_rt_arena = 0; u32* d_rt_counts = nullptr; u32* d_rt_emitted = nullptr; u64 cap_rt_emitted = 0;
-    u32 rt_prod = 0, rt_cap = 0, rt_tiles_max = 0;
-    u64* d_bin_arena = nullptr; u64 cap_bin_arena = 0; u32* d_bin_counts = nullptr; u32* d_bin_next = nullptr; u32* d_bin_flags = nullptr; u64 cap_bin_flags = 0;
-    u32 bin_pw = 0, bin_blocks = 0; u64 bin_cap = 0;
+    u32 rt_prod = 0, rt_cap = 0, rt_tiles_max = 0, rt_nw = 16;
+    u32* d_bin_flags = nullptr; u64 cap_bin_flags = 0;      // candidate flag per read of the current submission
     u8* d_in_bases = nullptr; u8* d_in_quals = nullptr; u64* d_in_off = nullptr; u64 cap_in_bytes = 0, cap_in_reads = 0;
     u32* d_packed = nullptr; u8* d_qrows = nullptr; u16* d_lens = nullptr; u64 cap_packed_words = 0, cap_qrow_bytes = 0, cap_lens = 0;
     u64 reads_seen = 0;
@@ -2444,7 +2320,6 @@ static void free_ref(mlst_handle* h) {
     hipFree(h->d_arena); hipFree(h->d_planes); hipFree(h->d_nmask); hipFree(h->d_allele_len); hipFree(h->d_allele_locus); hipFree(h->d_loci);
     hipFree(h->d_sieve); hipFree(h->d_bitmap); h->d_bitmap = nullptr; hipFree(h->d_gbitmap); h->d_gbitmap = nullptr; hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
     hipFree(h->d_ascii); hipFree(h->d_aoff);
-    hipFree(h->d_bloom); h->d_bloom = nullptr; h->binned = false;
     hipFree(h->d_rfilter); h->d_rfilter = nullptr;
     hipFree(h->d_allele_no); hipFree(h->d_auto_chosen); hipFree(h->d_fixed_colbase); hipFree(h->d_auto_counts); hipFree(h->d_auto_letters);
     if (h->h_auto) { hipHostFree(h->h_auto); h->h_auto = nullptr; }
@@ -2455,8 +2330,7 @@ static void free_ref(mlst_handle* h) {
 }
 static void free_state(mlst_handle* h) {
     EngineDev& E = h->E;
-    hipFree(h->d_bin_arena); hipFree(h->d_bin_counts); hipFree(h->d_bin_next); hipFree(h->d_bin_flags);
-    h->d_bin_arena = nullptr; h->d_bin_counts = nullptr; h->d_bin_next = nullptr; h->d_bin_flags = nullptr; h->cap_bin_arena = 0; h->cap_bin_flags = 0; h->bin_pw = 0;
+    hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; h->cap_bin_flags = 0;
     hipFree(h->d_rt_arena); hipFree(h->d_rt_counts); hipFree(h->d_rt_emitted);
     h->d_rt_arena = nullptr; h->d_rt_counts = nullptr; h->d_rt_emitted = nullptr; h->cap_rt_arena = 0; h->cap_rt_emitted = 0; h->rt_prod = 0;
     hipFree(h->d_E); h->d_E = nullptr;
@@ -2507,12 +2381,11 @@ struct HostIndex {
     std::vector<u16> sv; u64 nb = 0; u32 smask = 0, sieve_chain = 0;      // fingerprint sieve; longest overflow walk of any key
     std::vector<u32> bitmap; double bitmap_fill = 0.0;                   // LDS half-seed bitmaps (small databases)
     std::vector<u32> gbitmap; u32 gbits = 0;                             // hashed global bitmap (MLST_SIEVE=global)
-    std::vector<u64> bloom; u32 blk_bits = 0;                            // XCD-binned Bloom filters (MLST_SIEVE=binned)
-    std::vector<u32> rfilter;                                            // CU-routed filter slices (big databases)
+    std::vector<u64> rfilter;                                            // CU-routed filter slices (big databases)
     u64 n_keys = 0; u32 n_loci = 0; int kind = 0;                        // kind: MLST_SIEVE_* below
     std::string err; int err_code = 0;
 };
-enum { MLST_SIEVE_LDS = 0, MLST_SIEVE_GLOBAL = 1, MLST_SIEVE_BINNED = 2, MLST_SIEVE_ROUTED = 3 };
+enum { MLST_SIEVE_LDS = 0, MLST_SIEVE_GLOBAL = 1, MLST_SIEVE_ROUTED = 3 };      // (2 was round 1's XCD-binned sieve, replaced by the routed one)
 struct KP { u64 key; u32 post; };
 
 static u64 fnv1a(const void* p, u64 n, u64 hsh) {       // eight bytes at a time (a cache key, not a checksum of record)
@@ -2678,7 +2551,7 @@ static std::shared_ptr<HostIndex> build_host_index(const uint8_t* ascii, const u
     }
     // ---- first-level filter.  Small databases: two half-seed bitmaps kept in LDS by k_sieve_q<., true>, used when they
     // turn out at most half full.  Everything else: the CU-routed filter slices (K1c).  MLST_SIEVE = lds / routed /
-    // binned / global forces a kind (tests, A/B measurements; "lds" still falls back when the bitmaps are not selective).
+    // global forces a kind (tests, A/B measurements; "lds" still falls back when the bitmaps are not selective).
     int kind = want_kind;
     if (kind < 0 || kind == MLST_SIEVE_LDS) {
         const u64 nbits = 1ull << BITMAP_BITS;
@@ -2707,21 +2580,11 @@ static std::shared_ptr<HostIndex> build_host_index(const uint8_t* ascii, const u
             for (u64 i = 0; i < nk; i++) { u32 bi = bitmap_hash_bits((u32)ukeys[i], (u32)(ukeys[i] >> 32), gbits); H->gbitmap[bi >> 5] |= 1u << (bi & 31); }
         }
     }
-    if (kind == MLST_SIEVE_BINNED) {
-        const char* bb = getenv("MLST_BLOOM_BITS"); u32 blk_bits = bb ? (u32)atoi(bb) : 18u;     // 2^18 blocks x 8 B = 2 MiB per owner
-        if (blk_bits < 10 || blk_bits > 22) blk_bits = 18;
-        H->blk_bits = blk_bits; H->bloom.assign((u64)BIN_OWNERS << blk_bits, 0ull);
-        for (u64 i = 0; i < nk; i++) {
-            u32 owner, bi; u64 h36, m; bin_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32), owner, h36);
-            bin_bloom_addr(h36, blk_bits, bi, m);
-            H->bloom[((u64)owner << blk_bits) + bi] |= m;
-        }
-    }
     if (kind == MLST_SIEVE_ROUTED) {
-        H->rfilter.assign((u64)RT_OWNERS * RT_FWORDS, 0u);
+        H->rfilter.assign((u64)RT_OWNERS * (RT_FWORDS / 2), 0ull);
         for (u64 i = 0; i < nk; i++) {
-            const u32 hh = rt_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32)); u32 wd, mk; rt_filter_addr(hh & 0xFFFFFFu, wd, mk);
-            H->rfilter[(u64)(hh >> 24) * RT_FWORDS + wd] |= mk;
+            u32 ow, hh, bk; u64 mk; rt_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32), ow, hh); rt_filter_addr(hh, bk, mk);
+            H->rfilter[(u64)ow * (RT_FWORDS / 2) + bk] |= mk;
         }
     }
     H->kind = kind;
@@ -2738,7 +2601,6 @@ static int sieve_kind_from_env() {
     if (!s || !s[0]) return -1;
     if (!strcmp(s, "lds")) return MLST_SIEVE_LDS;
     if (!strcmp(s, "global")) return MLST_SIEVE_GLOBAL;
-    if (!strcmp(s, "binned")) return MLST_SIEVE_BINNED;
     if (!strcmp(s, "routed")) return MLST_SIEVE_ROUTED;
     return -1;
 }
@@ -2759,7 +2621,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         key[0] = fnv1a(off, ((u64)n_alleles + 1) * 8, 0xCBF29CE484222325ull ^ n_alleles);
         key[1] = fnv1a(ascii, off[n_alleles], fnv1a(locus_id, (u64)n_alleles * 4, 0x9E3779B97F4A7C15ull));
         key[2] = (u64)(want_kind + 2);
-        for (const char* v : {"MLST_GBM_BITS", "MLST_BLOOM_BITS"}) { const char* e = getenv(v); if (e) key[2] = fnv1a(e, strlen(e), key[2]); }
+        for (const char* v : {"MLST_GBM_BITS"}) { const char* e = getenv(v); if (e) key[2] = fnv1a(e, strlen(e), key[2]); }
         if (species_id) key[2] = fnv1a(species_id, (u64)n_alleles * 4, key[2]);
         std::lock_guard<std::mutex> lk(g_index_mu);
         if (g_index_last && g_index_key[0] == key[0] && g_index_key[1] == key[1] && g_index_key[2] == key[2]) HI = g_index_last;
@@ -2772,8 +2634,8 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     const u32 n_loci = HI->n_loci; h->n_loci = n_loci;
     const std::vector<LocusDev>& loci = HI->loci; const std::vector<u16>& alen = HI->alen;
     const std::vector<u32>&arena = HI->arena, &nmask = HI->nmask, &planes = HI->planes, &posts = HI->posts, &tvals = HI->tvals, &bitmap = HI->bitmap, &gbitmap = HI->gbitmap;
-    const std::vector<u64>&tkeys = HI->tkeys, &bloom = HI->bloom; const std::vector<u16>& sv = HI->sv;
-    const u64 tcap = tkeys.size(), nb = HI->nb; const u32 tmask = HI->tmask, smask = HI->smask, gbits = HI->gbits, blk_bits = HI->blk_bits;
+    const std::vector<u64>& tkeys = HI->tkeys; const std::vector<u16>& sv = HI->sv;
+    const u64 tcap = tkeys.size(), nb = HI->nb; const u32 tmask = HI->tmask, smask = HI->smask, gbits = HI->gbits;
     h->allele_locus.assign(locus_id, locus_id + n_alleles);
     h->sieve_kind = HI->kind; h->sieve_chain = HI->sieve_chain; h->n_keys = HI->n_keys;
     // ---- tables derived from the parameters
@@ -2793,8 +2655,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_loci, (u64)n_loci)); HIPCHK(h, hipMemcpy(h->d_loci, loci.data(), (u64)n_loci * sizeof(LocusDev), hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_sieve, nb)); HIPCHK(h, hipMemcpy(h->d_sieve, sv.data(), nb * 16, hipMemcpyHostToDevice));
     if (!bitmap.empty()) { HIPCHK(h, dmalloc(&h->d_bitmap, (u64)bitmap.size())); HIPCHK(h, hipMemcpy(h->d_bitmap, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice)); }
-    if (!bloom.empty()) { HIPCHK(h, dmalloc(&h->d_bloom, (u64)bloom.size())); HIPCHK(h, hipMemcpy(h->d_bloom, bloom.data(), bloom.size() * 8, hipMemcpyHostToDevice)); h->bloom_blk_bits = blk_bits; h->binned = true; }
-    if (!HI->rfilter.empty()) { HIPCHK(h, dmalloc(&h->d_rfilter, (u64)HI->rfilter.size())); HIPCHK(h, hipMemcpy(h->d_rfilter, HI->rfilter.data(), HI->rfilter.size() * 4, hipMemcpyHostToDevice)); }
+    if (!HI->rfilter.empty()) { HIPCHK(h, dmalloc(&h->d_rfilter, (u64)HI->rfilter.size() * 2)); HIPCHK(h, hipMemcpy(h->d_rfilter, HI->rfilter.data(), HI->rfilter.size() * 8, hipMemcpyHostToDevice)); }
     if (!gbitmap.empty()) { HIPCHK(h, dmalloc(&h->d_gbitmap, (u64)gbitmap.size())); HIPCHK(h, hipMemcpy(h->d_gbitmap, gbitmap.data(), gbitmap.size() * 4, hipMemcpyHostToDevice)); }
     HIPCHK(h, dmalloc(&h->d_keys, tcap)); HIPCHK(h, hipMemcpy(h->d_keys, tkeys.data(), tcap * 8, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_vals, tcap)); HIPCHK(h, hipMemcpy(h->d_vals, tvals.data(), tcap * 4, hipMemcpyHostToDevice));
@@ -2804,7 +2665,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     u64 abytes = off[n_alleles];
     HIPCHK(h, dmalloc(&h->d_ascii, abytes)); if (abytes) HIPCHK(h, hipMemcpy(h->d_ascii, ascii, abytes, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_aoff, (u64)n_alleles + 1)); HIPCHK(h, hipMemcpy(h->d_aoff, off, ((u64)n_alleles + 1) * 8, hipMemcpyHostToDevice));
-    h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4 + bloom.size() * 8 + HI->rfilter.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
+    h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4 + HI->rfilter.size() * 8; h->bytes_table = tcap * 12 + posts.size() * 4;
     h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
     {   // device-side typing: allele numbers, one slot of max_len columns per locus
         HIPCHK(h, dmalloc(&h->d_allele_no, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_no, allele_no, (u64)n_alleles * 4, hipMemcpyHostToDevice));
@@ -2893,35 +2754,18 @@ extern "C" int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, co
     return MLST_OK;
 }
 
-// arena / flag buffers of the XCD-binned sieve for a batch of n_reads (grow-only; must run outside stream capture)
-static int ensure_bin_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
-    const u64 n_groups = (n_reads + 63) >> 6;
-    u32 blocks = (u32)std::min<u64>(256 * 5, (n_groups + 3) / 4); if (blocks < 1) blocks = 1;
-    const u32 n_pw = blocks * 4;
-    const u64 per_wave = (n_groups + n_pw - 1) / n_pw;                                  // groups per producer wave
-    u64 cap = (u64)((double)(per_wave * 64 * (wpr - 1)) / BIN_OWNERS * 1.3) + 256; cap = (cap + 63) & ~63ull;
-    const u64 need = (u64)BIN_OWNERS * n_pw * cap;
-    if (h->cap_bin_arena < need || h->bin_pw != n_pw) {
-        hipStreamSynchronize(h->stream);
-        hipFree(h->d_bin_arena); hipFree(h->d_bin_counts); hipFree(h->d_bin_next); h->d_bin_arena = nullptr; h->d_bin_counts = nullptr; h->d_bin_next = nullptr;
-        HIPCHK(h, dmalloc(&h->d_bin_arena, need)); HIPCHK(h, dmalloc(&h->d_bin_counts, (u64)n_pw * BIN_OWNERS)); HIPCHK(h, dmalloc(&h->d_bin_next, (u64)BIN_OWNERS));
-        h->cap_bin_arena = need; h->bin_pw = n_pw;
-    }
-    const u64 n_flag_words = (n_reads + 31) >> 5;
-    if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words; }
-    h->bin_blocks = blocks; h->bin_cap = cap;
-    return MLST_OK;
-}
-
 // arena / list buffers of the CU-routed sieve for a batch of n_reads (grow-only; must run outside stream capture)
 static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
-    const u64 n_tiles = (n_reads + 1023) >> 10;
-    u32 prod = wpr <= 10 ? 512u : 256u;                 // two workgroups per CU while the sort buffer allows it
+    u32 nw = 16;                                        // waves per producer workgroup (tile = nw groups of 64 reads)
+    { const char* e = getenv("MLST_ROUTE_WAVES"); if (e && atoi(e) == 8) nw = 8; }
+    const u64 tile = (u64)nw * 64, n_tiles = (n_reads + tile - 1) / tile;
+    u32 prod = (wpr <= 10 ? 512u : 256u) * (16u / nw);  // as many workgroups as the LDS lets share the CUs
     { const char* e = getenv("MLST_ROUTE_BLOCKS"); if (e && atoi(e) > 0) prod = (u32)atoi(e); }
+    if (prod > RT_MAXP) prod = RT_MAXP;
     if (prod > n_tiles) prod = (u32)(n_tiles ? n_tiles : 1);
     const u64 tiles_max = (n_tiles + prod - 1) / prod;
-    // expected entries per (owner, tile): 1024 * seeds / 256 + ~2 dummies; 25 % and a constant on top
-    u64 cap = (u64)((double)tiles_max * (4.0 * (wpr - 1) + 2.0) * 1.25) + 256; cap = (cap + 3) & ~3ull;
+    // expected entries per (owner, tile): tile * seeds / 256 + dummies (~10 % of nw) + ~2 of padding; 25 % and a constant on top
+    u64 cap = (u64)((double)tiles_max * ((double)tile / 256.0 * (wpr - 1) + 0.15 * nw + 2.0) * 1.25) + 256; cap = (cap + 3) & ~3ull;
     if (cap >= (1ull << 31)) return fail(h, MLST_E_LIMIT, "batch too large for the routed sieve");
     const u64 need = (u64)RT_OWNERS * prod * cap;
     if (h->cap_rt_arena < need || h->rt_prod != prod || h->rt_cap != (u32)cap) {
@@ -2932,7 +2776,7 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     }
     const u64 need_e = (u64)prod * (tiles_max + 1);
     if (h->cap_rt_emitted < need_e) { hipStreamSynchronize(h->stream); hipFree(h->d_rt_emitted); h->d_rt_emitted = nullptr; HIPCHK(h, dmalloc(&h->d_rt_emitted, need_e)); h->cap_rt_emitted = need_e; }
-    h->rt_tiles_max = (u32)tiles_max;
+    h->rt_tiles_max = (u32)tiles_max; h->rt_nw = nw;
     const u64 n_flag_words = (n_reads + 31) >> 5;
     if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words; }
     return MLST_OK;
@@ -2951,12 +2795,11 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     (void)paired;   // mates are typed independently; they share a QNAME only for the coverage figure
     if (h->cap_cand < n_reads) { hipStreamSynchronize(h->stream); hipFree(h->d_cand); h->d_cand = nullptr; HIPCHK(h, dmalloc(&h->d_cand, n_reads)); h->cap_cand = n_reads; }
     EngineDev& E = h->E;
-    if (h->sieve_kind == MLST_SIEVE_BINNED) { int rc = ensure_bin_buffers(h, n_reads, wpr); if (rc) return rc; }
     if (h->sieve_kind == MLST_SIEVE_ROUTED) { int rc = ensure_route_buffers(h, n_reads, wpr); if (rc) return rc; }
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
-                                               (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand, (u64)(uintptr_t)h->d_bin_arena,
-                                               (u64)(uintptr_t)h->d_bin_flags, h->bin_cap, (u64)(uintptr_t)h->d_rt_arena, (u64)(uintptr_t)h->d_rt_counts,
-                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod});
+                                               (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand,
+                                               (u64)(uintptr_t)h->d_bin_flags, (u64)(uintptr_t)h->d_rt_arena, (u64)(uintptr_t)h->d_rt_counts,
+                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw});
     if (gs == 1) { h->reads_seen += n_reads; return MLST_OK; }
     { Prof pf(h, 0);
       if (h->sieve_kind == MLST_SIEVE_LDS) {      // LDS first level: one 1024-thread workgroup per CU
@@ -2969,29 +2812,22 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
         const u64 n_flag_words = (n_reads + 31) >> 5;
         HIPCHK(h, hipMemsetAsync(h->d_bin_flags, 0, n_flag_words * 4, h->stream));
         RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags;
-        R.cap = h->rt_cap; R.n_prod = h->rt_prod; R.tiles_max = h->rt_tiles_max;
+        R.cap = h->rt_cap; R.n_prod = h->rt_prod; R.tiles_max = h->rt_tiles_max; R.nw = h->rt_nw;
         { Prof pa(h, 9);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_route<W>, dim3(h->rt_prod), dim3(1024), 0, h->stream, d_packed, d_lens, (u64)n_reads, R, E.ctr); break;
+#define SIEVE_CASE(W) case W: if (h->rt_nw == 8) hipLaunchKernelGGL((k_route<W, 8>), dim3(h->rt_prod), dim3(512), 0, h->stream, d_packed, d_lens, (u64)n_reads, R, E.ctr); \
+                              else hipLaunchKernelGGL((k_route<W, 16>), dim3(h->rt_prod), dim3(1024), 0, h->stream, d_packed, d_lens, (u64)n_reads, R, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
         }
         { Prof pb(h, 10);
-          hipLaunchKernelGGL(k_route_probe, dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, d_lens, wpr, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); }
-        hipLaunchKernelGGL(k_flag_compact, dim3(grid_for(n_flag_words, 1024, 256)), dim3(1024), 0, h->stream, h->d_bin_flags, (u64)n_reads, h->d_cand, E.ctr);
-      } else if (h->sieve_kind == MLST_SIEVE_BINNED) {      // seeds routed to the XCD that owns their key range (K1b)
-        const u32 blocks = h->bin_blocks, n_pw = blocks * 4; const u64 cap = h->bin_cap, n_flag_words = (n_reads + 31) >> 5;
-        HIPCHK(h, hipMemsetAsync(h->d_bin_flags, 0, n_flag_words * 4, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_bin_next, 0, BIN_OWNERS * 4, h->stream));
-        BinDev B; B.arena = h->d_bin_arena; B.counts = h->d_bin_counts; B.next = h->d_bin_next; B.bloom = h->d_bloom; B.flags = h->d_bin_flags;
-        B.cap = cap; B.n_pw = n_pw; B.blk_bits = h->bloom_blk_bits;
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_bin<W>, dim3(blocks), dim3(256), 0, h->stream, d_packed, d_lens, (u64)n_reads, B, E.ctr); break;
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_route_probe<W>, dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
-        hipLaunchKernelGGL(k_bin_probe, dim3(2048), dim3(256), 0, h->stream, d_packed, wpr, (u64)n_reads, E.sieve, E.sieve_mask, B, E.ctr);
+        }
         hipLaunchKernelGGL(k_flag_compact, dim3(grid_for(n_flag_words, 1024, 256)), dim3(1024), 0, h->stream, h->d_bin_flags, (u64)n_reads, h->d_cand, E.ctr);
-      } else {      // big database: global first-level bitmap, 256-thread workgroups
+      } else {      // hashed first-level bitmap in global memory, 256-thread workgroups (MLST_SIEVE=global; databases without seeds)
         dim3 grid(grid_for((n_reads + 255) / 256, 1, h->sieve_g_blocks)), block(256);
 #define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, false>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.gbitmap.p, E.gbitmap_bits, h->d_cand, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)

@@ -21,7 +21,7 @@ MLST_CNT_N = 8
 CNT_TOTAL_RECORDS, CNT_IGNORED, CNT_READS_SEEN, CNT_CANDIDATES, CNT_RETAINED, CNT_ITEMS, CNT_DP_PAIRS = range(7)
 KERNELS = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup", "pack", "sieve_inkernel", "sieve_wg_longest",
            "sieve_route", "sieve_probe")
-SIEVE_KINDS = ("lds", "global", "binned", "routed")
+SIEVE_KINDS = ("lds", "global", "binned (round 1, removed)", "routed")
 
 
 class MlstParams(C.Structure):

@@ -222,17 +222,16 @@ def test_sharded_engines_reduce_to_the_single_engine_result():
     assert letters == b"".join(whole.consensus(chosen)[a] for a in chosen)
 
 
-@pytest.mark.parametrize("kind", ["global", "binned", "routed"])
-def test_big_database_sieves_on_a_small_database(monkeypatch, kind):
+@pytest.mark.parametrize("kind,waves", [("global", "16"), ("routed", "16"), ("routed", "8")])
+def test_big_database_sieves_on_a_small_database(monkeypatch, kind, waves):
     """Large databases skip the LDS first-level bitmap; force those paths on a small one (MLST_SIEVE): the single-kernel
-    sieve with the global bitmap, the XCD-binned sieve (k_bin -> k_bin_probe -> k_flag_compact; also with Bloom filters so
-    small that nearly every seed goes the exact way) and the CU-routed sieve (k_route -> k_route_probe -> k_flag_compact:
-    the one databases beyond the LDS bitmaps get by default)."""
+    sieve with the global bitmap and the CU-routed sieve (k_route -> k_route_probe -> k_flag_compact: the one databases
+    beyond the LDS bitmaps get by default; with 16- and 8-wave producer workgroups)."""
     monkeypatch.setenv("MLST_SIEVE", kind)
+    monkeypatch.setenv("MLST_ROUTE_WAVES", waves)
     db, idx = fx.ecoli_small(80)
     fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 8, n_reads=9000)
-    for bloom_bits in (("18", "10") if kind == "binned" else ("18",)):
-        monkeypatch.setenv("MLST_BLOOM_BITS", bloom_bits)
+    for _once in (0,):
         eng, orc = both(idx)
         assert eng.sieve_info()["kind"] == kind
         s, _ = run_both(eng, orc, fb, fq, off)
@@ -489,7 +488,7 @@ def test_dense_on_locus_reads_overflow_the_sieve_queue():
             r = r[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
         reads.append(r); quals.append(bytes([40 + 33]) * L)
     fb, fq, off = synth.ragged_reads(reads, quals)
-    for kind in ("lds", "global", "binned", "routed"):
+    for kind in ("lds", "global", "routed"):
         os.environ["MLST_SIEVE"] = kind
         try:
             eng, orc = both(idx)
