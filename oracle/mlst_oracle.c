@@ -574,6 +574,117 @@ int orc_pileup(const orc_ref* r, const uint8_t* bases, const uint8_t* quals, con
     return 0;
 }
 
+/* ------------------------------------------------------------------ exhaustive mode (measurement of the seeding policy)
+ *
+ * What bowtie2 -a would report if it examined EVERYTHING: for every read, every allele and both strands the best
+ * local alignment under the same scoring (match bonus, quality-aware mismatch, N, affine gaps, --gbar), found by a full
+ * (unbanded, unseeded) Gotoh recurrence over the whole read x allele matrix.  Same packed values, so XM / XO come out of
+ * the maximum.  O(read x allele) per pair: small databases only.  tests/test_seeding_deviation.py compares it with the
+ * seeded specification (orc_pass1_dense) to put a number on what seeding every 16th base / one diagonal per
+ * (locus, strand) / band 8 leaves out (bowtie2 itself [NOT IN TREE] seeds more densely: -L 20 -i S,1,0.50
+ * via /root/reference/README.md:20).
+ * out_score / out_xm / out_xo: [n_reads][n_alleles], score 0 = no alignment reaches a positive score. */
+static int32_t full_local(const orc_ref* r, const uint8_t* rb, const uint8_t* pen, int n, const uint8_t* ab, int m) {
+    const int G = r->prm.gbar;
+    const int32_t OPEN = ((int32_t)(r->prm.gap_open + r->prm.gap_ext) << MLST_P_SHIFT) + (1 << 8);
+    const int32_t EXT = (int32_t)r->prm.gap_ext << MLST_P_SHIFT;
+    int32_t* H = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1) * 2);      /* two rows: previous read base, this one */
+    int32_t* F = (int32_t*)malloc(sizeof(int32_t) * (size_t)(m + 1) * 2);
+    for (int j = 0; j <= m; j++) { H[j] = MLST_P0; F[j] = MLST_P_NEG; }
+    int32_t best = MLST_P0;
+    for (int i = 0; i < n; i++) {
+        int32_t* Hp = H + (size_t)(i & 1) * (m + 1); int32_t* Hc = H + (size_t)((i + 1) & 1) * (m + 1);
+        int32_t* Fp = F + (size_t)(i & 1) * (m + 1); int32_t* Fc = F + (size_t)((i + 1) & 1) * (m + 1);
+        const int gap_ok = (i >= G && i < n - G);
+        int32_t e = MLST_P_NEG; Hc[0] = MLST_P0; Fc[0] = MLST_P_NEG;
+        for (int j = 1; j <= m; j++) {           /* cell (read i, allele j-1) */
+            int32_t diag = Hp[j - 1] + col_delta(r, rb[i], pen[i], ab[j - 1]);
+            int32_t f = MLST_P_NEG;
+            if (gap_ok) { int32_t e1 = Hc[j - 1] - OPEN, e2 = e - EXT; e = e2 > e1 ? e2 : e1;      /* gap in the read: allele base skipped */
+                          int32_t f1 = Hp[j] - OPEN, f2 = Fp[j] - EXT; f = f2 > f1 ? f2 : f1; }     /* gap in the allele: read base skipped */
+            else e = MLST_P_NEG;
+            int32_t h = MLST_P0;
+            if (diag > h) h = diag;
+            if (e > h) h = e;
+            if (f > h) h = f;
+            Hc[j] = h; Fc[j] = f;
+            if (h > best) best = h;
+        }
+    }
+    free(H); free(F);
+    return best;
+}
+
+int orc_exhaustive(const orc_ref* r, const uint8_t* bases, const uint8_t* quals, const uint64_t* off, uint64_t n_reads,
+                   int16_t* out_score, uint8_t* out_xm, uint8_t* out_xo, int n_threads) {
+    const uint32_t nA = r->n_alleles;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    int bad = 0;
+    #pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t ri = 0; ri < (int64_t)n_reads; ri++) {
+        int n = (int)(off[ri + 1] - off[ri]);
+        if (n > MLST_MAX_READ_LEN) { bad = 1; continue; }
+        uint8_t code[MLST_MAX_READ_LEN], phred[MLST_MAX_READ_LEN], rb[MLST_MAX_READ_LEN], pen[MLST_MAX_READ_LEN], q[MLST_MAX_READ_LEN];
+        for (int i = 0; i < n; i++) {
+            code[i] = base_code(bases[off[ri] + i]);
+            int qq = (int)quals[off[ri] + i] - 33; phred[i] = (uint8_t)(qq < 0 ? 0 : (qq > 127 ? 127 : qq));
+        }
+        for (uint32_t a = 0; a < nA; a++) {
+            int32_t best = MLST_P0;
+            for (int strand = 0; strand < 2; strand++) {
+                orient_read(r, code, phred, n, strand, rb, pen, q);
+                int32_t v = n > 0 ? full_local(r, rb, pen, n, r->code[a], (int)r->len[a]) : MLST_P0;
+                if (v > best) best = v;
+            }
+            size_t o = (size_t)ri * nA + a;
+            out_score[o] = (int16_t)(best >> MLST_P_SHIFT); out_xm[o] = (uint8_t)(255 - (best & 0xFF)); out_xo[o] = (uint8_t)(127 - ((best >> 8) & 0x7F));
+        }
+    }
+    return bad ? -5 : 0;
+}
+
+/* The seeded specification (what orc_pass1 accumulates) as dense per-(read, allele) tables, for the comparison above:
+ * score 0 = the pair was never extended or did not reach a positive score.  A read with work items on both strands of
+ * one locus keeps the better record per allele (exhaustive mode reports one value per pair too). */
+int orc_pass1_dense(const orc_ref* r, const uint8_t* bases, const uint8_t* quals, const uint64_t* off, uint64_t n_reads,
+                    int16_t* out_score, uint8_t* out_xm, uint8_t* out_xo, int n_threads) {
+    const uint32_t nA = r->n_alleles;
+    memset(out_score, 0, sizeof(int16_t) * (size_t)n_reads * nA); memset(out_xm, 0, (size_t)n_reads * nA); memset(out_xo, 0, (size_t)n_reads * nA);
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    #pragma omp parallel
+    {
+        aln_t* al = (aln_t*)malloc(sizeof(aln_t));
+        #pragma omp for schedule(dynamic, 64)
+        for (int64_t ri = 0; ri < (int64_t)n_reads; ri++) {
+            int n = (int)(off[ri + 1] - off[ri]);
+            if (n > MLST_MAX_READ_LEN || n < K) continue;
+            uint8_t code[MLST_MAX_READ_LEN], phred[MLST_MAX_READ_LEN];
+            for (int i = 0; i < n; i++) {
+                code[i] = base_code(bases[off[ri] + i]);
+                int qq = (int)quals[off[ri] + i] - 33; phred[i] = (uint8_t)(qq < 0 ? 0 : (qq > 127 ? 127 : qq));
+            }
+            cand_t items[MLST_MAX_CAND];
+            int ni = seed_read(r, code, n, items);
+            for (int it = 0; it < ni; it++) {
+                uint8_t rb[MLST_MAX_READ_LEN], pen[MLST_MAX_READ_LEN], q[MLST_MAX_READ_LEN];
+                orient_read(r, code, phred, n, items[it].strand, rb, pen, q);
+                uint32_t L = items[it].locus;
+                for (uint32_t a = r->locus_begin[L]; a < r->locus_begin[L] + r->locus_count[L]; a++) {
+                    align_pair(r, rb, pen, n, a, items[it].diag, al);
+                    size_t o = (size_t)ri * nA + a;
+                    if (al->score > out_score[o]) { out_score[o] = (int16_t)al->score; out_xm[o] = (uint8_t)al->xm; out_xo[o] = (uint8_t)al->xo; }
+                }
+            }
+        }
+        free(al);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ allele match */
 
 /* stringDiff (metaMLST_functions.py:230-234): mismatches over zip(s1, s2) -- the shorter

@@ -43,6 +43,9 @@ def lib():
         _lib.orc_pileup.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_int]
         _lib.orc_align_one.restype = C.c_int
         _lib.orc_align_one.argtypes = [vp, vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+        for fn in ("orc_exhaustive", "orc_pass1_dense"):
+            getattr(_lib, fn).restype = C.c_int
+            getattr(_lib, fn).argtypes = [vp, vp, vp, vp, C.c_uint64, vp, vp, vp, C.c_int]
         _lib.orc_string_diff.restype = C.c_uint32
         _lib.orc_string_diff.argtypes = [vp, C.c_uint32, vp, C.c_uint32]
         _lib.orc_hamming_all.restype = C.c_int
@@ -99,6 +102,25 @@ class Oracle:
             arr = np.array([(x.read_index, x.locus, x.strand, x.diag, x.votes) for x in items[:k]], dtype=np.int64).reshape(-1, 5)
             return s, arr
         return s
+
+    def _dense(self, fn):
+        b, q, off = self._reads
+        n = len(off) - 1
+        sc = np.zeros((n, self.index.n_alleles), np.int16)
+        xm = np.zeros((n, self.index.n_alleles), np.uint8)
+        xo = np.zeros((n, self.index.n_alleles), np.uint8)
+        rc = getattr(lib(), fn)(self._r, _p(b), _p(q), _p(off), n, _p(sc), _p(xm), _p(xo), self.threads)
+        if rc != 0:
+            raise RuntimeError("%s rc=%d" % (fn, rc))
+        return sc, xm, xo
+
+    def exhaustive(self):
+        """(score, xm, xo)[n_reads, n_alleles]: best local alignment of every read against every allele, no seeding, no band."""
+        return self._dense("orc_exhaustive")
+
+    def pass1_dense(self):
+        """The same tables under the seeded specification (what stats() accumulates)."""
+        return self._dense("orc_pass1_dense")
 
     def accumulate_records(self, read_index, allele, AS, XM, XO, seqlen) -> SampleStats:
         nA, nL = self.index.n_alleles, self.index.n_loci
