@@ -202,39 +202,70 @@ __host__ __device__ inline u64 packed_index(u64 r, u32 wpr, u32 c) {
 __host__ __device__ inline u64 packed_words(u64 n_reads, u32 wpr) { return ((n_reads + 63) & ~63ull) * wpr; }
 
 // ------------------------------------------------------------------ K0: pack
-// One thread packs 16 bases (one 32-bit word) and their 16 Phred bytes.  lens[r] bit 15 = read has a non-ACGT base.
+// One workgroup per group of 64 reads.  Pass 1: thread = one 16-base word of one read, consecutive threads = consecutive
+// words of the same read, so a wave reads its sequence and quality bytes with 16-byte loads from contiguous memory and
+// writes contiguous quality rows; the 2-bit word goes to LDS.  Pass 2: the group's words leave LDS in the resident
+// (transposed) order as fully coalesced dword stores, and one thread per read stores its length (bit 15 = the read holds a
+// non-ACGT base).  No atomics, no scattered global stores (the first version wrote every word to its own line:
+// 0.18 TB/s).
+// seq_off / qual_off: byte offset of every read's bases / qualities inside `bases` / `quals` (the same array for ASCII
+// reads given by one offset table; FASTQ text has separate ones); len_of(r) gives the length.
+template <typename LenFn>
+__device__ inline void pack_group(const u8* __restrict__ bases, const u8* __restrict__ quals, const u64* __restrict__ seq_off,
+                                  const u64* __restrict__ qual_off, LenFn len_of, u64 n_reads, u64 grp,
+                                  u32* __restrict__ packed, u8* __restrict__ qrows, u16* __restrict__ lens, u32 wpr, u32 qstride,
+                                  u32* s_words /* 64 * wpr */, u32* s_anyn /* 2 */) {
+    const int tid = threadIdx.x;
+    if (tid < 2) s_anyn[tid] = 0;
+    __syncthreads();
+    const u32 total = 64u * wpr;
+    for (u32 idx = (u32)tid; idx < total; idx += blockDim.x) {
+        const u32 i = idx / wpr, w = idx - i * wpr; const u64 r = grp * 64 + i;
+        u32 word = 0;
+        if (r < n_reads) {
+            const u64 so = seq_off[r], qo = qual_off[r]; const u32 n = len_of(r);
+            u8 cs[16], cq[16];
+            if (w * 16 + 16 <= n) {      // whole word inside the read: two 16-byte copies (the compiler picks the widest loads the target allows unaligned)
+                __builtin_memcpy(cs, bases + so + w * 16, 16); __builtin_memcpy(cq, quals + qo + w * 16, 16);
+            } else {
+                #pragma unroll
+                for (int k = 0; k < 16; k++) { const u32 p = w * 16 + k; const bool in = p < n; cs[k] = in ? bases[so + p] : (u8)'A'; cq[k] = in ? quals[qo + p] : (u8)33; }
+            }
+            u32 anyn = 0, qw[4] = {0, 0, 0, 0};
+            #pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u32 p = w * 16 + k;
+                if (p < n) {
+                    const u8 c = cs[k] & 0xDF;               // upper case
+                    u32 b, isn = 0;
+                    if (c == 'A') b = 0; else if (c == 'C') b = 1; else if (c == 'G') b = 2; else if (c == 'T') b = 3; else { b = 0; isn = 1; }
+                    word |= b << (2 * k);
+                    int q = (int)cq[k] - 33; q = q < 0 ? 0 : (q > 127 ? 127 : q);
+                    qw[k >> 2] |= ((u32)q | (isn << 7)) << (8 * (k & 3));
+                    anyn |= isn;
+                }
+            }
+            #pragma unroll
+            for (int j = 0; j < 4; j++) if (w * 16 + 4 * j < qstride) reinterpret_cast<u32*>(qrows + r * qstride)[w * 4 + j] = qw[j];     // qstride is a multiple of 4
+            if (anyn) atomicOr(&s_anyn[i >> 5], 1u << (i & 31));      // LDS
+        }
+        s_words[i * wpr + w] = word;
+    }
+    __syncthreads();
+    // resident order: word o of the group = unit o >> 7, read (o >> 1) & 63, half o & 1
+    u32* out = packed + grp * total;
+    for (u32 o = (u32)tid; o < total; o += blockDim.x) out[o] = s_words[((o >> 1) & 63u) * wpr + ((o >> 7) << 1) + (o & 1u)];
+    if (tid < 64) { const u64 r = grp * 64 + tid; if (r < n_reads) lens[r] = (u16)(len_of(r) | (((s_anyn[tid >> 5] >> (tid & 31)) & 1u) << 15)); }
+}
 __global__ __launch_bounds__(256) void k_pack(const u8* __restrict__ bases, const u8* __restrict__ quals,
                                                const u64* __restrict__ off, u64 n_reads, u32* __restrict__ packed,
                                                u8* __restrict__ qrows, u16* __restrict__ lens, u32 wpr, u32 qstride) {
-    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 total = packed_words(n_reads, wpr);      // one thread per output word, in output order (coalesced stores)
-    for (; gid < total; gid += (u64)gridDim.x * blockDim.x) {
-        u64 grp = gid / (64ull * wpr); u32 in = (u32)(gid - grp * 64ull * wpr);
-        u64 r = grp * 64 + ((in >> 1) & 63); u32 w = ((in >> 7) << 1) | (in & 1);
-        if (r >= n_reads) { packed[gid] = 0; continue; }         // padding rows of the last group
-        u64 o = off[r]; u32 n = (u32)(off[r + 1] - o);
-        u32 word = 0; u32 anyn = 0;
-        for (int k = 0; k < 16; k++) {
-            u32 i = w * 16 + k;
-            if (i < n) {
-                u8 c = bases[o + i]; u32 b; u32 isn = 0;
-                switch (c) { case 'A': case 'a': b = 0; break; case 'C': case 'c': b = 1; break;
-                             case 'G': case 'g': b = 2; break; case 'T': case 't': b = 3; break; default: b = 0; isn = 1; }
-                word |= b << (2 * k);
-                int q = (int)quals[o + i] - 33; q = q < 0 ? 0 : (q > 127 ? 127 : q);
-                if (i < qstride) qrows[r * qstride + i] = (u8)q | (u8)(isn << 7);
-                anyn |= isn;
-            } else if (i < qstride) qrows[r * qstride + i] = 0;
-        }
-        packed[gid] = word;
-        // lens[r] was stored by k_pack_lens (earlier launch on the same stream); OR in the "has N" flag
-        if (anyn) atomicOr((u32*)(lens + (r & ~1ull)), (r & 1) ? 0x80000000u : 0x00008000u);
+    __shared__ u32 s_words[64 * RW]; __shared__ u32 s_anyn[2];
+    const u64 n_groups = (n_reads + 63) >> 6;
+    for (u64 grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        pack_group(bases, quals, off, off, [&](u64 r) { return (u32)(off[r + 1] - off[r]); }, n_reads, grp, packed, qrows, lens, wpr, qstride, s_words, s_anyn);
+        __syncthreads();
     }
-}
-// first pass of the pack: plain lengths (d_lens must hold n_reads rounded up to an even count)
-__global__ __launch_bounds__(256) void k_pack_lens(const u64* __restrict__ off, u64 n_reads, u16* __restrict__ lens) {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; r < n_reads; r += (u64)gridDim.x * blockDim.x) lens[r] = (u16)(off[r + 1] - off[r]);
 }
 
 // ------------------------------------------------------------------ K1: seed sieve (the streaming kernel)
@@ -1018,41 +1049,17 @@ __global__ __launch_bounds__(256) void k_fq_records(const u8* __restrict__ text,
     if (mx) atomicMax(&flags[0], mx);
     if (err) atomicOr(&flags[1], err);
 }
-// pack from text: same output format as k_pack, reads addressed by separate sequence / quality offsets
+// pack from text: same output format as k_pack, reads addressed by separate sequence / quality offsets; lens holds the
+// plain lengths on entry (k_fq_records)
 __global__ __launch_bounds__(256) void k_pack_text(const u8* __restrict__ text, const u64* __restrict__ seq_off, const u64* __restrict__ qual_off,
                                                     u16* __restrict__ lens, u64 n_reads, u32* __restrict__ packed, u8* __restrict__ qrows, u32 wpr, u32 qstride) {
-    // thread = one 16-base word of one read, consecutive threads = consecutive words of the same read: a wave reads its
-    // sequence and quality bytes from contiguous text and writes contiguous quality rows (four bytes at a time)
-    const u64 total = packed_words(n_reads, wpr);       // rows padded to a multiple of 64 reads
-    for (u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (u64)gridDim.x * blockDim.x) {
-        const u64 r = gid / wpr; const u32 w = (u32)(gid - r * wpr);
-        if (r >= n_reads) { packed[packed_index(r, wpr, w)] = 0; continue; }
-        const u64 so = seq_off[r], qo = qual_off[r]; const u32 n = lens[r] & 0x7FFFu;
-        u8 cs[16], cq[16];
-        if (w * 16 + 16 <= n) {      // whole word inside the read: two 16-byte copies (the compiler picks the widest loads the target allows unaligned)
-            __builtin_memcpy(cs, text + so + w * 16, 16); __builtin_memcpy(cq, text + qo + w * 16, 16);
-        } else {
-            #pragma unroll
-            for (int k = 0; k < 16; k++) { const u32 i = w * 16 + k; const bool in = i < n; cs[k] = in ? text[so + i] : (u8)'A'; cq[k] = in ? text[qo + i] : (u8)33; }
-        }
-        u32 word = 0, anyn = 0, qw[4] = {0, 0, 0, 0};
-        #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u32 i = w * 16 + k;
-            if (i < n) {
-                const u8 c = cs[k] & 0xDF;               // upper case
-                u32 b, isn = 0;
-                if (c == 'A') b = 0; else if (c == 'C') b = 1; else if (c == 'G') b = 2; else if (c == 'T') b = 3; else { b = 0; isn = 1; }
-                word |= b << (2 * k);
-                int q = (int)cq[k] - 33; q = q < 0 ? 0 : (q > 127 ? 127 : q);
-                qw[k >> 2] |= ((u32)q | (isn << 7)) << (8 * (k & 3));
-                anyn |= isn;
-            }
-        }
-        packed[packed_index(r, wpr, w)] = word;
-        #pragma unroll
-        for (int j = 0; j < 4; j++) if (w * 16 + 4 * j < qstride) reinterpret_cast<u32*>(qrows + r * qstride)[w * 4 + j] = qw[j];     // qstride is a multiple of 4
-        if (anyn) atomicOr((u32*)(lens + (r & ~1ull)), (r & 1) ? 0x80000000u : 0x00008000u);
+    __shared__ u32 s_words[64 * RW]; __shared__ u32 s_anyn[2]; __shared__ u16 s_len[64];
+    const u64 n_groups = (n_reads + 63) >> 6;
+    for (u64 grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        if (threadIdx.x < 64) { const u64 r = grp * 64 + threadIdx.x; s_len[threadIdx.x] = r < n_reads ? (u16)(lens[r] & 0x7FFFu) : (u16)0; }
+        __syncthreads();
+        pack_group(text, text, seq_off, qual_off, [&](u64 r) { return (u32)s_len[r & 63]; }, n_reads, grp, packed, qrows, lens, wpr, qstride, s_words, s_anyn);
+        __syncthreads();
     }
 }
 
@@ -2192,7 +2199,8 @@ struct mlst_handle {
     u64 reads_seen = 0;
     int ext_threads = 256, ext_blocks = 1024;    // k_extend launch shape (set in mlst_load_reference)
     int sieve_g_blocks = 256 * 5;                // k_sieve_q<.,false> grid (MLST_SIEVE_BLOCKS overrides it)
-    u8* d_fq_text = nullptr; u64 cap_fq_text = 0; u32* d_fq_blk = nullptr; u64 cap_fq_blk = 0;
+    u8* d_fq_text = nullptr;                    // the text buffer of the chunk being parsed: one of d_fq_slot[] (not owned)
+    u32* d_fq_blk = nullptr; u64 cap_fq_blk = 0;
     // BGZF input: compressed bytes + block descriptors on the device; the partial record at the end of a chunk (carry)
     u8* d_bgzf = nullptr; u64 cap_bgzf = 0; void* d_bgzf_blk = nullptr; u64 cap_bgzf_blk = 0; u8* d_fq_carry = nullptr; u64 cap_fq_carry = 0, fq_carry_len = 0;
     u64* d_fq_lines = nullptr; u64 cap_fq_lines = 0; u64* d_fq_soff = nullptr; u64* d_fq_qoff = nullptr; u64 cap_fq_reads = 0; u64* d_fq_meta = nullptr;
@@ -2202,6 +2210,10 @@ struct mlst_handle {
     // device-side typing (mlst_typing_enqueue / mlst_typing_fetch): fixed column layout, one slot of loc_maxlen columns per locus
     int* d_allele_no = nullptr; int* d_auto_chosen = nullptr; u64* d_fixed_colbase = nullptr; std::vector<u64> fixed_colbase; u64 fixed_cols = 0;
     u32* d_auto_counts = nullptr; u8* d_auto_letters = nullptr; u8* h_auto = nullptr; bool auto_pending = false;
+    // host-to-device copies of the FASTQ entries: a copy stream, two text buffers used in turn, the event that says a
+    // buffer's last chunk has been packed (h2d_overlapped)
+    hipStream_t copy_stream = nullptr; hipEvent_t stage_done = nullptr;
+    u8* d_fq_slot[2] = {nullptr, nullptr}; u64 cap_fq_slot[2] = {0, 0}; hipEvent_t ev_packed[2] = {nullptr, nullptr}; int fq_slot = 0;
     hipStream_t own_stream = nullptr;           // the stream created by mlst_create (h->stream may be a caller's stream: mlst_set_stream)
     u32* d_dist = nullptr; u8* d_query = nullptr; u64 cap_dist = 0, cap_query = 0;
     // one contiguous device block [sum_score | locus_len | Counters | n_hits | pad][locus_first] with a pinned mirror
@@ -2352,8 +2364,11 @@ extern "C" void mlst_destroy(mlst_handle* h) {
     for (auto& e : h->ev_pool) hipEventDestroy(e);
     free_ref(h); free_state(h);
     if (h->h_pin) hipHostFree(h->h_pin);
+    for (int k = 0; k < 2; k++) { if (h->ev_packed[k]) hipEventDestroy(h->ev_packed[k]); }
+    if (h->stage_done) hipEventDestroy(h->stage_done);
+    if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     hipFree(h->d_cand); hipFree(h->d_in_bases); hipFree(h->d_in_quals); hipFree(h->d_in_off);
-    hipFree(h->d_fq_text); hipFree(h->d_fq_blk); hipFree(h->d_fq_lines); hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); hipFree(h->d_fq_meta);
+    hipFree(h->d_fq_slot[0]); hipFree(h->d_fq_slot[1]); hipFree(h->d_fq_blk); hipFree(h->d_fq_lines); hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); hipFree(h->d_fq_meta);
     hipFree(h->d_bgzf); hipFree(h->d_bgzf_blk); hipFree(h->d_fq_carry); h->d_bgzf = nullptr; h->d_bgzf_blk = nullptr; h->d_fq_carry = nullptr; h->cap_bgzf = h->cap_bgzf_blk = h->cap_fq_carry = h->fq_carry_len = 0;
     hipFree(h->d_packed); hipFree(h->d_qrows); hipFree(h->d_lens); hipFree(h->d_counts); hipFree(h->d_dist); hipFree(h->d_query);
     for (auto* g : {&h->g_submit, &h->g_typing}) if (g->exec) hipGraphExecDestroy(g->exec);
@@ -2747,8 +2762,7 @@ extern "C" int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, co
     if (qstride < 1 || qstride > RQ) return fail(h, MLST_E_INVALID, "qual_stride must be in 1..%d", RQ);
     if (n_reads == 0) return MLST_OK;
     Prof pf(h, 6);
-    hipLaunchKernelGGL(k_pack_lens, dim3(grid_for(n_reads, 256)), dim3(256), 0, h->stream, (const u64*)d_off, (u64)n_reads, d_lens);
-    hipLaunchKernelGGL(k_pack, dim3(grid_for(packed_words(n_reads, wpr), 256, 8192)), dim3(256), 0, h->stream, d_bases, d_quals, (const u64*)d_off, (u64)n_reads,
+    hipLaunchKernelGGL(k_pack, dim3(grid_for((n_reads + 63) / 64, 1, 8192)), dim3(256), 0, h->stream, d_bases, d_quals, (const u64*)d_off, (u64)n_reads,
                        d_packed, d_qrows, d_lens, wpr, qstride);
     HIPCHK(h, hipGetLastError());
     return MLST_OK;
@@ -2862,6 +2876,24 @@ static int ensure_pack_buffers(mlst_handle* h, u64 n_reads, u32 wpr, u32 qstride
     return MLST_OK;
 }
 
+// Host -> device copy on the engine's copy stream, ordered in front of whatever the engine's stream does next.  The runtime
+// moves a caller's pageable buffer at the speed of the link already (56 GB/s against 57 GB/s from pinned memory on the
+// MI355X box, profiles/h2d_rate.py; a ring of pinned slices filled by worker threads was measured and is slower), so what
+// is left to gain is overlap: the copy runs on its own stream while the engine's stream still works on the chunk before
+// (the FASTQ entries alternate between two device text buffers).  `before` (optional) is an event the copy has to wait
+// for: the last reader of the destination buffer.  The source has been read completely when the call returns.
+static int h2d_overlapped(mlst_handle* h, void* d_dst, const void* src, u64 n, hipEvent_t before) {
+    if (n == 0) return MLST_OK;
+    if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!h->stage_done) HIPCHK(h, hipEventCreateWithFlags(&h->stage_done, hipEventDisableTiming));
+    if (before) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, before, 0));
+    HIPCHK(h, hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->stage_done, h->copy_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_done, 0));
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));      // the caller owns src again on return
+    return MLST_OK;
+}
+
 extern "C" int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals, const uint64_t* d_off,
                                         uint64_t n_reads, uint32_t max_len, int paired) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
@@ -2897,6 +2929,19 @@ extern "C" int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uin
     return mlst_submit_reads_device(h, h->d_in_bases, h->d_in_quals, (const uint64_t*)h->d_in_off, n_reads, max_len, paired);
 }
 
+// The next text buffer (the two are used in turn), grown to `bytes`; h->d_fq_text points at it.  The chunk that used it
+// last has been packed when ev_packed[slot] fires.
+static int next_text_slot(mlst_handle* h, u64 bytes) {
+    const int slot = h->fq_slot ^= 1;
+    if (!h->ev_packed[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_packed[slot], hipEventDisableTiming));
+    if (h->cap_fq_slot[slot] < bytes) {
+        HIPCHK(h, hipEventSynchronize(h->ev_packed[slot]));      // (an event never recorded counts as complete)
+        hipFree(h->d_fq_slot[slot]); h->d_fq_slot[slot] = nullptr; HIPCHK(h, dmalloc(&h->d_fq_slot[slot], bytes + 16)); h->cap_fq_slot[slot] = bytes;
+    }
+    h->d_fq_text = h->d_fq_slot[slot];
+    return MLST_OK;
+}
+
 // FASTQ text in h->d_fq_text[0 .. n_bytes) -> packed reads -> pass 1.  whole: the text consists of whole records; else
 // the partial record at its end is kept (h->d_fq_carry) for the next chunk.
 static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, uint64_t* n_reads_out) {
@@ -2928,7 +2973,7 @@ static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, u
         }
         n_bytes = end_off; n_lines = 4 * n_reads;
     }
-    if (n_reads == 0) return MLST_OK;
+    if (n_reads == 0) { HIPCHK(h, hipEventRecord(h->ev_packed[h->fq_slot], h->stream)); return MLST_OK; }
     if (h->cap_fq_reads < n_reads) { hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); h->d_fq_soff = h->d_fq_qoff = nullptr;
                                      HIPCHK(h, dmalloc(&h->d_fq_soff, n_reads)); HIPCHK(h, dmalloc(&h->d_fq_qoff, n_reads)); h->cap_fq_reads = n_reads; }
     // lengths are needed before the packed buffers can be sized: worst-case row width first, then the real one
@@ -2952,9 +2997,10 @@ static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, u
             HIPCHK(h, hipMemcpy(h->d_lens, keep.data(), n_reads * 2, hipMemcpyHostToDevice));
         }
     }
-    hipLaunchKernelGGL(k_pack_text, dim3(grid_for(packed_words(n_reads, wpr), 256, 8192)), dim3(256), 0, h->stream, h->d_fq_text, h->d_fq_soff, h->d_fq_qoff,
+    hipLaunchKernelGGL(k_pack_text, dim3(grid_for((n_reads + 63) / 64, 1, 8192)), dim3(256), 0, h->stream, h->d_fq_text, h->d_fq_soff, h->d_fq_qoff,
                        h->d_lens, n_reads, h->d_packed, h->d_qrows, wpr, qstride);
     HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_packed[h->fq_slot], h->stream));      // the text buffer may be overwritten from here on
     if (n_reads_out) *n_reads_out = n_reads;
     return mlst_submit_packed_device(h, h->d_packed, h->d_qrows, h->d_lens, n_reads, wpr, qstride, paired);
 }
@@ -2967,10 +3013,10 @@ extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n
     if (n_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
     if (h->fq_carry_len) return fail(h, MLST_E_INVALID, "a BGZF stream is open (its last chunk was not marked final)");
     hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);     // the previous chunk may still be read
-    if (h->cap_fq_text < n_bytes) { hipFree(h->d_fq_text); h->d_fq_text = nullptr; HIPCHK(h, dmalloc(&h->d_fq_text, n_bytes + 16)); h->cap_fq_text = n_bytes; }
+    // no wait for the chunk before: its text sits in the other buffer, and this buffer's last reader is named by an event
+    { int rc = next_text_slot(h, n_bytes); if (rc) return rc; }
     if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
-    HIPCHK(h, hipMemcpyAsync(h->d_fq_text, text, n_bytes, hipMemcpyHostToDevice, h->stream));
+    { int rc = h2d_overlapped(h, h->d_fq_text, text, n_bytes, h->ev_packed[h->fq_slot]); if (rc) return rc; }
     return fastq_pipeline(h, n_bytes, paired, true, n_reads_out);
 }
 
@@ -3018,8 +3064,7 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
     if (text_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
     if (n_consumed_out) *n_consumed_out = n_bytes;
     if (text_bytes == 0) return MLST_OK;
-    hipStreamSynchronize(h->stream);     // the previous chunk may still be read
-    if (h->cap_fq_text < text_bytes) { hipFree(h->d_fq_text); h->d_fq_text = nullptr; HIPCHK(h, dmalloc(&h->d_fq_text, text_bytes + 16)); h->cap_fq_text = text_bytes; }
+    { int rc = next_text_slot(h, text_bytes); if (rc) return rc; }      // (the inflate kernel writes it on the engine's stream: ordered behind its last reader)
     if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
     if (h->fq_carry_len) HIPCHK(h, hipMemcpyAsync(h->d_fq_text, h->d_fq_carry, h->fq_carry_len, hipMemcpyDeviceToDevice, h->stream));
     if (!blks.empty()) {
