@@ -562,8 +562,8 @@ __device__ inline bool bin_exact(u32 w0, u32 w1, const uint4* __restrict__ sieve
 //                  lines (the open lines of an XCD's workgroups are ~2 MiB).  A 4-byte entry = first-of-(owner, wave)
 //                  flag | lane | 25 hash bits; the read index is implied by the position in the region: the
 //                  consumer counts the flags (every (owner, wave) pair of a tile contributes at least a dummy entry).
-//   k_route_probe  one workgroup per owner holds the owner's 128 KiB filter slice in LDS (four bits of one 64-bit block per
-//                  key: ~1 % of foreign seeds pass), streams the owner's regions 16 bytes per lane, and sends the
+//   k_route_probe  one workgroup per owner holds the owner's 128 KiB filter slice in LDS (four bits in each of two 32-bit
+//                  words per key: ~0.3 % of foreign seeds pass, hash collisions included), streams the owner's regions 16 bytes per lane, and sends the
 //                  entries that pass the exact way: the read's seeds are re-hashed, the one(s) equal to the entry's hash
 //                  probe the fingerprint sieve, a hit sets the read's candidate flag.
 //   k_flag_compact candidate flags -> candidate list.
@@ -592,10 +592,16 @@ __host__ __device__ inline void rt_hash(u32 lo, u32 hi, u32& owner, u32& h25) {
     h25 = ((a & 0xFFFFFFu) << 1) | rt_parity(lo ^ (lo >> 13) ^ (hi * 0x2Du));      // one more bit, taken from the key itself
     if (h25 == RT_DUMMY) h25 = RT_DUMMY - 1u;
 }
-__host__ __device__ inline void rt_filter_addr(u32 h25, u32& block, u64& mask) {       // 2^14 blocks of 64 bits = 128 KiB, four bits per key
-    block = h25 >> 11;
-    const u32 m = h25 * 0x9E3779B1u;               // positions from a product of the whole hash (its top bits are the well mixed ones)
-    mask = (1ull << (m >> 26)) | (1ull << ((m >> 20) & 63u)) | (1ull << ((m >> 14) & 63u)) | (1ull << ((m >> 8) & 63u));
+// Filter slice = 2^15 words of 32 bits (128 KiB).  A key sets three bits in each of TWO words (~0.02 % of foreign seeds pass
+// both; one 64-bit block of four bits passed 0.45 %, and every entry that passes costs the consumer ~0.8 KB of row and
+// bucket traffic -- more than the 4-byte entry stream itself at that rate).  32-bit words and one multiply: the consumer
+// is bound by instruction issue (PMC: 531 M VALU wave-instructions with 64-bit masks and two multiplies per entry).
+__host__ __device__ inline void rt_filter_addr(u32 h25, u32& word0, u32& mask0, u32& word1, u32& mask1) {
+    const u32 m = h25 * 0x9E3779B1u;               // top bits of a product are the well mixed ones
+    word0 = h25 >> 10;
+    mask0 = (1u << (m >> 27)) | (1u << ((m >> 22) & 31u)) | (1u << ((m >> 17) & 31u));
+    word1 = ((m >> 9) ^ h25) & 0x7FFFu;
+    mask1 = (1u << ((m >> 12) & 31u)) | (1u << ((m >> 7) & 31u)) | (1u << ((m >> 2) & 31u));
 }
 struct RouteDev {
     GP<u32> arena;                   // [owner][producer][cap] entries
@@ -837,7 +843,7 @@ __device__ inline void rt_examine(const u64* q, u32 cnt, int lane, u32 owner, co
 template <int WPR>
 __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
                                                       const uint4* __restrict__ sieve, u32 smask, const RouteDev R, Counters* __restrict__ ctr) {
-    __shared__ __attribute__((aligned(16))) u64 s_f[RT_FWORDS / 2];
+    __shared__ __attribute__((aligned(16))) u32 s_f[RT_FWORDS];
     __shared__ u64 s_q[16][128];                  // per-wave queue of entries that passed the filter: read | hash << 32
     constexpr int PF = 4;                         // 16-byte loads per lane in flight: 4 KiB per wave, 64 KiB per CU
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -897,12 +903,21 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
                     B[j] = __ballot(fg[j]);
                     before += (u32)__popcll(B[j] & lt);
                 }
+                // the filter words of the four entries in one batch of independent LDS reads (an entry without a seed reads word 0
+                // and fails on its own flag)
+                u32 f0[4], f1[4], k0[4], k1[4]; bool sd[4];
+                #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    sd[j] = lv[j] && (ev[u][j] & RT_HMASK) != RT_DUMMY;
+                    u32 b0, b1; rt_filter_addr(ev[u][j] & RT_HMASK, b0, k0[j], b1, k1[j]);
+                    f0[j] = s_f[sd[j] ? b0 : 0u]; f1[j] = s_f[sd[j] ? b1 : 0u];
+                }
+                tie_all<4>(f0); tie_all<4>(f1);
                 int run = seq + (int)before;
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     run += fg[j] ? 1 : 0;
-                    bool pass = false;
-                    if (lv[j] && (ev[u][j] & RT_HMASK) != RT_DUMMY) { u32 bk; u64 mk; rt_filter_addr(ev[u][j] & RT_HMASK, bk, mk); pass = (s_f[bk] & mk) == mk; }
+                    bool pass = sd[j] && (((f0[j] & k0[j]) ^ k0[j]) | ((f1[j] & k1[j]) ^ k1[j])) == 0u;
                     u64 rr = 0;
                     if (pass) {
                         const u32 jt = NWP == 16 ? (u32)run >> 4 : (u32)run >> 3, wv = (u32)run & (NWP - 1u);
@@ -2396,7 +2411,7 @@ struct HostIndex {
     std::vector<u16> sv; u64 nb = 0; u32 smask = 0, sieve_chain = 0;      // fingerprint sieve; longest overflow walk of any key
     std::vector<u32> bitmap; double bitmap_fill = 0.0;                   // LDS half-seed bitmaps (small databases)
     std::vector<u32> gbitmap; u32 gbits = 0;                             // hashed global bitmap (MLST_SIEVE=global)
-    std::vector<u64> rfilter;                                            // CU-routed filter slices (big databases)
+    std::vector<u32> rfilter;                                            // CU-routed filter slices (big databases)
     u64 n_keys = 0; u32 n_loci = 0; int kind = 0;                        // kind: MLST_SIEVE_* below
     std::string err; int err_code = 0;
 };
@@ -2596,10 +2611,10 @@ static std::shared_ptr<HostIndex> build_host_index(const uint8_t* ascii, const u
         }
     }
     if (kind == MLST_SIEVE_ROUTED) {
-        H->rfilter.assign((u64)RT_OWNERS * (RT_FWORDS / 2), 0ull);
+        H->rfilter.assign((u64)RT_OWNERS * RT_FWORDS, 0u);
         for (u64 i = 0; i < nk; i++) {
-            u32 ow, hh, bk; u64 mk; rt_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32), ow, hh); rt_filter_addr(hh, bk, mk);
-            H->rfilter[(u64)ow * (RT_FWORDS / 2) + bk] |= mk;
+            u32 ow, hh, b0, b1, k0, k1; rt_hash((u32)ukeys[i], (u32)(ukeys[i] >> 32), ow, hh); rt_filter_addr(hh, b0, k0, b1, k1);
+            H->rfilter[(u64)ow * RT_FWORDS + b0] |= k0; H->rfilter[(u64)ow * RT_FWORDS + b1] |= k1;
         }
     }
     H->kind = kind;
@@ -2670,7 +2685,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_loci, (u64)n_loci)); HIPCHK(h, hipMemcpy(h->d_loci, loci.data(), (u64)n_loci * sizeof(LocusDev), hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_sieve, nb)); HIPCHK(h, hipMemcpy(h->d_sieve, sv.data(), nb * 16, hipMemcpyHostToDevice));
     if (!bitmap.empty()) { HIPCHK(h, dmalloc(&h->d_bitmap, (u64)bitmap.size())); HIPCHK(h, hipMemcpy(h->d_bitmap, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice)); }
-    if (!HI->rfilter.empty()) { HIPCHK(h, dmalloc(&h->d_rfilter, (u64)HI->rfilter.size() * 2)); HIPCHK(h, hipMemcpy(h->d_rfilter, HI->rfilter.data(), HI->rfilter.size() * 8, hipMemcpyHostToDevice)); }
+    if (!HI->rfilter.empty()) { HIPCHK(h, dmalloc(&h->d_rfilter, (u64)HI->rfilter.size())); HIPCHK(h, hipMemcpy(h->d_rfilter, HI->rfilter.data(), HI->rfilter.size() * 4, hipMemcpyHostToDevice)); }
     if (!gbitmap.empty()) { HIPCHK(h, dmalloc(&h->d_gbitmap, (u64)gbitmap.size())); HIPCHK(h, hipMemcpy(h->d_gbitmap, gbitmap.data(), gbitmap.size() * 4, hipMemcpyHostToDevice)); }
     HIPCHK(h, dmalloc(&h->d_keys, tcap)); HIPCHK(h, hipMemcpy(h->d_keys, tkeys.data(), tcap * 8, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_vals, tcap)); HIPCHK(h, hipMemcpy(h->d_vals, tvals.data(), tcap * 4, hipMemcpyHostToDevice));
@@ -2680,7 +2695,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     u64 abytes = off[n_alleles];
     HIPCHK(h, dmalloc(&h->d_ascii, abytes)); if (abytes) HIPCHK(h, hipMemcpy(h->d_ascii, ascii, abytes, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_aoff, (u64)n_alleles + 1)); HIPCHK(h, hipMemcpy(h->d_aoff, off, ((u64)n_alleles + 1) * 8, hipMemcpyHostToDevice));
-    h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4 + HI->rfilter.size() * 8; h->bytes_table = tcap * 12 + posts.size() * 4;
+    h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4 + HI->rfilter.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
     h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
     {   // device-side typing: allele numbers, one slot of max_len columns per locus
         HIPCHK(h, dmalloc(&h->d_allele_no, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_no, allele_no, (u64)n_alleles * 4, hipMemcpyHostToDevice));
