@@ -2737,8 +2737,12 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_tb, (u64)64 * 64 * MLST_MAX_READ_LEN * (2 * MAX_W + 1)));
     HIPCHK(h, dmalloc(&h->d_E, (u64)1)); HIPCHK(h, hipMemcpy(h->d_E, &h->E, sizeof(EngineDev), hipMemcpyHostToDevice));
     {   // k_extend launch shape: threads per work item from the largest locus (MLST_EXT_THREADS / MLST_EXT_BLOCKS override it)
+        // lanes = alleles.  Up to 512 alleles per locus: one pass, the workgroup is the locus size rounded up to whole waves
+        // (300 alleles -> 320 threads; 256 threads took two passes with 41 % of the lanes idle: cfg3 0.78 -> 0.56 ms).  Larger
+        // loci: 256 threads and as many passes as it takes (a one-wave workgroup leaves as few lanes idle, but with few items --
+        // 9 k in cfg2 -- the 23 serial passes of an item become the tail of the kernel: 0.18 -> 0.31 ms).
         u32 mx = 0; for (auto& L : loci) mx = std::max(mx, L.n_alleles);
-        int thr = mx <= 64 ? 64 : (mx <= 128 ? 128 : (mx <= 192 ? 192 : 256));
+        int thr = mx <= 512 ? (int)((mx + 63) & ~63u) : 256; if (thr < 64) thr = 64;
         const char* e1 = getenv("MLST_EXT_THREADS"); if (e1 && atoi(e1) >= 64 && atoi(e1) <= 1024 && atoi(e1) % 64 == 0) thr = atoi(e1);
         int blocks = 1792 * 256 / thr;     // 7 waves per SIMD (k_extend_160 is held to 72 VGPRs); the work queue balances the rest
         const char* e2 = getenv("MLST_EXT_BLOCKS"); if (e2 && atoi(e2) > 0) blocks = atoi(e2);
