@@ -169,6 +169,7 @@ struct EngineDev {
     GP<long long> sum_score; GP<u32> n_hits; GP<u64> locus_len; GP<u64> locus_first;
     GP<Counters> ctr;
     GP<u32> ret_bases; GP<u8> ret_quals; GP<u16> ret_len; GP<u64> ret_ridx; GP<u32> ret_nrec;
+    GP<u32> ret_mate; GP<u32> ret_item0; GP<u8> ret_nitems;      // Q3: slot of the mate (or ~0), first work item and number of items of the read
     GP<ItemDev> items; GP<u8> item_state; GP<u32> res; GP<u64> dp_list;
     u64 cap_ret, cap_items, cap_res, cap_dp;
 };
@@ -341,9 +342,12 @@ __device__ inline void sv_check(const SvProbe& P, const uint4* __restrict__ siev
     if (hit) atomicOr(&hitw[P.src >> 5], 1u << (P.src & 31));
 }
 // append the reads of one tile whose bit is set in the wave's hit mask to the candidate list; clears the mask
-__device__ inline void sv_emit(u32* hitw, u32* __restrict__ cand, Counters* __restrict__ ctr, u64 r, int lane) {
+// paired: mates (reads 2k, 2k+1: neighbouring lanes) become candidates together, so that they sit side by side in the list and
+// k_seed can link them (Q3: sequenceBank is keyed by QNAME, metamlst.py:127); a superfluous candidate costs one exact lookup
+__device__ inline void sv_emit(u32* hitw, u32* __restrict__ cand, Counters* __restrict__ ctr, u64 r, int lane, int paired) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     u64 mask = uniform_u64((u64)hitw[0] | ((u64)hitw[1] << 32));
+    if (paired) mask |= ((mask & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((mask & 0x5555555555555555ull) << 1);
     if (mask) {
         if (lane < 2) hitw[lane] = 0;
         u64 base = 0;
@@ -359,7 +363,7 @@ __device__ inline void sv_emit(u32* hitw, u32* __restrict__ cand, Counters* __re
 template <int WPR, bool LDSBM>
 __global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
                                                                const uint4* __restrict__ sieve, u32 smask, const u32* __restrict__ bitmap,
-                                                               u32 gbm_bits, u32* __restrict__ cand, Counters* __restrict__ ctr) {
+                                                               u32 gbm_bits, u32* __restrict__ cand, Counters* __restrict__ ctr, int paired) {
     constexpr int NW = LDSBM ? 16 : 4;                 // waves per workgroup; a tile = NW groups of 64 reads
     constexpr int NP = LDSBM ? 2 : 3;                  // bucket requests kept in flight across the first level
     constexpr u32 TILE = NW * 64;
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __res
         // ---- examine the buckets requested above; candidates of the previous tile
         #pragma unroll
         for (int j = 0; j < NP; j++) if (j == 0 || qcnt > 64u * j) sv_check(PR[j], sieve, smask, hitw);
-        sv_emit(hitw, cand, ctr, last_tile * TILE + tid, lane);
+        sv_emit(hitw, cand, ctr, last_tile * TILE + tid, lane, paired);
         // ---- queue the passing seeds of this tile (probed during the next iteration).  If the queue could overflow
         // (dense on-locus data) it is drained on the spot and filling continues.
         u32 cnt = 0; int t0 = 0;
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(LDSBM ? 1024 : 256) void k_sieve_q(const u32* __res
         SvProbe Ps; sv_issue<!LDSBM>(Ps, queue, base + (u32)lane, qcnt, sieve, sshift);
         sv_check(Ps, sieve, smask, hitw);
     }
-    sv_emit(hitw, cand, ctr, last_tile * TILE + tid, lane);
+    sv_emit(hitw, cand, ctr, last_tile * TILE + tid, lane, paired);
     __syncthreads();
     if (tid == 0) { const u64 t1 = (u64)wall_clock64(); atomicMax(&ctr->sv_t1, t1); atomicMax(&ctr->sv_wgmax, t1 - wg_t0); }
 }
@@ -859,6 +863,7 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
     const u64 n_tiles = (n_reads + (u64)NWP * 64 - 1) / ((u64)NWP * 64);
     u64* const q = s_q[wave]; u32 qn = 0;          // wave-uniform
     const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const v4u none4 = {RT_DUMMY, RT_DUMMY, RT_DUMMY, RT_DUMMY};      // lanes beyond a region's end: neither a seed nor a run start
     // the entry counts and routed-tile counts of this wave's regions (lane i: region wave + 16 i), fetched once: read
     // region by region they cost two dependent round trips in front of every region's first load
     u32 my_n[RT_MAXP / 1024], my_em[RT_MAXP / 1024];
@@ -880,7 +885,7 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
         int seq = -1;                               // flags seen so far - 1 = sequence number of the current (tile, wave) run
         v4u en[PF];
         #pragma unroll
-        for (int u = 0; u < PF; u++) { const u32 i = (u32)u * 256 + (u32)lane * 4; en[u] = i < n ? __builtin_nontemporal_load(ent4 + (i >> 2)) : v4u{0u, 0u, 0u, 0u}; }
+        for (int u = 0; u < PF; u++) { const u32 i = (u32)u * 256 + (u32)lane * 4; en[u] = i < n ? __builtin_nontemporal_load(ent4 + (i >> 2)) : none4; }
         for (u32 i0 = 0; i0 < n; i0 += 256 * PF) {
             u32 ev[PF][4];
             #pragma unroll
@@ -889,26 +894,26 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
                 asm volatile("v_mov_b32 %0, %1" : "=v"(ev[u][2]) : "v"(en[u].z)); asm volatile("v_mov_b32 %0, %1" : "=v"(ev[u][3]) : "v"(en[u].w));
             }
             #pragma unroll
-            for (int u = 0; u < PF; u++) { const u32 i = i0 + 256 * PF + (u32)u * 256 + (u32)lane * 4; en[u] = i < n ? __builtin_nontemporal_load(ent4 + (i >> 2)) : v4u{0u, 0u, 0u, 0u}; }
+            for (int u = 0; u < PF; u++) { const u32 i = i0 + 256 * PF + (u32)u * 256 + (u32)lane * 4; en[u] = i < n ? __builtin_nontemporal_load(ent4 + (i >> 2)) : none4; }
             asm volatile("" ::: "memory");
             #pragma unroll
             for (int u = 0; u < PF; u++) {
                 const u32 ib = i0 + (u32)u * 256;
                 if (ib >= n) break;                 // wave-uniform
-                bool lv[4], fg[4]; u64 B[4]; u32 before = 0;
+                // (a region's length is a multiple of four: a lane's four entries are all inside it or all the no-seed filler)
+                bool fg[4]; u64 B[4]; u32 before = 0;
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    lv[j] = ib + (u32)lane * 4 + j < n;
-                    fg[j] = lv[j] && (ev[u][j] & RT_FLAG);
+                    fg[j] = (ev[u][j] & RT_FLAG) != 0;
                     B[j] = __ballot(fg[j]);
-                    before += (u32)__popcll(B[j] & lt);
+                    before = __builtin_amdgcn_mbcnt_hi((u32)(B[j] >> 32), __builtin_amdgcn_mbcnt_lo((u32)B[j], before));      // run starts in the lanes below
                 }
                 // the filter words of the four entries in one batch of independent LDS reads (an entry without a seed reads word 0
                 // and fails on its own flag)
                 u32 f0[4], f1[4], k0[4], k1[4]; bool sd[4];
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    sd[j] = lv[j] && (ev[u][j] & RT_HMASK) != RT_DUMMY;
+                    sd[j] = (ev[u][j] & RT_HMASK) != RT_DUMMY;
                     u32 b0, b1; rt_filter_addr(ev[u][j] & RT_HMASK, b0, k0[j], b1, k1[j]);
                     f0[j] = s_f[sd[j] ? b0 : 0u]; f1[j] = s_f[sd[j] ? b1 : 0u];
                 }
@@ -947,13 +952,18 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
 }
 
 // candidate flags -> candidate list (one atomic per 1024-thread workgroup that holds candidates)
-__global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ flags, u64 n_reads, u32* __restrict__ cand, Counters* __restrict__ ctr) {
+__global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ flags, u64 n_reads, u32* __restrict__ cand, Counters* __restrict__ ctr, int paired) {
     __shared__ u32 s_cnt[16]; __shared__ u64 s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u64 n_words = (n_reads + 31) >> 5;
     for (u64 w0 = (u64)blockIdx.x * 1024; w0 < n_words; w0 += (u64)gridDim.x * 1024) {
         const u64 wi = w0 + tid;
-        const u32 f = wi < n_words ? flags[wi] : 0u;
+        u32 f = wi < n_words ? flags[wi] : 0u;
+        if (paired) {      // mates become candidates together (see sv_emit); the last word is clipped to the reads that exist
+            f |= ((f & 0xAAAAAAAAu) >> 1) | ((f & 0x55555555u) << 1);
+            const u64 first = wi * 32;
+            if (first + 32 > n_reads) f &= first < n_reads ? ((1u << (n_reads - first)) - 1u) : 0u;
+        }
         u32 c = (u32)__popc(f), tot;
         const u32 pre = wave_excl_scan_u32(c, tot);
         if (lane == 0) s_cnt[wv] = tot;
@@ -1095,7 +1105,7 @@ __device__ inline bool table_find(const EngineDev& E, u32 lo, u32 hi, u32& val) 
 
 __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, const u32* __restrict__ packed, const u8* __restrict__ qrows,
                                                const u16* __restrict__ lens, u32 wpr, u32 qstride, u64 read_base,
-                                               const u32* __restrict__ cand) {
+                                               const u32* __restrict__ cand, int paired) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     __shared__ Bin s_bins[256][MLST_MAX_CAND];
     __shared__ Bin s_items[256][MLST_MAX_CAND];
@@ -1201,6 +1211,12 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
         // the 400-byte copy of each kept read is left to k_retain (one half-block per read, all reads in parallel);
         // doing it here, read after read inside the wave, was the longest chain of this kernel
         if (no > 0) { E.ret_len[slot] = (u16)lw; E.ret_ridx[slot] = read_base + r; E.ret_nrec[slot] = 0; }
+        // Q3: the mate (the neighbouring candidate when the two are reads 2k, 2k+1) and where this read's items start
+        u32 mate_slot = 0xFFFFFFFFu;
+        if (paired) {
+            const u32 other_r = (u32)__shfl_xor((int)r, 1); const u64 other_slot = (u64)__shfl_xor((long long)slot, 1); const bool other_in = __shfl_xor((int)(c < n_cand), 1) != 0;
+            if (other_in && (other_r ^ 1u) == r && other_slot != ~0ull) mate_slot = (u32)other_slot;
+        }
         // item slots and result rows: wave prefix sums, one atomic per counter per wave
         u32 my_res = 0;
         for (int u = 0; u < no; u++) my_res += E.loci[items[u].locus].n_pad;
@@ -1213,6 +1229,7 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             ib0 = __shfl(ib0, 0); ro0 = __shfl(ro0, 0);
         }
         u64 ib = ib0 + pre_items, ro = ro0 + pre_res;
+        if (no > 0) { E.ret_mate[slot] = mate_slot; E.ret_item0[slot] = (u32)ib; E.ret_nitems[slot] = (u8)no; }
         for (int u = 0; u < no; u++) {
             u32 np = E.loci[items[u].locus].n_pad;
             if (ib + u >= E.cap_items) { atomicOr(&E.ctr->err, 2ull); break; }
@@ -1920,17 +1937,29 @@ __global__ __launch_bounds__(256) void k_accumulate(const EngineDev* __restrict_
 }
 
 // sequenceBank[locus][QNAME] = len(SEQ) (metamlst.py:127) and first-seen order (Q6): one lane per item, items of the
-// same locus inside a wave are combined before touching the per-locus words.
-__global__ __launch_bounds__(256) void k_locus(const EngineDev* __restrict__ Ep) {
+// same locus inside a wave are combined before touching the per-locus words.  The dictionary holds ONE length per
+// (locus, QNAME) -- that of the last accepted record (Q3) -- so a read that matches both strands of a locus counts once,
+// and of two mates that share a QNAME (paired) the second one's length replaces the first one's.
+__global__ __launch_bounds__(256) void k_locus(const EngineDev* __restrict__ Ep, int paired) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     const int lane = threadIdx.x & 63;
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
     for (u64 i0 = begin + (u64)blockIdx.x * 256; i0 < end; i0 += (u64)gridDim.x * 256) {
         u64 ii = i0 + threadIdx.x;
-        bool acc = false; u32 locus = 0; u64 n = 0, ridx = ~0ull;
+        bool acc = false, counts = false; u32 locus = 0; u64 n = 0, ridx = ~0ull;
         if (ii < end && (E.item_state[ii] & IS_ACC)) {
             ItemDev it = E.items[ii];
-            acc = true; locus = it.locus; n = (u64)(E.ret_len[it.ret] & 0x7FFFu); ridx = E.ret_ridx[it.ret];
+            acc = true; counts = true; locus = it.locus; n = (u64)(E.ret_len[it.ret] & 0x7FFFu); ridx = E.ret_ridx[it.ret];
+            // an earlier item of the same read on the same locus (the other strand) already stands for this QNAME
+            const u64 first = E.ret_item0[it.ret];
+            for (u64 j = first; j < ii; j++) if (E.items[j].locus == locus && (E.item_state[j] & IS_ACC)) counts = false;
+            if (counts && paired && !(ridx & 1ull)) {      // first mate: superseded when the second mate has an accepted record here
+                const u32 ms = E.ret_mate[it.ret];
+                if (ms != 0xFFFFFFFFu) {
+                    const u64 m0 = E.ret_item0[ms], m1 = m0 + E.ret_nitems[ms];
+                    for (u64 j = m0; j < m1; j++) if (E.items[j].locus == locus && (E.item_state[j] & IS_ACC)) counts = false;
+                }
+            }
         }
         u64 todo = __ballot(acc);
         while (todo) {
@@ -1938,7 +1967,7 @@ __global__ __launch_bounds__(256) void k_locus(const EngineDev* __restrict__ Ep)
             u32 L0 = __shfl(locus, src);
             bool in = acc && locus == L0;
             u64 grp = __ballot(in); todo &= ~grp;
-            u64 sum = wave_sum_u64(in ? n : 0ull), mn = wave_min_u64(in ? ridx : ~0ull);
+            u64 sum = wave_sum_u64(in && counts ? n : 0ull), mn = wave_min_u64(in ? ridx : ~0ull);
             if (lane == src) { atomicAdd(&E.locus_len[L0], sum); atomicMin(&E.locus_first[L0], mn); }
         }
     }
@@ -2326,6 +2355,7 @@ extern "C" int mlst_create(int device, const mlst_params* p, mlst_handle** out) 
     if (prm.match_bonus < 1 || prm.match_bonus > 127) return fail(nullptr, MLST_E_INVALID, "match_bonus must be in 1..127");
     if (!prm.max_retained_reads) prm.max_retained_reads = 4ull << 20;
     if (!prm.max_items) prm.max_items = 8ull << 20;
+    if (prm.max_items >= (1ull << 32)) return fail(nullptr, MLST_E_INVALID, "max_items must be below 2^32");
     if (!prm.max_pair_results) prm.max_pair_results = 256ull << 20;
     mlst_handle* h = new mlst_handle();
     h->device = device; h->prm = prm;
@@ -2363,6 +2393,7 @@ static void free_state(mlst_handle* h) {
     hipFree(h->d_E); h->d_E = nullptr;
     hipFree(h->d_stats); h->d_stats = nullptr; if (h->h_stats) { hipHostFree(h->h_stats); h->h_stats = nullptr; }
     hipFree(E.ret_bases); hipFree(E.ret_quals); hipFree(E.ret_len); hipFree(E.ret_ridx); hipFree(E.ret_nrec);
+    hipFree(E.ret_mate); hipFree(E.ret_item0); hipFree(E.ret_nitems); E.ret_mate = nullptr; E.ret_item0 = nullptr; E.ret_nitems = nullptr;
     hipFree(E.items); hipFree(E.item_state); hipFree(E.res); hipFree(E.dp_list);
     hipFree(h->d_locus_chosen); hipFree(h->d_locus_colbase); hipFree(h->d_pl_list); hipFree(h->d_tb);
     E.sum_score = nullptr; E.n_hits = nullptr; E.locus_len = E.locus_first = nullptr; E.ctr = nullptr; E.ret_bases = nullptr; E.ret_quals = nullptr;
@@ -2731,18 +2762,20 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     }
     HIPCHK(h, dmalloc(&E.ret_bases, E.cap_ret * RW)); HIPCHK(h, dmalloc(&E.ret_quals, E.cap_ret * RQ));
     HIPCHK(h, dmalloc(&E.ret_len, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_ridx, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_nrec, E.cap_ret));
+    HIPCHK(h, dmalloc(&E.ret_mate, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_item0, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_nitems, E.cap_ret));
     HIPCHK(h, dmalloc(&E.items, E.cap_items)); HIPCHK(h, dmalloc(&E.item_state, E.cap_items)); HIPCHK(h, dmalloc(&E.res, E.cap_res)); HIPCHK(h, dmalloc(&E.dp_list, E.cap_dp));
     HIPCHK(h, dmalloc(&h->d_locus_colbase, (u64)n_loci * 2 + 2));   // [colbase u64 x L][chosen int x L]
     HIPCHK(h, dmalloc(&h->d_pl_list, E.cap_items));
     HIPCHK(h, dmalloc(&h->d_tb, (u64)64 * 64 * MLST_MAX_READ_LEN * (2 * MAX_W + 1)));
     HIPCHK(h, dmalloc(&h->d_E, (u64)1)); HIPCHK(h, hipMemcpy(h->d_E, &h->E, sizeof(EngineDev), hipMemcpyHostToDevice));
     {   // k_extend launch shape: threads per work item from the largest locus (MLST_EXT_THREADS / MLST_EXT_BLOCKS override it)
-        // lanes = alleles.  Up to 512 alleles per locus: one pass, the workgroup is the locus size rounded up to whole waves
-        // (300 alleles -> 320 threads; 256 threads took two passes with 41 % of the lanes idle: cfg3 0.78 -> 0.56 ms).  Larger
-        // loci: 256 threads and as many passes as it takes (a one-wave workgroup leaves as few lanes idle, but with few items --
-        // 9 k in cfg2 -- the 23 serial passes of an item become the tail of the kernel: 0.18 -> 0.31 ms).
+        // lanes = alleles.  An item costs a workgroup ~8 us of staging and barriers whatever its size, so what counts is how
+        // many items are in flight.  Up to 512 alleles per locus (at most 8 passes of one wave): one-wave workgroups, 7168
+        // of them -- cfg3 (300 alleles, 121 k items): 0.55 ms; 128 / 192 / 320 / 384 threads: 0.61 / 0.69 / 0.86 / 1.01 ms.
+        // Larger loci: 256 threads -- cfg2 (1430 alleles, 9 k items): 0.18 ms against 0.31 ms with one wave, whose 23 serial
+        // passes per item become the tail of the kernel.
         u32 mx = 0; for (auto& L : loci) mx = std::max(mx, L.n_alleles);
-        int thr = mx <= 512 ? (int)((mx + 63) & ~63u) : 256; if (thr < 64) thr = 64;
+        int thr = mx <= 512 ? 64 : 256;
         const char* e1 = getenv("MLST_EXT_THREADS"); if (e1 && atoi(e1) >= 64 && atoi(e1) <= 1024 && atoi(e1) % 64 == 0) thr = atoi(e1);
         int blocks = 1792 * 256 / thr;     // 7 waves per SIMD (k_extend_160 is held to 72 VGPRs); the work queue balances the rest
         const char* e2 = getenv("MLST_EXT_BLOCKS"); if (e2 && atoi(e2) > 0) blocks = atoi(e2);
@@ -2825,19 +2858,22 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     if (n_reads >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "a batch holds at most 2^32-1 reads");
     if (((uintptr_t)d_packed & 15) != 0) return fail(h, MLST_E_INVALID, "packed rows must be 16-byte aligned");
     if (n_reads == 0) return MLST_OK;
-    (void)paired;   // mates are typed independently; they share a QNAME only for the coverage figure
+    // mates are aligned and typed independently (the documented pipeline is bowtie2 -U); sharing a QNAME matters for the
+    // per-locus read-length sums only (Q3, k_locus)
+    paired = paired ? 1 : 0;
+    if (paired && ((n_reads | h->reads_seen) & 1ull)) return fail(h, MLST_E_INVALID, "paired submissions hold whole pairs (reads 2k, 2k+1) and start at an even read index");
     if (h->cap_cand < n_reads) { hipStreamSynchronize(h->stream); hipFree(h->d_cand); h->d_cand = nullptr; HIPCHK(h, dmalloc(&h->d_cand, n_reads)); h->cap_cand = n_reads; }
     EngineDev& E = h->E;
     if (h->sieve_kind == MLST_SIEVE_ROUTED) { int rc = ensure_route_buffers(h, n_reads, wpr); if (rc) return rc; }
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
                                                (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand,
                                                (u64)(uintptr_t)h->d_bin_flags, (u64)(uintptr_t)h->d_rt_arena, (u64)(uintptr_t)h->d_rt_counts,
-                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw});
+                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw, (u64)paired});
     if (gs == 1) { h->reads_seen += n_reads; return MLST_OK; }
     { Prof pf(h, 0);
       if (h->sieve_kind == MLST_SIEVE_LDS) {      // LDS first level: one 1024-thread workgroup per CU
         dim3 grid(grid_for((n_reads + 1023) / 1024, 1, 256)), block(1024);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, true>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.bitmap, 0u, h->d_cand, E.ctr); break;
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, true>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.bitmap, 0u, h->d_cand, E.ctr, paired); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
@@ -2859,17 +2895,17 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
         }
-        hipLaunchKernelGGL(k_flag_compact, dim3(grid_for(n_flag_words, 1024, 256)), dim3(1024), 0, h->stream, h->d_bin_flags, (u64)n_reads, h->d_cand, E.ctr);
+        hipLaunchKernelGGL(k_flag_compact, dim3(grid_for(n_flag_words, 1024, 256)), dim3(1024), 0, h->stream, h->d_bin_flags, (u64)n_reads, h->d_cand, E.ctr, paired);
       } else {      // hashed first-level bitmap in global memory, 256-thread workgroups (MLST_SIEVE=global; databases without seeds)
         dim3 grid(grid_for((n_reads + 255) / 256, 1, h->sieve_g_blocks)), block(256);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, false>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.gbitmap.p, E.gbitmap_bits, h->d_cand, E.ctr); break;
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, false>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.gbitmap.p, E.gbitmap_bits, h->d_cand, E.ctr, paired); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
       }
     }
     { Prof pf(h, 1);
-      hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand);
+      hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand, paired);
       hipLaunchKernelGGL(k_retain, dim3(1024), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
     { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
       const int thr = h->ext_threads, blocks = h->ext_blocks;
@@ -2877,7 +2913,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
-      hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, h->d_E); }
+      hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, h->d_E, paired); }
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, h->stream, E.ctr, n_reads);
     if (gs == 2) { int rc = graph_leave(h, h->g_submit); if (rc) return rc; }
     HIPCHK(h, hipGetLastError());

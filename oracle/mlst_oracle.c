@@ -384,19 +384,26 @@ typedef struct {
  *   cel[sp][gene][allele].append(score) (:125); sequenceBank[sp_gene][QNAME] = len(SEQ) (:127);
  *   ignoredReads / totalReads count records (:129-130, Q13).
  * `item` groups the records of one (read, locus, strand) extension. */
-static void accumulate_read(const orc_ref* r, int n, uint64_t gi, const rec_t* recs, size_t nrec, acc_t* A) {
+/* sequenceBank[species_gene][readCode] = len(sequence) (metamlst.py:127) for the reads that share ONE readCode (QNAME): a
+ * dictionary entry per locus, overwritten by every accepted record, so that the locus is credited with the length of the
+ * LAST accepted record of the QNAME (Q3) -- once for a read that matches both strands of the locus, and with the second
+ * mate's length when both mates of a pair (same QNAME) have accepted records there. */
+typedef struct { uint32_t locus[2 * MLST_MAX_CAND]; int len[2 * MLST_MAX_CAND]; int n; } bank_t;
+static void bank_set(bank_t* b, uint32_t locus, int len) {
+    for (int i = 0; i < b->n; i++) if (b->locus[i] == locus) { b->len[i] = len; return; }
+    b->locus[b->n] = locus; b->len[b->n] = len; b->n++;
+}
+static void bank_flush(bank_t* b, acc_t* A) { for (int i = 0; i < b->n; i++) A->len[b->locus[i]] += (uint64_t)b->len[i]; b->n = 0; }
+
+static void accumulate_read(const orc_ref* r, int n, uint64_t gi, const rec_t* recs, size_t nrec, acc_t* A, bank_t* bank) {
     int use_xo = r->prm.xm_field_quirk && nrec == 1;
-    int item_acc[MLST_MAX_CAND]; for (int it = 0; it < MLST_MAX_CAND; it++) item_acc[it] = 0;
     for (size_t k = 0; k < nrec; k++) {
         int f15 = use_xo ? recs[k].xo : recs[k].xm;
         A->cnt[MLST_CNT_TOTAL_RECORDS]++;
         if (recs[k].score >= r->prm.minscore && n >= r->prm.min_read_len && f15 <= r->prm.max_xm) {
             A->sum[recs[k].allele] += recs[k].score; A->hits[recs[k].allele]++;
-            if (!item_acc[recs[k].item]) {
-                item_acc[recs[k].item] = 1;
-                A->len[recs[k].locus] += (uint64_t)n;
-                if (gi < A->first[recs[k].locus]) A->first[recs[k].locus] = gi;
-            }
+            bank_set(bank, recs[k].locus, n);
+            if (gi < A->first[recs[k].locus]) A->first[recs[k].locus] = gi;
         } else A->cnt[MLST_CNT_IGNORED]++;
     }
 }
@@ -410,7 +417,7 @@ int orc_pass1(const orc_ref* r, const uint8_t* bases, const uint8_t* quals, cons
               uint64_t n_reads, uint64_t read_index_base,
               int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_len_sum, uint64_t* locus_first,
               uint64_t* counters, mlst_item* items_out, uint64_t items_cap, uint64_t* n_items_out,
-              int n_threads) {
+              int n_threads, int paired /* reads 2k, 2k+1 are mates sharing a QNAME (Q3) */) {
     const uint32_t nA = r->n_alleles, nL = r->n_loci;
     memset(sum_score, 0, sizeof(int64_t) * nA); memset(n_hits, 0, sizeof(uint32_t) * nA);
     memset(locus_len_sum, 0, sizeof(uint64_t) * nL);
@@ -431,8 +438,11 @@ int orc_pass1(const orc_ref* r, const uint8_t* bases, const uint8_t* quals, cons
         uint64_t* t_cnt = A.cnt;
         rec_t* recs = NULL; size_t recs_cap = 0;
         aln_t* al = (aln_t*)malloc(sizeof(aln_t));
-        #pragma omp for schedule(dynamic, 4096)
-        for (int64_t ri = 0; ri < (int64_t)n_reads; ri++) {
+        const int64_t unit = paired ? 2 : 1;          /* reads that share a QNAME are accumulated together */
+        bank_t bank; bank.n = 0;
+        #pragma omp for schedule(dynamic, 2048)
+        for (int64_t ui = 0; ui < ((int64_t)n_reads + unit - 1) / unit; ui++) {
+          for (int64_t ri = ui * unit; ri < (ui + 1) * unit && ri < (int64_t)n_reads; ri++) {
             int n = (int)(off[ri + 1] - off[ri]);
             t_cnt[MLST_CNT_READS_SEEN]++;
             if (n > MLST_MAX_READ_LEN) { bad = 1; continue; }
@@ -468,7 +478,9 @@ int orc_pass1(const orc_ref* r, const uint8_t* bases, const uint8_t* quals, cons
                     recs[nrec].allele = a; recs[nrec].score = al->score; recs[nrec].xm = al->xm; recs[nrec].xo = al->xo; recs[nrec].locus = L; recs[nrec].item = it; nrec++;
                 }
             }
-            accumulate_read(r, n, read_index_base + (uint64_t)ri, recs, nrec, &A);
+            accumulate_read(r, n, read_index_base + (uint64_t)ri, recs, nrec, &A, &bank);
+          }
+          bank_flush(&bank, &A);
         }
         #pragma omp critical
         {
@@ -506,7 +518,7 @@ int orc_accumulate_records(const orc_ref* r, uint64_t n_recs, const uint64_t* re
             recs[nrec].allele = allele[j]; recs[nrec].score = as[j]; recs[nrec].xm = xm[j]; recs[nrec].xo = xo[j];
             recs[nrec].locus = L; recs[nrec].item = it; nrec++; j++;
         }
-        accumulate_read(r, seqlen[i], read_index[i], recs, nrec, &A);
+        { bank_t bank; bank.n = 0; accumulate_read(r, seqlen[i], read_index[i], recs, nrec, &A, &bank); bank_flush(&bank, &A); }
         i = j;
     }
     memcpy(counters, A.cnt, sizeof(A.cnt));

@@ -36,7 +36,7 @@ def lib():
         _lib.orc_ref_n_keys.argtypes = [vp]
         _lib.orc_pass1.restype = C.c_int
         _lib.orc_pass1.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_uint64,
-                                   C.POINTER(C.c_uint64), C.c_int]
+                                   C.POINTER(C.c_uint64), C.c_int, C.c_int]
         _lib.orc_accumulate_records.restype = C.c_int
         _lib.orc_accumulate_records.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib.orc_pileup.restype = C.c_int
@@ -84,6 +84,7 @@ class Oracle:
         self._reads = (np.ascontiguousarray(bases, np.uint8), np.ascontiguousarray(quals, np.uint8),
                        np.ascontiguousarray(off, np.uint64))
         self._read_base = read_base
+        self._paired = bool(paired)
 
     def stats(self, want_items: int = 0):
         b, q, off = self._reads
@@ -94,7 +95,8 @@ class Oracle:
         n_items = C.c_uint64()
         rc = lib().orc_pass1(self._r, _p(b), _p(q), _p(off), len(off) - 1, getattr(self, '_read_base', 0), _p(s.sum_score), _p(s.n_hits),
                              _p(s.locus_len_sum), _p(s.locus_first), _p(s.counters),
-                             C.cast(items, C.c_void_p) if want_items else None, want_items, C.byref(n_items), self.threads)
+                             C.cast(items, C.c_void_p) if want_items else None, want_items, C.byref(n_items), self.threads,
+                             int(getattr(self, "_paired", False)))
         if rc != 0:
             raise RuntimeError("orc_pass1 rc=%d" % rc)
         if want_items:

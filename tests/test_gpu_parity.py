@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import fixtures as fx
+from metamlst_amd.engine import MlstError
 import oracle_lib
 from metamlst_amd import synth
 from metamlst_amd.engine import Engine, default_params
@@ -283,8 +284,11 @@ def test_alleles_with_ambiguity_codes_use_the_n_mask_paths():
 
 
 def test_paired_end_five_fold_coverage_cfg5():
-    """cfg5 of SURVEY.md 8(d): 2 x 150 bp pairs, insert N(300, 30), loci at ~5x.  The documented pipeline
-    aligns mates as unpaired reads (bowtie2 -U), so pairing only affects the displayed coverage figure."""
+    """cfg5 of SURVEY.md 8(d): 2 x 150 bp pairs, insert N(300, 30), loci at ~5x.  The documented pipeline aligns mates as
+    unpaired reads (bowtie2 -U): every mate gets its own records.  Sharing a QNAME matters in one place, the dictionary
+    sequenceBank[locus][QNAME] = len(SEQ) (metamlst.py:127, Q3): of two mates with accepted records on a locus only the
+    second one's length stays.  Engine (paired=1: candidates in pairs, mate links, k_locus) = oracle, and the per-locus
+    sums are smaller than those of the same reads submitted as single reads by exactly the first mates' lengths."""
     db, idx = fx.ecoli_small(80)
     g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][2], size=100_000)
     b, q = synth.sample_pairs(g, n_pairs=int(100_000 * 5 / 300))
@@ -292,13 +296,62 @@ def test_paired_end_five_fold_coverage_cfg5():
     eng, orc = both(idx)
     eng.reset_sample()
     eng.submit_reads(fb, fq, off, paired=True)
-    orc.submit_reads(fb, fq, off)
+    orc.submit_reads(fb, fq, off, paired=True)
     s = eng.stats()
     so, items_o = orc.stats(want_items=1 << 16)
     fx.assert_stats_equal(s, so)
     chosen, pc = check_pileup(eng, orc, idx, s)
     holes = sum(int((pc[a].sum(axis=1) == 0).sum()) for a in chosen)
     assert holes > 0, "5x coverage should leave some columns for the gap-fill path"
+    # the same reads as single reads: identical hits and scores, larger length sums (both mates of a pair counted)
+    eng.reset_sample()
+    eng.submit_reads(fb, fq, off, paired=False)
+    orc.submit_reads(fb, fq, off, paired=False)
+    s1, so1 = eng.stats(), orc.stats()
+    fx.assert_stats_equal(s1, so1)
+    assert np.array_equal(s1.sum_score, s.sum_score) and np.array_equal(s1.n_hits, s.n_hits)
+    assert (s1.locus_len_sum >= s.locus_len_sum).all() and int(s1.locus_len_sum.sum()) > int(s.locus_len_sum.sum())
+    # larger batches of pairs through the other sieves (candidates are paired up in sv_emit / k_flag_compact)
+    import os
+    for kind in ("global", "routed"):
+        os.environ["MLST_SIEVE"] = kind
+        try:
+            e2, o2 = both(idx)
+            e2.submit_reads(fb, fq, off, paired=True); o2.submit_reads(fb, fq, off, paired=True)
+            fx.assert_stats_equal(e2.stats(), o2.stats())
+        finally:
+            os.environ.pop("MLST_SIEVE", None)
+    with pytest.raises(MlstError):
+        eng.reset_sample(); eng.submit_reads(fb[:150 * 3], fq[:150 * 3], off[:4], paired=True)       # an odd number of reads
+
+
+def test_read_matching_both_strands_of_a_locus_counts_once():
+    """Q3, single reads: a read whose two strands both align to one locus (a palindromic allele) has two work items there;
+    the dictionary of metamlst.py:127 holds one length per (locus, QNAME)."""
+    import sqlite3
+    import tempfile
+    from metamlst_amd.index import load_index
+    d = tempfile.mkdtemp()
+    rng = np.random.default_rng(9)
+    half = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=120))
+    comp = half[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    pal = half + comp                                            # its own reverse complement
+    conn = sqlite3.connect(d + "/p.db")
+    synth.create_schema(conn)
+    conn.execute("INSERT INTO organisms VALUES ('spP','palindromes')")
+    conn.execute("INSERT INTO genes VALUES ('g0','spP')")
+    for k, seq in enumerate([pal, pal[:100] + "A" + pal[101:]], start=1):
+        conn.execute("INSERT INTO alleles (bacterium,gene,sequence,alignedSequence,alleleVariant) VALUES ('spP','g0',?,?,?)", (seq, seq, k))
+    conn.commit(); conn.close()
+    idx = load_index(d + "/p.db")
+    reads = [pal[s:s + 150].encode() for s in (0, 20, 45, 90)] * 3
+    fb, fq, off = synth.ragged_reads(reads, [bytes([73]) * 150] * len(reads))
+    eng, orc = both(idx)
+    eng.submit_reads(fb, fq, off); orc.submit_reads(fb, fq, off)
+    s, so = eng.stats(), orc.stats()
+    fx.assert_stats_equal(s, so)
+    assert int(s.counters[5]) > int(s.counters[4])               # more work items than retained reads: both strands
+    assert int(s.locus_len_sum[0]) <= 150 * len(reads)
 
 
 def test_larger_multi_species_database():
