@@ -18,4 +18,5 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   rocprofv3 --pmc $grp -d "$OUT/pass$i" --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --pipeline 1 --no-secondary --min-seconds 0.01 "$@" > "$OUT/pass$i.log" 2>&1 || { tail -5 "$OUT/pass$i.log"; exit 1; }
 done
 python3 $ROOT/profiles/pmc_extract.py "$OUT" > "$OUT/pmc_counters.json"
+python3 $ROOT/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --pipeline 1 --no-secondary --min-seconds 0.01 "$@" > "$OUT/bench_for_pmc.json" 2> /dev/null      # the same command unprofiled: counters of the line
 find "$OUT" -name "*.csv" -size +2M -delete            # the raw per-dispatch tables stay on the box

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 python3 $ROOT/__graft_entry__.py > /dev/null          # build outside the profiler
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/serial" --output-format csv -- python3 $ROOT/bench.py --pipeline 1 --cpu-seconds 0 --steps 10 --warmup 2 > "$OUT/bench_under_rocprof_serial.json" 2> "$OUT/serial.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/serial" --output-format csv -- python3 $ROOT/bench.py --pipeline 1 --no-secondary --cpu-seconds 0 --steps 10 --warmup 2 > "$OUT/bench_under_rocprof_serial.json" 2> "$OUT/serial.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/pipelined" --output-format csv -- python3 $ROOT/bench.py --cpu-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/pipelined.err"
 for m in serial pipelined; do
   f=$(find "$OUT/$m" -name "*kernel_stats.csv" | head -1)
