@@ -1107,20 +1107,22 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
                                                const u16* __restrict__ lens, u32 wpr, u32 qstride, u64 read_base,
                                                const u32* __restrict__ cand, int paired) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
-    __shared__ Bin s_bins[256][MLST_MAX_CAND];
-    __shared__ Bin s_items[256][MLST_MAX_CAND];
+    // a lane's eight 12-byte bins = 24 words: left at that stride the 64 lanes share 4 of the 32 LDS banks (16-way conflicts
+    // on every access of the vote loops); one word of padding per lane makes the stride odd
+    __shared__ u32 s_bins[256][MLST_MAX_CAND * 3 + 1];
+    __shared__ u32 s_items[256][MLST_MAX_CAND * 3 + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     u64 n_cand = E.ctr->n_cand;
     for (u64 c0 = (u64)blockIdx.x * 256; c0 < n_cand; c0 += (u64)gridDim.x * 256) {
         u64 c = c0 + tid;
         u32 r = 0, lw = 0, n = 0; int no = 0;
-        Bin* items = s_items[tid];
+        Bin* items = reinterpret_cast<Bin*>(s_items[tid]);
         if (c < n_cand) {
             r = cand[c];
             lw = lens[r]; n = lw & 0x7FFFu; bool has_n = (lw & 0x8000u) != 0;
             const u32* row = packed + packed_index(r, wpr, 0);      // word c of the row: row[(c >> 1) * 128 + (c & 1)]
             const u8* qrow = qrows + (u64)r * qstride;
-            Bin* bins = s_bins[tid]; int nb = 0;
+            Bin* bins = reinterpret_cast<Bin*>(s_bins[tid]); int nb = 0;
             int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
             // The lane's work is a chain of dependent look-ups (key -> value -> postings); a kernel over ~10^4
             // candidates is as long as one lane's chain.  So the look-ups of up to SEED_CHUNK seeds are issued
@@ -1275,11 +1277,22 @@ __device__ inline void stage_read(const EngineDev& E, const KParams& P, const It
     const u8 pen_def = s_pentab[40];     // s_odd marks the positions whose penalty is not the Phred-40 one
     auto rb = E.ret_bases.g() + (u64)it.ret * RW;
     auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
-    for (int i0 = 0; i0 < RQ; i0 += nthreads) {
+    constexpr int KP = RQ / 64;          // (loads of all passes in one batch: see stage_read_planes)
+    u32 qv[KP], wv[KP];
+    #pragma unroll
+    for (int k = 0; k < KP; k++) {
+        const int i = k * nthreads + tid; qv[k] = 0; wv[k] = 0;
+        if (i < n) { const int s = it.strand ? n - 1 - i : i; qv[k] = rq[s]; wv[k] = rb[s >> 4]; }
+    }
+    tie_all<KP>(qv); tie_all<KP>(wv);
+    #pragma unroll
+    for (int k = 0; k < KP; k++) {
+        const int i0 = k * nthreads;
+        if (i0 >= RQ) break;
         int i = i0 + tid; u32 v = 0, nb = 0, ob = 0;
         if (i < n) {
-            int s = it.strand ? n - 1 - i : i; u8 qb = rq[s];
-            u32 b = src_base(rb, s); if (it.strand) b ^= 3u;
+            int s = it.strand ? n - 1 - i : i; u8 qb = (u8)qv[k];
+            u32 b = (wv[k] >> (2 * (s & 15))) & 3u; if (it.strand) b ^= 3u;
             u32 isn = qb >> 7;
             u8 pen = isn ? (u8)P.n_penalty : s_pentab[qb & 0x7F];
             s_pen[i] = pen;
@@ -1404,6 +1417,8 @@ __device__ inline int stage_read_planes(const EngineDev& E, const KParams& P, co
     auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
     const u8 qmid = rq[n >> 1];
     const u8 pen_def = (qmid >> 7) ? (u8)P.n_penalty : s_pentab[qmid & 0x7F];
+    // (issuing the loads of all passes in one batch was measured: k_extend 554 -> 610 us on cfg3 -- the kernel is bound by
+    // instruction issue, not by this chain; the same change in stage_read, whose kernel waits on it, stays)
     for (int i0 = 0; i0 < RQ; i0 += nthreads) {
         int i = i0 + tid; u32 b = 0, isn = 0, odd = 0;
         if (i < n) {
@@ -1961,8 +1976,11 @@ __global__ __launch_bounds__(256) void k_locus(const EngineDev* __restrict__ Ep,
                 }
             }
         }
+        // lanes of the same locus are combined before the per-locus words are touched -- for the first few loci of the wave
+        // (an isolate's items all sit on 7 loci); a metagenome's wave holds dozens of loci, and combining them one locus at
+        // a time was the kernel (114 us on cfg3): what is left after four rounds goes to the words lane by lane
         u64 todo = __ballot(acc);
-        while (todo) {
+        for (int round = 0; round < 4 && todo; round++) {
             int src = __ffsll((long long)todo) - 1;
             u32 L0 = __shfl(locus, src);
             bool in = acc && locus == L0;
@@ -1970,6 +1988,7 @@ __global__ __launch_bounds__(256) void k_locus(const EngineDev* __restrict__ Ep,
             u64 sum = wave_sum_u64(in && counts ? n : 0ull), mn = wave_min_u64(in ? ridx : ~0ull);
             if (lane == src) { atomicAdd(&E.locus_len[L0], sum); atomicMin(&E.locus_first[L0], mn); }
         }
+        if ((todo >> lane) & 1ull) { if (counts) atomicAdd(&E.locus_len[locus], n); atomicMin(&E.locus_first[locus], ridx); }
     }
 }
 
@@ -2906,14 +2925,16 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     }
     { Prof pf(h, 1);
       hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand, paired);
-      hipLaunchKernelGGL(k_retain, dim3(1024), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
+      // (one pair of reads per workgroup and sweep, every sweep a chain of dependent scattered loads: a large grid keeps the
+      // sweeps few -- 1024 workgroups took 59 sweeps = 112 us for the 121 k retained reads of cfg3)
+      hipLaunchKernelGGL(k_retain, dim3(16384), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
     { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
       const int thr = h->ext_threads, blocks = h->ext_blocks;
       if (wpr <= 10) hipLaunchKernelGGL(k_extend_160, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
       else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
-      hipLaunchKernelGGL(k_locus, dim3(256), dim3(256), 0, h->stream, h->d_E, paired); }
+      hipLaunchKernelGGL(k_locus, dim3(1024), dim3(256), 0, h->stream, h->d_E, paired); }
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, h->stream, E.ctr, n_reads);
     if (gs == 2) { int rc = graph_leave(h, h->g_submit); if (rc) return rc; }
     HIPCHK(h, hipGetLastError());
@@ -3230,7 +3251,7 @@ static int pileup_launch(mlst_handle* h, const uint32_t* chosen, uint32_t n, uin
     HIPCHK(h, hipMemsetAsync(&h->E.ctr.p->n_pl_dp, 0, 8, h->stream));
     const int* d_lc = (const int*)((u8*)h->d_locus_colbase + nl * 8);
     { Prof pf(h, 5);
-      hipLaunchKernelGGL(k_pileup, dim3(4096), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list);
+      hipLaunchKernelGGL(k_pileup, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list);
       hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list, h->d_tb); }
     HIPCHK(h, hipGetLastError());
     return MLST_OK;
@@ -3360,7 +3381,8 @@ extern "C" int mlst_typing_choose_pileup(mlst_handle* h, int32_t penalty, uint32
     HIPCHK(h, hipMemsetAsync(cnt, 0, (ncols ? ncols : 1) * 16, h->stream));
     HIPCHK(h, hipMemsetAsync(&h->E.ctr.p->n_pl_dp, 0, 8, h->stream));
     { Prof pf(h, 5);
-      hipLaunchKernelGGL(k_pileup, dim3(4096), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list);
+      // one wave per item, 64 VGPRs: 8192 waves fill the chip's wave slots (4096 left half of them empty: 224 us on cfg3)
+      hipLaunchKernelGGL(k_pileup, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list);
       hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list, h->d_tb); }
     HIPCHK(h, hipGetLastError());
     return MLST_OK;
