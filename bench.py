@@ -575,7 +575,8 @@ def main():
            "kernel_ms_per_launch_isolated": {k: round(v, 4) for k, v in res["iso_launch_ms"].items()},
            "host_ms_per_step": res["host_ms_per_step"], "serial_ms_per_step": round(res["serial_ms_per_step"], 4),
            "counters": {"records": int(stats.counters[0]), "ignored": int(stats.counters[1]), "candidates": int(stats.counters[3]),
-                        "retained": int(stats.counters[4]), "items": int(stats.counters[5]), "banded_sw_pairs": int(stats.counters[6])},
+                        "retained": int(stats.counters[4]), "items": int(stats.counters[5]), "banded_sw_pairs": int(stats.counters[6]),
+                        "routed_filter_passes": int(stats.counters[7])},
            "index_bytes": dict(zip(("allele_arena", "sieve", "seed_table"), eng.index_bytes()[:3])),
            "setup_s": {"database": round(w.t_db, 1), "index_host": round(w.t_index_host, 1), "index_device_x%d" % depth: round(w.t_index_dev, 1),
                        "resident_reads_x%d" % depth: round(w.t_reads, 1)},

@@ -62,6 +62,7 @@ enum {
     MLST_CNT_RETAINED      = 4,  /* reads with at least one exact seed (kept for pass 2) */
     MLST_CNT_ITEMS         = 5,  /* (read,locus,strand,diag) work items */
     MLST_CNT_DP_PAIRS      = 6,  /* (item,allele) pairs sent to banded SW */
+    MLST_CNT_SIEVE_PASS    = 7,  /* routed sieve: entries that passed the LDS filter and were examined exactly (a tuning figure) */
     MLST_CNT_N             = 8
 };
 

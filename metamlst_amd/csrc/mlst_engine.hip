@@ -861,7 +861,7 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
     __syncthreads();
     const u32 NWP = R.nw;                          // runs per tile in a region (one per producer wave)
     const u64 n_tiles = (n_reads + (u64)NWP * 64 - 1) / ((u64)NWP * 64);
-    u64* const q = s_q[wave]; u32 qn = 0;          // wave-uniform
+    u64* const q = s_q[wave]; u32 qn = 0, n_pass = 0;      // wave-uniform: parked entries; entries that passed the filter so far
     const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     const v4u none4 = {RT_DUMMY, RT_DUMMY, RT_DUMMY, RT_DUMMY};      // lanes beyond a region's end: neither a seed nor a run start
     // the entry counts and routed-tile counts of this wave's regions (lane i: region wave + 16 i), fetched once: read
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
                         if (qn >= 64) {
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                             rt_examine<WPR>(q + (qn - 64), 64, lane, owner, packed, sieve, smask, sshift, R.flags.p);
-                            qn -= 64;
+                            qn -= 64; n_pass += 64;
                         }
                     }
                 }
@@ -947,6 +947,8 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     rt_examine<WPR>(q, qn, lane, owner, packed, sieve, smask, sshift, R.flags.p);
+    n_pass += qn;
+    if (lane == 0 && n_pass) atomicAdd(&ctr->cnt[MLST_CNT_SIEVE_PASS], (u64)n_pass);
     __syncthreads();
     if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
 }
