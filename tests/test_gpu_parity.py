@@ -550,3 +550,18 @@ def test_dense_on_locus_reads_overflow_the_sieve_queue():
             check_pileup(eng, orc, idx, s)
         finally:
             os.environ.pop("MLST_SIEVE", None)
+
+@pytest.mark.parametrize("kind", ["lds", "routed", "global"])
+def test_read_lengths_from_36_to_300_through_every_sieve(monkeypatch, kind):
+    """The sieve kernels are instantiated per row width (2 .. 20 words): batches of 36, 75, 100, 250 and 300 bp reads (whole
+    batches of one length, so that the row width follows the length) through each sieve, 320 bp reads included."""
+    monkeypatch.setenv("MLST_SIEVE", kind)
+    db, idx = fx.ecoli_small(80)
+    g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][4], size=60_000)
+    eng, orc = both(idx)
+    for L in (36, 75, 100, 250, 300, 320):
+        b, q = synth.sample_reads(g, 4000, read_len=L, seed=L)
+        fb, fq, off = synth.flatten_reads(b, q)
+        s, _ = run_both(eng, orc, fb, fq, off)
+        if L >= 75:
+            assert int(s.counters[4]) > 0
