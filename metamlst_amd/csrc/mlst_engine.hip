@@ -1111,14 +1111,14 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     // a lane's eight 12-byte bins = 24 words: left at that stride the 64 lanes share 4 of the 32 LDS banks (16-way conflicts
     // on every access of the vote loops); one word of padding per lane makes the stride odd
+    // (the per-(locus, strand) items are compacted in place over the bins: slot ni <= k is free by the time bin k is read)
     __shared__ u32 s_bins[256][MLST_MAX_CAND * 3 + 1];
-    __shared__ u32 s_items[256][MLST_MAX_CAND * 3 + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     u64 n_cand = E.ctr->n_cand;
     for (u64 c0 = (u64)blockIdx.x * 256; c0 < n_cand; c0 += (u64)gridDim.x * 256) {
         u64 c = c0 + tid;
         u32 r = 0, lw = 0, n = 0; int no = 0;
-        Bin* items = reinterpret_cast<Bin*>(s_items[tid]);
+        Bin* items = reinterpret_cast<Bin*>(s_bins[tid]);
         if (c < n_cand) {
             r = cand[c];
             lw = lens[r]; n = lw & 0x7FFFu; bool has_n = (lw & 0x8000u) != 0;
@@ -1248,21 +1248,42 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
 }
 
 // Copy the reads k_seed decided to keep into the retained-read arena: 128 lanes per read (20 base words + 80 quality
-// words), every read of the submission in parallel.
+// words).  Each copy is two dependent loads (slot -> read index -> row); a half-block that takes one read per turn spends
+// the kernel waiting for them 30 times over (67 us on cfg3), so it takes eight reads per turn and has their loads in flight
+// together.
 __global__ __launch_bounds__(256) void k_retain(const EngineDev* __restrict__ Ep, const u32* __restrict__ packed, const u8* __restrict__ qrows,
                                                  u32 wpr, u32 qstride, u64 read_base) {
     const EngineDev& E = *Ep;
+    constexpr int U = 8;
     const u64 begin = E.ctr->ret_done, end = E.ctr->n_ret < E.cap_ret ? E.ctr->n_ret : E.cap_ret;
     const u32 sub = threadIdx.x & 127;
-    for (u64 sl = begin + (u64)blockIdx.x * 2 + (threadIdx.x >> 7); sl < end; sl += (u64)gridDim.x * 2) {
-        const u64 rr = E.ret_ridx[sl] - read_base;
-        const u32 nn = E.ret_len[sl] & 0x7FFFu;
-        if (sub < RW) E.ret_bases[sl * RW + sub] = sub < wpr ? packed[packed_index(rr, wpr, sub)] : 0u;
-        else if (sub < RW + RQ / 4) {
-            const u32 w = sub - RW;
-            const u32 nq = nn < qstride ? nn : qstride;        // bytes to keep; rows hold zeros beyond the read length
-            const u32* qrow32 = reinterpret_cast<const u32*>(qrows + rr * qstride);
-            reinterpret_cast<GP<u32>::G*>(E.ret_quals.g() + sl * RQ)[w] = (w * 4 < nq) ? qrow32[w] : 0u;
+    if (sub >= RW + RQ / 4) return;
+    const bool is_base = sub < RW; const u32 w = is_base ? sub : sub - RW;
+    for (u64 s0 = begin + ((u64)blockIdx.x * 2 + (threadIdx.x >> 7)) * U; s0 < end; s0 += (u64)gridDim.x * 2 * U) {
+        u64 rr[U]; u32 nn[U];
+        #pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 sl = s0 + u; rr[u] = 0; nn[u] = 0;
+            if (sl < end) { rr[u] = E.ret_ridx[sl] - read_base; nn[u] = E.ret_len[sl] & 0x7FFFu; }
+        }
+        u32 val[U];
+        #pragma unroll
+        for (int u = 0; u < U; u++) {
+            val[u] = 0;
+            if (s0 + u >= end) continue;
+            if (is_base) { if (w < wpr) val[u] = packed[packed_index(rr[u], wpr, w)]; }
+            else {
+                const u32 nq = nn[u] < qstride ? nn[u] : qstride;        // bytes to keep; rows hold zeros beyond the read length
+                if (w * 4 < nq) val[u] = reinterpret_cast<const u32*>(qrows + rr[u] * qstride)[w];
+            }
+        }
+        tie_all<U>(val);
+        #pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 sl = s0 + u;
+            if (sl >= end) continue;
+            if (is_base) E.ret_bases[sl * RW + w] = val[u];
+            else reinterpret_cast<GP<u32>::G*>(E.ret_quals.g() + sl * RQ)[w] = val[u];
         }
     }
 }
@@ -1270,43 +1291,6 @@ __global__ __launch_bounds__(256) void k_retain(const EngineDev* __restrict__ Ep
 // ------------------------------------------------------------------ shared read-orientation helpers
 // Oriented read i (after reverse-complement when strand = 1) lives at source position s = strand ? n-1-i : i.
 __device__ inline u32 src_base(const u32* rb, int s) { return (rb[s >> 4] >> (2 * (s & 15))) & 3u; }
-
-// Build the oriented read of an item in LDS: 2-bit words, N bits (1 per base) and the per-position mismatch
-// penalty (bowtie2 --mp 6,2 quality-aware; --np 1 for N).  Cooperative: nthreads is a multiple of 64, every thread
-// owns read positions tid, tid+nthreads, ...; words are assembled with lane OR-reductions.
-__device__ inline void stage_read(const EngineDev& E, const KParams& P, const ItemDev& it, int n,
-                                  u32* s_rw, u32* s_rn, u32* s_odd, u8* s_pen, u8* s_q, const u8* s_pentab, int tid, int nthreads) {
-    const u8 pen_def = s_pentab[40];     // s_odd marks the positions whose penalty is not the Phred-40 one
-    auto rb = E.ret_bases.g() + (u64)it.ret * RW;
-    auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
-    constexpr int KP = RQ / 64;          // (loads of all passes in one batch: see stage_read_planes)
-    u32 qv[KP], wv[KP];
-    #pragma unroll
-    for (int k = 0; k < KP; k++) {
-        const int i = k * nthreads + tid; qv[k] = 0; wv[k] = 0;
-        if (i < n) { const int s = it.strand ? n - 1 - i : i; qv[k] = rq[s]; wv[k] = rb[s >> 4]; }
-    }
-    tie_all<KP>(qv); tie_all<KP>(wv);
-    #pragma unroll
-    for (int k = 0; k < KP; k++) {
-        const int i0 = k * nthreads;
-        if (i0 >= RQ) break;
-        int i = i0 + tid; u32 v = 0, nb = 0, ob = 0;
-        if (i < n) {
-            int s = it.strand ? n - 1 - i : i; u8 qb = (u8)qv[k];
-            u32 b = (wv[k] >> (2 * (s & 15))) & 3u; if (it.strand) b ^= 3u;
-            u32 isn = qb >> 7;
-            u8 pen = isn ? (u8)P.n_penalty : s_pentab[qb & 0x7F];
-            s_pen[i] = pen;
-            if (s_q) s_q[i] = qb;
-            v = b << (2 * (i & 15)); nb = isn << (i & 31); ob = (u32)(pen != pen_def) << (i & 31);
-        }
-        v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 8);
-        nb |= __shfl_xor(nb, 1); nb |= __shfl_xor(nb, 2); nb |= __shfl_xor(nb, 4); nb |= __shfl_xor(nb, 8); nb |= __shfl_xor(nb, 16);
-        ob |= __shfl_xor(ob, 1); ob |= __shfl_xor(ob, 2); ob |= __shfl_xor(ob, 4); ob |= __shfl_xor(ob, 8); ob |= __shfl_xor(ob, 16);
-        if (i < RQ) { if ((i & 15) == 0) s_rw[i >> 4] = v; if ((i & 31) == 0) { s_rn[i >> 5] = nb; s_odd[i >> 5] = ob; } }
-    }
-}
 
 __device__ inline u32 arena_word(const EngineDev& E, const LocusDev& L, int q, u32 a_local) {
     return (q >= 0 && q < (int)L.words) ? E.arena[L.arena_off + (u64)q * L.n_pad + a_local] : 0u;
@@ -1322,91 +1306,8 @@ __device__ inline u32 compress16(u32 x) {
     x &= 0x55555555u; x = (x | (x >> 1)) & 0x33333333u; x = (x | (x >> 2)) & 0x0F0F0F0Fu;
     x = (x | (x >> 4)) & 0x00FF00FFu; x = (x | (x >> 8)) & 0xFFFFu; return x;
 }
-// spread the low 16 bits of x to the even bit positions
-__device__ inline u32 spread16(u32 x) {
-    x &= 0xFFFFu; x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu;
-    x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u; return x;
-}
 
-// Ungapped local alignment of the staged read against allele a_local on diagonal d (Kadane over the mismatch
-// positions of the XOR of 2-bit words).  Returns the packed best value; mm_total = mismatching columns of the
-// whole overlap; [bs,be) = aligned read span.  Same recurrence as oracle align_ungapped.
-// The allele window (one dword per 16 bases, coalesced across lanes = alleles) is fetched as one batch of
-// independent loads before the serial Kadane pass.
-// NW = number of 16-base read words the instantiation supports (register arrays are sized by it)
-template <int NW>
-__device__ inline int ungapped(const EngineDev& E, const KParams& P, const LocusDev& L, u32 a_local, int m, int n, int d,
-                               const u32* s_rw, const u32* s_rn, const u32* s_odd, const u8* s_pen, int pen_def, bool read_has_n,
-                               int& mm_total, int& bs, int& be) {
-    int i0 = d < 0 ? -d : 0, i1 = (m - d) < n ? (m - d) : n;
-    mm_total = 0; bs = be = i0;
-    if (i1 <= i0) return P0;
-    const int MA = P.match_bonus << MLST_P_SHIFT;
-    const int nw = (n + 15) >> 4;                  // read words in use (block-uniform)
-    const int q0 = d >> 4, r2 = (d & 15) * 2;      // allele word of read position 0 (floor), bit shift
-    auto abase = E.arena.g() + L.arena_off;          // uniform base of the locus; lanes differ only in a_local
-    u32 Aw[NW + 1];
-    #pragma unroll
-    for (int t = 0; t <= NW; t++) {
-        Aw[t] = 0;
-        if (t <= nw) {                             // uniform guard
-            int q = q0 + t; int qc = q < 0 ? 0 : (q >= (int)L.words ? (int)L.words - 1 : q);
-            Aw[t] = abase[(u32)qc * L.n_pad + a_local];
-        }
-    }
-    // Words outside the allele only ever meet read positions outside [i0, i1), which the valid mask removes,
-    // so clamped (out-of-range) words need no zeroing.  Issue the whole window before using any of it:
-    tie_all<NW + 1>(Aw);
-    // mismatch bits, one per read base, 32 bases per mask
-    u32 M[NW / 2], AN[NW / 2];
-    #pragma unroll
-    for (int w = 0; w < NW / 2; w++) {
-        M[w] = 0; AN[w] = 0;
-        if (w * 2 < nw) {                          // uniform guard
-            u32 x0 = s_rw[2 * w] ^ __builtin_amdgcn_alignbit(Aw[2 * w + 1], Aw[2 * w], r2);        // allele bases aligned to the read word
-            u32 x1 = s_rw[2 * w + 1] ^ __builtin_amdgcn_alignbit(Aw[2 * w + 2], Aw[2 * w + 1], r2);
-            M[w] = compress16(x0 | (x0 >> 1)) | (compress16(x1 | (x1 >> 1)) << 16);
-            if (read_has_n) M[w] |= s_rn[w];
-            if (L.has_n) {                         // allele N bits for allele bases 32w+d .. 32w+d+31
-                int gg = 32 * w + d; int nq = gg >> 5, nr = gg & 31;
-                AN[w] = __builtin_amdgcn_alignbit(nmask_word(E, L, nq + 1, a_local), nmask_word(E, L, nq, a_local), nr);
-                M[w] |= AN[w];
-            }
-            int lo_i = i0 - 32 * w; lo_i = lo_i < 0 ? 0 : (lo_i > 32 ? 32 : lo_i);
-            int hi_i = i1 - 32 * w; hi_i = hi_i < 0 ? 0 : (hi_i > 32 ? 32 : hi_i);
-            u32 vm = (hi_i >= 32 ? 0xFFFFFFFFu : ((1u << hi_i) - 1u)) & ~(lo_i >= 32 ? 0xFFFFFFFFu : ((1u << lo_i) - 1u));
-            M[w] &= vm;
-            mm_total += __popc(M[w]);
-        }
-    }
-    // Kadane over the mismatch positions.  The penalty is the read's default (Phred 40) except where s_odd / the
-    // allele N mask says otherwise, so the LDS lookup stays out of the dependent chain.
-    int cur = P0, best = P0, cs = i0, last = i0, blen = 0, bend = i0;
-    const int PD = (pen_def << MLST_P_SHIFT) + 1;
-    #pragma unroll
-    for (int w = 0; w < NW / 2; w++) {
-        if (w * 2 < nw) {
-            u32 Mw = M[w];
-            const u32 special = s_odd[w] | AN[w];
-            while (Mw) {
-                int bit = __ffs(Mw) - 1; Mw &= Mw - 1;
-                int i = 32 * w + bit;
-                cur += (i - last) * MA;
-                if (cur > best) { best = cur; blen = i - cs; bend = i; }
-                int dec = PD;
-                if ((special >> bit) & 1u) dec = ((((AN[w] >> bit) & 1u) ? P.n_penalty : (int)s_pen[i]) << MLST_P_SHIFT) + 1;
-                cur -= dec;
-                if (cur <= P0) { cur = P0; cs = i + 1; }
-                last = i + 1;
-            }
-        }
-    }
-    cur += (i1 - last) * MA;
-    if (cur > best) { best = cur; blen = i1 - cs; bend = i1; }
-    be = bend; bs = bend - blen;
-    return best;
-}
-// ---- bit-plane form of the same alignment (k_extend).  A base is two bits; kept as two planes of 32 bases per
+// ---- Ungapped local alignment in bit-plane form (k_extend).  A base is two bits; kept as two planes of 32 bases per
 // word (low bits, high bits), the mismatch mask of 32 columns is (rl ^ al) | (rh ^ ah): no bit gathering, and the
 // read planes come straight out of ballots.  k_extend is VALU-bound (a wave64 VALU op takes 4 cycles on a SIMD16),
 // so what counts here is instructions per (read, allele) pair.
@@ -1463,7 +1364,7 @@ __device__ inline u32 ld_row(GP<const u32>::G* row, u32 byte_off) {
 }
 
 // NB = 32-base read blocks the instantiation supports.  TRACK = also report the aligned span [bs, be) (only the
-// gap-trigger policy needs it, and only for pairs with many mismatches).  Value-identical to ungapped<>.
+// gap-trigger policy needs it, and only for pairs with many mismatches).  Same recurrence as oracle align_ungapped (Kadane over the mismatch columns).
 // rl/rh/od/rn = read planes, non-default-penalty mask and N mask, block-uniform (scalar registers); s_pen stays in LDS
 // because they are needed only for reads with N / for the rare non-default penalty.
 template <int NB, bool TRACK, bool HASN>
@@ -1910,13 +1811,21 @@ __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep
 __global__ __launch_bounds__(256) void k_accumulate(const EngineDev* __restrict__ Ep, KParams P) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     // items k_extend could not finish: reads with several work items, or pairs that went through the banded SW
-    __shared__ u32 s_red[4][4];
+    // (they are few: the states of 256 items are read at once and the open ones listed, instead of one dependent
+    // state load per item and block)
+    __shared__ u32 s_red[4][4]; __shared__ u32 s_list[256]; __shared__ u32 s_nlist;
     const int tid = threadIdx.x;
     u64 c_tot = 0, c_ign = 0, c_dp = 0;
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
-    for (u64 ii = begin + blockIdx.x; ii < end; ii += gridDim.x) {
+    for (u64 i0 = begin + (u64)blockIdx.x * 256; i0 < end; i0 += (u64)gridDim.x * 256) {
+      if (tid == 0) s_nlist = 0;
+      __syncthreads();
+      if (i0 + tid < end && !(E.item_state[i0 + tid] & IS_DONE)) s_list[atomicAdd(&s_nlist, 1u)] = (u32)tid;
+      __syncthreads();
+      const u32 n_open = s_nlist;
+      for (u32 q = 0; q < n_open; q++) {
+        const u64 ii = i0 + s_list[q];
         u8 state = E.item_state[ii];
-        if (state & IS_DONE) continue;
         ItemDev it = E.items[ii];
         const LocusDev L = E.loci[it.locus];
         if (it.res_off + L.n_pad > E.cap_res) continue;
@@ -1945,6 +1854,8 @@ __global__ __launch_bounds__(256) void k_accumulate(const EngineDev* __restrict_
             c_tot += T; c_ign += I; c_dp += D;
             E.item_state[ii] = (u8)(state | IS_DONE | (A ? IS_ACC : 0));
         }
+      }
+      __syncthreads();
     }
     if (tid == 0) {
         if (c_tot) atomicAdd(&E.ctr->cnt[MLST_CNT_TOTAL_RECORDS], c_tot);
@@ -1957,40 +1868,49 @@ __global__ __launch_bounds__(256) void k_accumulate(const EngineDev* __restrict_
 // same locus inside a wave are combined before touching the per-locus words.  The dictionary holds ONE length per
 // (locus, QNAME) -- that of the last accepted record (Q3) -- so a read that matches both strands of a locus counts once,
 // and of two mates that share a QNAME (paired) the second one's length replaces the first one's.
-__global__ __launch_bounds__(256) void k_locus(const EngineDev* __restrict__ Ep, int paired) {
+// The per-locus words are hot: an isolate's items sit on 7 of them, a metagenome's on ~140, and 2 x 121 k device atomics
+// on those few addresses were the kernel (61 of 76 us on cfg3).  Items are first combined in an LDS table per workgroup
+// (1024 items wide: one sweep of 128 workgroups covers cfg3), and each workgroup then touches every locus it saw once.
+#define LOCUS_LT 1024
+__global__ __launch_bounds__(1024) void k_locus(const EngineDev* __restrict__ Ep, int paired) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
-    const int lane = threadIdx.x & 63;
+    __shared__ u32 s_key[LOCUS_LT]; __shared__ u64 s_sum[LOCUS_LT]; __shared__ u64 s_first[LOCUS_LT];
+    for (u32 i = threadIdx.x; i < LOCUS_LT; i += blockDim.x) { s_key[i] = 0xFFFFFFFFu; s_sum[i] = 0; s_first[i] = ~0ull; }
+    __syncthreads();
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
-    for (u64 i0 = begin + (u64)blockIdx.x * 256; i0 < end; i0 += (u64)gridDim.x * 256) {
+    for (u64 i0 = begin + (u64)blockIdx.x * blockDim.x; i0 < end; i0 += (u64)gridDim.x * blockDim.x) {
         u64 ii = i0 + threadIdx.x;
-        bool acc = false, counts = false; u32 locus = 0; u64 n = 0, ridx = ~0ull;
-        if (ii < end && (E.item_state[ii] & IS_ACC)) {
-            ItemDev it = E.items[ii];
-            acc = true; counts = true; locus = it.locus; n = (u64)(E.ret_len[it.ret] & 0x7FFFu); ridx = E.ret_ridx[it.ret];
-            // an earlier item of the same read on the same locus (the other strand) already stands for this QNAME
-            const u64 first = E.ret_item0[it.ret];
-            for (u64 j = first; j < ii; j++) if (E.items[j].locus == locus && (E.item_state[j] & IS_ACC)) counts = false;
-            if (counts && paired && !(ridx & 1ull)) {      // first mate: superseded when the second mate has an accepted record here
-                const u32 ms = E.ret_mate[it.ret];
-                if (ms != 0xFFFFFFFFu) {
-                    const u64 m0 = E.ret_item0[ms], m1 = m0 + E.ret_nitems[ms];
-                    for (u64 j = m0; j < m1; j++) if (E.items[j].locus == locus && (E.item_state[j] & IS_ACC)) counts = false;
-                }
+        if (!(ii < end && (E.item_state[ii] & IS_ACC))) continue;
+        ItemDev it = E.items[ii];
+        bool counts = true; const u32 locus = it.locus; const u64 n = (u64)(E.ret_len[it.ret] & 0x7FFFu), ridx = E.ret_ridx[it.ret];
+        // an earlier item of the same read on the same locus (the other strand) already stands for this QNAME
+        const u64 first = E.ret_item0[it.ret];
+        for (u64 j = first; j < ii; j++) if (E.items[j].locus == locus && (E.item_state[j] & IS_ACC)) counts = false;
+        if (counts && paired && !(ridx & 1ull)) {      // first mate: superseded when the second mate has an accepted record here
+            const u32 ms = E.ret_mate[it.ret];
+            if (ms != 0xFFFFFFFFu) {
+                const u64 m0 = E.ret_item0[ms], m1 = m0 + E.ret_nitems[ms];
+                for (u64 j = m0; j < m1; j++) if (E.items[j].locus == locus && (E.item_state[j] & IS_ACC)) counts = false;
             }
         }
-        // lanes of the same locus are combined before the per-locus words are touched -- for the first few loci of the wave
-        // (an isolate's items all sit on 7 loci); a metagenome's wave holds dozens of loci, and combining them one locus at
-        // a time was the kernel (114 us on cfg3): what is left after four rounds goes to the words lane by lane
-        u64 todo = __ballot(acc);
-        for (int round = 0; round < 4 && todo; round++) {
-            int src = __ffsll((long long)todo) - 1;
-            u32 L0 = __shfl(locus, src);
-            bool in = acc && locus == L0;
-            u64 grp = __ballot(in); todo &= ~grp;
-            u64 sum = wave_sum_u64(in && counts ? n : 0ull), mn = wave_min_u64(in ? ridx : ~0ull);
-            if (lane == src) { atomicAdd(&E.locus_len[L0], sum); atomicMin(&E.locus_first[L0], mn); }
+        u32 slot = (locus * 0x9E3779B1u) >> 22;
+        bool placed = false;
+        for (int probe = 0; probe < 8 && !placed; probe++) {
+            const u32 prev = atomicCAS(&s_key[slot], 0xFFFFFFFFu, locus);
+            if (prev == 0xFFFFFFFFu || prev == locus) {
+                if (counts) atomicAdd((unsigned long long*)&s_sum[slot], (unsigned long long)n);
+                atomicMin((unsigned long long*)&s_first[slot], (unsigned long long)ridx);
+                placed = true;
+            } else slot = (slot + 1) & (LOCUS_LT - 1);
         }
-        if ((todo >> lane) & 1ull) { if (counts) atomicAdd(&E.locus_len[locus], n); atomicMin(&E.locus_first[locus], ridx); }
+        if (!placed) { if (counts) atomicAdd(&E.locus_len[locus], n); atomicMin(&E.locus_first[locus], ridx); }     // table crowded
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < LOCUS_LT; i += blockDim.x) {
+        const u32 locus = s_key[i];
+        if (locus == 0xFFFFFFFFu) continue;
+        if (s_sum[i]) atomicAdd(&E.locus_len[locus], s_sum[i]);
+        atomicMin(&E.locus_first[locus], s_first[i]);
     }
 }
 
@@ -2014,43 +1934,163 @@ __device__ inline void pile_base(const EngineDev& E, const KParams& P, const Ite
     atomicAdd(&counts[(colbase + (u64)j) * 4 + b], 1u);
 }
 
-__global__ __launch_bounds__(64) void k_pileup(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen,
-                                               const u64* __restrict__ locus_colbase, u32* __restrict__ counts,
-                                               u64* __restrict__ pl_list) {
+// Two phases per batch of 64 items.
+//  (1) one LANE per item: the item's descriptors, its single ungapped alignment against the chosen allele of its locus
+//      (value-identical to ungapped_planes<., true, .>), the gap-trigger policy and the tag filter.  The read stays in
+//      source order; for the reverse strand it is the allele window that is fetched mirrored (words in descending order,
+//      bit-reversed, complemented), and the Kadane pass walks the mismatches from the top bit down.
+//  (2) one WAVE per item that passed: its aligned columns are piled up 64 at a time.
+// The first version staged every read in LDS and had all 64 lanes evaluate the same alignment: ~700 instructions per item,
+// issue-bound at 207 us on cfg3 (8 waves per SIMD x 15 items each).
+template <int NB>
+__device__ __forceinline__ void pileup_body(const EngineDev* __restrict__ Ep, const KParams& P, const int* __restrict__ locus_chosen,
+                                            const u64* __restrict__ locus_colbase, u32* __restrict__ counts, u64* __restrict__ pl_list) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
-    // one wave per item: the 64 lanes stage the oriented read together, every lane evaluates the (single)
-    // ungapped alignment redundantly, then the aligned columns are piled up 64 at a time
-    __shared__ u32 s_rw[RW + 2]; __shared__ u32 s_rn[RW / 2 + 1]; __shared__ u32 s_odd[RW / 2 + 1]; __shared__ u8 s_pen[RQ]; __shared__ u8 s_q[RQ]; __shared__ u8 s_pentab[128];
+    __shared__ u8 s_pentab[128];
     const int lane = threadIdx.x;
     for (int i = lane; i < 128; i += 64) s_pentab[i] = E.pen_tab[i];
+    __syncthreads();
     const u64 end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
-    for (u64 ii = blockIdx.x; ii < end; ii += gridDim.x) {
-        ItemDev it = E.items[ii];
-        int ca = locus_chosen[it.locus];
-        if (ca < 0) continue;                                   // block-uniform
-        const LocusDev L = E.loci[it.locus];
-        u32 a = (u32)ca - L.a_begin;
-        u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu);
-        __syncthreads();
-        stage_read(E, P, it, n, s_rw, s_rn, s_odd, s_pen, s_q, s_pentab, lane, 64);
-        if (lane == 0) { s_rw[RW] = s_rw[RW + 1] = 0; }
-        __syncthreads();
-        int m = (int)E.allele_len[ca];
-        int mm, bs, be;
-        int best = ungapped<RW>(E, P, L, a, m, n, it.diag, s_rw, s_rn, s_odd, s_pen, (int)s_pentab[40], (lw & 0x8000u) != 0, mm, bs, be);
-        int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF);
-        int floor_n = E.floor_tab[n];
-        bool need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
-        if (need_dp) { if (lane == 0) { u64 slot = atomicAdd(&E.ctr->n_pl_dp, 1ull); pl_list[slot] = ii; } continue; }
-        if (score < floor_n || score <= 0 || score < P.minscore || xm > P.max_xm) continue;   // BAM_tagFilter AS, XM
-        u64 colbase = locus_colbase[it.locus];
-        for (int i = bs + lane; i < be; i += 64) {
-            u8 qb = s_q[i];
-            if ((qb & 0x80) || (int)(qb & 0x7F) < P.minqual) continue;
-            u32 b = (s_rw[i >> 4] >> (2 * (i & 15))) & 3u;
-            atomicAdd(&counts[(colbase + (u64)(i + it.diag)) * 4 + b], 1u);
+    constexpr int NI = (32 * NB + 63) / 64;                            // sweeps of 64 columns that cover one read
+    const int MA = P.match_bonus << MLST_P_SHIFT;
+    for (u64 base = blockIdx.x; base < end; base += (u64)gridDim.x * 64) {       // the item of lane k: base + k * gridDim.x
+        const u64 my = base + (u64)lane * gridDim.x;
+        u32 f_ret = 0, f_strand = 0; int f_diag = 0, f_n = 0, f_bs = 0, f_be = 0; u64 f_col = 0; bool f_pile = false;
+        if (my < end) {
+            const ItemDev it = E.items[my];
+            const int ca = locus_chosen[it.locus];
+            if (ca >= 0) {
+                const LocusDev L = E.loci[it.locus];
+                const u32 lw = E.ret_len[it.ret];
+                const int n = (int)(lw & 0x7FFFu), d = it.diag; const bool read_has_n = (lw & 0x8000u) != 0, rev = it.strand != 0;
+                const int m = (int)E.allele_len[ca]; const int floor_n = E.floor_tab[n];
+                f_ret = it.ret; f_strand = it.strand; f_diag = d; f_n = n; f_col = locus_colbase[it.locus];
+                const u32 a = (u32)ca - L.a_begin;
+                auto rb = E.ret_bases.g() + (u64)it.ret * RW;
+                auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
+                // allele window: block w of the read (source positions 32w..32w+31) meets allele bits pbit - 32w .. +31 going
+                // down (reverse) or pbit + 32w .. +31 going up (forward); NB + 1 consecutive words cover all blocks
+                const int pbit = rev ? n + d - 32 : d;
+                const int q0 = pbit >> 5, r = pbit & 31, qlow = rev ? q0 - (NB - 1) : q0;
+                auto pbase = E.planes.g() + L.plane_off; auto nbase = E.nmask.g() + L.nmask_off;
+                u32 Wl[NB + 1], Wh[NB + 1], Wn[NB + 1];
+                #pragma unroll
+                for (int t = 0; t <= NB; t++) {
+                    const int q = qlow + t; const u32 qc = (u32)(q < 0 ? 0 : (q >= (int)L.pblocks ? (int)L.pblocks - 1 : q));
+                    Wl[t] = pbase[(u64)(2u * qc) * L.n_pad + a]; Wh[t] = pbase[(u64)(2u * qc + 1u) * L.n_pad + a];
+                    Wn[t] = 0;
+                    if (L.has_n) Wn[t] = nbase[(u64)qc * L.n_pad + a];
+                }
+                u32 xw[2 * NB];
+                #pragma unroll
+                for (int w = 0; w < 2 * NB; w++) xw[w] = rb[w];
+                tie_all<NB + 1>(Wl); tie_all<NB + 1>(Wh); tie_all<2 * NB>(xw);
+                // columns of the overlap, in source coordinates
+                const int i0 = d < 0 ? -d : 0, i1 = (m - d) < n ? (m - d) : n;
+                const int slo = rev ? n - i1 : i0, shi = rev ? n - i0 : i1;
+                u32 M[NB], AN[NB]; int mm = 0;
+                #pragma unroll
+                for (int w = 0; w < NB; w++) {
+                    const u32 rl = compress16(xw[2 * w]) | (compress16(xw[2 * w + 1]) << 16);
+                    const u32 rh = compress16(xw[2 * w] >> 1) | (compress16(xw[2 * w + 1] >> 1) << 16);
+                    const int t = rev ? NB - 1 - w : w;
+                    u32 al = __builtin_amdgcn_alignbit(Wl[t + 1], Wl[t], r), ah = __builtin_amdgcn_alignbit(Wh[t + 1], Wh[t], r);
+                    u32 an = __builtin_amdgcn_alignbit(Wn[t + 1], Wn[t], r);
+                    if (rev) { al = ~__brev(al); ah = ~__brev(ah); an = __brev(an); }
+                    AN[w] = an;
+                    u32 rn = 0;
+                    if (read_has_n) {                                   // rare: N positions of the read, from the quality rows
+                        for (int k = 0; k < 32; k++) { const int sp = 32 * w + k; if (sp < n && (rq[sp] & 0x80)) rn |= 1u << k; }
+                    }
+                    int lo_i = slo - 32 * w; lo_i = lo_i < 0 ? 0 : (lo_i > 32 ? 32 : lo_i);
+                    int hi_i = shi - 32 * w; hi_i = hi_i < 0 ? 0 : (hi_i > 32 ? 32 : hi_i);
+                    const u32 vm = (hi_i >= 32 ? 0xFFFFFFFFu : ((1u << hi_i) - 1u)) & ~(lo_i >= 32 ? 0xFFFFFFFFu : ((1u << lo_i) - 1u));
+                    M[w] = ((al ^ rl) | (ah ^ rh) | rn | an) & vm;
+                    mm += __popc(M[w]);
+                }
+                int cur = P0, best = P0, cs = i0, last = i0, blen = 0, bend = i0;
+                if (i1 > i0) {
+                    // one mismatch at oriented position i (source position sp, bit `bit` of block w)
+                    auto step = [&](int i, int sp, u32 an_bit) {
+                        cur += (i - last) * MA;
+                        if (cur > best) { best = cur; blen = i - cs; bend = i; }
+                        int pen = P.n_penalty;
+                        if (!an_bit) { const u8 qb = rq[sp]; if (!(qb & 0x80)) pen = (int)s_pentab[qb & 0x7F]; }
+                        cur -= (pen << MLST_P_SHIFT) + 1;
+                        if (cur <= P0) { cur = P0; cs = i + 1; }
+                        last = i + 1;
+                    };
+                    if (!rev) {
+                        #pragma unroll
+                        for (int w = 0; w < NB; w++) {
+                            u32 Mw = M[w];
+                            while (Mw) { const int bit = __ffs(Mw) - 1; Mw &= Mw - 1; step(32 * w + bit, 32 * w + bit, (AN[w] >> bit) & 1u); }
+                        }
+                    } else {
+                        #pragma unroll
+                        for (int w = NB - 1; w >= 0; w--) {
+                            u32 Mw = M[w];
+                            while (Mw) { const int bit = 31 - __clz(Mw); Mw &= ~(1u << bit); step(n - 1 - (32 * w + bit), 32 * w + bit, (AN[w] >> bit) & 1u); }
+                        }
+                    }
+                    cur += (i1 - last) * MA;
+                    if (cur > best) { best = cur; blen = i1 - cs; bend = i1; }
+                }
+                const int be = bend, bs = bend - blen;
+                const int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF);
+                if (gap_trigger(P, mm, xm, score, floor_n, m, n, d, bs, be)) { const u64 slot = atomicAdd(&E.ctr->n_pl_dp, 1ull); pl_list[slot] = my; }
+                else if (!(score < floor_n || score <= 0 || score < P.minscore || xm > P.max_xm)) {      // BAM_tagFilter AS, XM
+                    f_pile = be > bs; f_bs = bs; f_be = be;
+                }
+            }
+        }
+        // ---- phase 2: the wave piles up the columns of one item after the other; the rows of the next item are requested
+        // before the atomics of this one go out (on gfx9 the loads behind an atomic wait for its acknowledgement)
+        u64 todo = __ballot(f_pile);
+        u32 qv[NI], wv[NI]; int c_n = 0, c_bs = 0, c_be = 0, c_d = 0; u32 c_strand = 0; u64 c_col = 0;
+        auto fetch = [&](int k) {
+            c_n = __builtin_amdgcn_readlane(f_n, k); c_bs = __builtin_amdgcn_readlane(f_bs, k); c_be = __builtin_amdgcn_readlane(f_be, k);
+            c_d = __builtin_amdgcn_readlane(f_diag, k); c_strand = (u32)__builtin_amdgcn_readlane((int)f_strand, k);
+            c_col = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)f_col, k) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(f_col >> 32), k) << 32);
+            const u32 ret = (u32)__builtin_amdgcn_readlane((int)f_ret, k);
+            auto rb = E.ret_bases.g() + (u64)ret * RW; auto rq = E.ret_quals.g() + (u64)ret * RQ;
+            #pragma unroll
+            for (int t = 0; t < NI; t++) {
+                const int i = c_bs + 64 * t + lane; qv[t] = 0x80u; wv[t] = 0;
+                if (i < c_be) { const int sp = c_strand ? c_n - 1 - i : i; qv[t] = rq[sp]; wv[t] = rb[sp >> 4]; }
+            }
+        };
+        if (todo) { const int k = __ffsll((long long)todo) - 1; todo &= todo - 1; fetch(k); }
+        else continue;
+        for (;;) {                                                      // block-uniform
+            u32 q0v[NI], w0v[NI];
+            #pragma unroll
+            for (int t = 0; t < NI; t++) { q0v[t] = qv[t]; w0v[t] = wv[t]; }
+            const int p_n = c_n, p_bs = c_bs, p_be = c_be, p_d = c_d; const u32 p_strand = c_strand; const u64 p_col = c_col;
+            const bool more = todo != 0;
+            if (more) { const int k = __ffsll((long long)todo) - 1; todo &= todo - 1; fetch(k); }
+            #pragma unroll
+            for (int t = 0; t < NI; t++) {
+                const int i = p_bs + 64 * t + lane;
+                if (i >= p_be) continue;
+                const u32 qb = q0v[t];
+                if ((qb & 0x80u) || (int)(qb & 0x7Fu) < P.minqual) continue;
+                const int sp = p_strand ? p_n - 1 - i : i;
+                u32 b = (w0v[t] >> (2 * (sp & 15))) & 3u; if (p_strand) b ^= 3u;
+                atomicAdd(&counts[(p_col + (u64)(i + p_d)) * 4 + b], 1u);
+            }
+            if (!more) break;
         }
     }
+}
+// reads up to 160 bases / up to MLST_MAX_READ_LEN (the host knows the longest row width submitted for the sample)
+__global__ __launch_bounds__(64) void k_pileup_160(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen,
+                                                   const u64* __restrict__ locus_colbase, u32* __restrict__ counts, u64* __restrict__ pl_list) {
+    pileup_body<5>(Ep, P, locus_chosen, locus_colbase, counts, pl_list);
+}
+__global__ __launch_bounds__(64) void k_pileup_320(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen,
+                                                   const u64* __restrict__ locus_colbase, u32* __restrict__ counts, u64* __restrict__ pl_list) {
+    pileup_body<RW / 2>(Ep, P, locus_chosen, locus_colbase, counts, pl_list);
 }
 
 __global__ __launch_bounds__(64) void k_pileup_dp(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen,
@@ -2262,6 +2302,7 @@ struct mlst_handle {
     u8* d_in_bases = nullptr; u8* d_in_quals = nullptr; u64* d_in_off = nullptr; u64 cap_in_bytes = 0, cap_in_reads = 0;
     u32* d_packed = nullptr; u8* d_qrows = nullptr; u16* d_lens = nullptr; u64 cap_packed_words = 0, cap_qrow_bytes = 0, cap_lens = 0;
     u64 reads_seen = 0;
+    u32 max_wpr = 0;                             // widest read rows submitted since the last reset (picks the k_pileup instantiation)
     int ext_threads = 256, ext_blocks = 1024;    // k_extend launch shape (set in mlst_load_reference)
     int sieve_g_blocks = 256 * 5;                // k_sieve_q<.,false> grid (MLST_SIEVE_BLOCKS overrides it)
     u8* d_fq_text = nullptr;                    // the text buffer of the chunk being parsed: one of d_fq_slot[] (not owned)
@@ -2450,7 +2491,7 @@ static inline int base_code(u8 c) {
 static int reset_sample_state(mlst_handle* h) {
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, h->stats_zero_bytes, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_stats + h->off_first, 0xFF, h->stats_bytes - h->off_first, h->stream));
-    h->reads_seen = 0; h->fq_carry_len = 0;
+    h->reads_seen = 0; h->fq_carry_len = 0; h->max_wpr = 0;
     return MLST_OK;
 }
 
@@ -2885,6 +2926,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     if (paired && ((n_reads | h->reads_seen) & 1ull)) return fail(h, MLST_E_INVALID, "paired submissions hold whole pairs (reads 2k, 2k+1) and start at an even read index");
     if (h->cap_cand < n_reads) { hipStreamSynchronize(h->stream); hipFree(h->d_cand); h->d_cand = nullptr; HIPCHK(h, dmalloc(&h->d_cand, n_reads)); h->cap_cand = n_reads; }
     EngineDev& E = h->E;
+    if (wpr > h->max_wpr) h->max_wpr = wpr;
     if (h->sieve_kind == MLST_SIEVE_ROUTED) { int rc = ensure_route_buffers(h, n_reads, wpr); if (rc) return rc; }
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
                                                (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand,
@@ -2926,17 +2968,17 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       }
     }
     { Prof pf(h, 1);
-      hipLaunchKernelGGL(k_seed, dim3(512), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand, paired);
+      hipLaunchKernelGGL(k_seed, dim3(1024), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand, paired);
       // (one pair of reads per workgroup and sweep, every sweep a chain of dependent scattered loads: a large grid keeps the
       // sweeps few -- 1024 workgroups took 59 sweeps = 112 us for the 121 k retained reads of cfg3)
-      hipLaunchKernelGGL(k_retain, dim3(16384), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
+      hipLaunchKernelGGL(k_retain, dim3(2048), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
     { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
       const int thr = h->ext_threads, blocks = h->ext_blocks;
       if (wpr <= 10) hipLaunchKernelGGL(k_extend_160, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
       else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
-      hipLaunchKernelGGL(k_locus, dim3(1024), dim3(256), 0, h->stream, h->d_E, paired); }
+      hipLaunchKernelGGL(k_locus, dim3(128), dim3(1024), 0, h->stream, h->d_E, paired); }
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, h->stream, E.ctr, n_reads);
     if (gs == 2) { int rc = graph_leave(h, h->g_submit); if (rc) return rc; }
     HIPCHK(h, hipGetLastError());
@@ -3253,7 +3295,8 @@ static int pileup_launch(mlst_handle* h, const uint32_t* chosen, uint32_t n, uin
     HIPCHK(h, hipMemsetAsync(&h->E.ctr.p->n_pl_dp, 0, 8, h->stream));
     const int* d_lc = (const int*)((u8*)h->d_locus_colbase + nl * 8);
     { Prof pf(h, 5);
-      hipLaunchKernelGGL(k_pileup, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list);
+      if (h->max_wpr <= 10) hipLaunchKernelGGL(k_pileup_160, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list);
+      else hipLaunchKernelGGL(k_pileup_320, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list);
       hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, d_lc, h->d_locus_colbase, d_counts, h->d_pl_list, h->d_tb); }
     HIPCHK(h, hipGetLastError());
     return MLST_OK;
@@ -3384,7 +3427,8 @@ extern "C" int mlst_typing_choose_pileup(mlst_handle* h, int32_t penalty, uint32
     HIPCHK(h, hipMemsetAsync(&h->E.ctr.p->n_pl_dp, 0, 8, h->stream));
     { Prof pf(h, 5);
       // one wave per item, 64 VGPRs: 8192 waves fill the chip's wave slots (4096 left half of them empty: 224 us on cfg3)
-      hipLaunchKernelGGL(k_pileup, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list);
+      if (h->max_wpr <= 10) hipLaunchKernelGGL(k_pileup_160, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list);
+      else hipLaunchKernelGGL(k_pileup_320, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list);
       hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list, h->d_tb); }
     HIPCHK(h, hipGetLastError());
     return MLST_OK;
@@ -3405,7 +3449,7 @@ extern "C" int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_cha
 extern "C" int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);
-    const int gs = graph_enter(h, h->g_typing, {(u64)(u32)penalty, (u64)mincov, (u64)(u8)none_char});
+    const int gs = graph_enter(h, h->g_typing, {(u64)(u32)penalty, (u64)mincov, (u64)(u8)none_char, (u64)(h->max_wpr <= 10)});
     if (gs == 1) { h->auto_pending = true; return MLST_OK; }
     int rc = mlst_typing_choose_pileup(h, penalty, nullptr);
     if (!rc) rc = mlst_typing_finish(h, mincov, none_char, nullptr);
