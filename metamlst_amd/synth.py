@@ -288,14 +288,48 @@ def rows_to_tiled(rows, torch):
     return torch.cat([t, torch.zeros(4, dtype=rows.dtype, device=rows.device)])
 
 
-def metagenome_plan(sdb: SynthDB, n_genomes: int, seed: int = 5):
+def _told_apart(seqs: dict[int, bytes], allele: int, margin: int) -> bool:
+    """True when `allele` differs from every other allele of its locus (of the same length) in a column at least `margin`
+    columns away from both ends."""
+    me = np.frombuffer(seqs[allele], np.uint8)
+    inner = me[margin:len(me) - margin]
+    for other, sq in seqs.items():
+        if other == allele or len(sq) != len(me):
+            continue
+        if np.array_equal(np.frombuffer(sq, np.uint8)[margin:len(me) - margin], inner):
+            return False
+    return True
+
+
+def metagenome_plan(sdb: SynthDB, n_genomes: int, seed: int = 5, margin: int = 8):
     """cfg3 of SURVEY.md 8(d): which species are in the mixture, their log-normal abundances and the ST planted in
-    each.  -> [(species, abundance fraction, st_row)]; the same for every batch and rank (pure function of the seed)."""
+    each.  -> [(species, abundance fraction, st_row)]; the same for every batch and rank (pure function of the seed and the
+    database).  The planted ST of species k is the first profile row from k on whose seven alleles are told apart from every
+    other allele of their locus by an interior column: a local aligner soft-clips a mismatch in the outermost ~4 columns, so
+    two alleles that differ only there get the same records, the lower allele number wins the tie (metamlst.py:244) and the
+    uncovered end column is filled from it -- the reference itself cannot recover such a planted ST (whole-batch check against
+    the oracle: profiles/round2/check_batch.json)."""
     rng = np.random.default_rng(seed)
     chosen = list(rng.choice(len(sdb.species), size=min(n_genomes, len(sdb.species)), replace=False))
     ab = rng.lognormal(0.0, 1.0, size=len(chosen))
     ab /= ab.sum()
-    return [(sdb.species[int(si)], float(fr), k % len(sdb.profiles[sdb.species[int(si)]])) for k, (si, fr) in enumerate(zip(chosen, ab))]
+    conn = sqlite3.connect(sdb.path)
+    plan = []
+    for k, (si, fr) in enumerate(zip(chosen, ab)):
+        sp = sdb.species[int(si)]
+        prof = sdb.profiles[sp]
+        seqs: dict[str, dict[int, bytes]] = {g: {} for g, _ in sdb.loci[sp]}
+        for gene, no, sq in conn.execute("SELECT gene, alleleVariant, sequence FROM alleles WHERE bacterium=?", (sp,)):
+            seqs[gene][int(no)] = sq.encode()
+        row = k % len(prof)
+        for r in range(len(prof)):
+            cand = (k + r) % len(prof)
+            if all(_told_apart(seqs[g], int(a), margin) for (g, _), a in zip(sdb.loci[sp], prof[cand])):
+                row = cand
+                break
+        plan.append((sp, float(fr), row))
+    conn.close()
+    return plan
 
 
 def make_metagenome_gpu(eng, torch, device, sdb: SynthDB, plan, n_reads: int, genome_size: int, seed: int, read_len: int = 150,
