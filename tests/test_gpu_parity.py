@@ -565,3 +565,22 @@ def test_read_lengths_from_36_to_300_through_every_sieve(monkeypatch, kind):
         s, _ = run_both(eng, orc, fb, fq, off)
         if L >= 75:
             assert int(s.counters[4]) > 0
+            if kind == "lds":
+                check_pileup(eng, orc, idx, s)      # k_pileup_160 for rows up to 160 bases, k_pileup_320 beyond
+
+
+def test_loci_longer_than_1024_columns(tmp_path):
+    """k_pileup keeps the counters of one locus in LDS: loci up to 1,024 columns and up to MLST_MAX_ALLELE_LEN (4,095) are
+    separate instantiations.  Three long loci, both row widths, against the oracle (statistics, items, pile-up, consensus)."""
+    from metamlst_amd.index import load_index
+    db = synth.make_db(str(tmp_path / "long.db"), {"lg": [("g0", 1500), ("g1", 3000), ("g2", 4095)]}, alleles_per_locus=12, n_profiles=6)
+    idx = load_index(db.path)
+    g, _ = synth.make_genome(db, "lg", db.profiles["lg"][2], size=80_000)
+    eng, orc = both(idx)
+    for L in (150, 300):
+        b, q = synth.sample_reads(g, 12000, read_len=L, seed=L)
+        fb, fq, off = synth.flatten_reads(b, q)
+        s, _ = run_both(eng, orc, fb, fq, off)
+        assert int(s.counters[0]) > 1000
+        chosen, pc = check_pileup(eng, orc, idx, s)
+        assert len(chosen) == 3 and all(int(pc[a].sum()) > 0 for a in chosen)
