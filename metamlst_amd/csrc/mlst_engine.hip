@@ -1093,14 +1093,22 @@ __global__ __launch_bounds__(256) void k_pack_text(const u8* __restrict__ text, 
 // ------------------------------------------------------------------ K2: exact seeds -> work items
 struct Bin { u32 locus; int diag; u16 strand, votes; };
 
+// Linear probing, four slots per round trip: a wave walks for its worst lane (about a dozen slots among the 640 look-ups of
+// a wave at load 0.5).  Variant builds cut after each stage put k_seed's 132 us on cfg3 at ~15 rows / 12 home slots / 43 values
+// and walks / 4 votes / ~55 item emission: every stage is a level of ~2.5 M scattered requests, not a latency chain.
 __device__ inline bool table_find(const EngineDev& E, u32 lo, u32 hi, u32& val) {
-    u64 key = (u64)lo | ((u64)hi << 32);
+    const u64 key = (u64)lo | ((u64)hi << 32);
     u32 h = table_hash(lo, hi) & E.table_mask;
-    for (u32 step = 0; step <= E.table_mask; step++) {
-        u64 k = E.keys[h];
-        if (k == key) { val = E.vals[h]; return true; }
-        if (k == KEY_EMPTY) return false;
-        h = (h + 1) & E.table_mask;
+    for (u64 step = 0; step <= (u64)E.table_mask; step += 4) {
+        u64 k[4];
+        #pragma unroll
+        for (int j = 0; j < 4; j++) k[j] = E.keys[(h + (u32)j) & E.table_mask];
+        #pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (k[j] == key) { val = E.vals[(h + (u32)j) & E.table_mask]; return true; }
+            if (k[j] == KEY_EMPTY) return false;
+        }
+        h = (h + 4) & E.table_mask;
     }
     return false;
 }
