@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Engine against the CPU oracle on WHOLE resident batches of the cfg3 bench workload (GPU box; ~2 min of 256 host threads
+"""Engine against the CPU oracle on WHOLE resident batches of the bench workloads (cfg3, or cfg2 with --workload) (GPU box; ~2 min of 256 host threads
 per batch).  bench.py checks the planted STs on the batch of its last step only and the oracle on a 4 M-read slice; this
 script takes any batch index, types it with the engine, runs the oracle over all of its reads in chunks (the statistics
 are additive) and compares sums, hit counts, first-seen order, pile-up counts and the ST calls.
@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="0,1")
     ap.add_argument("--chunk", type=int, default=4_000_000)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
     a = ap.parse_args()
     import __graft_entry__ as ge
     ge.build()
@@ -41,7 +42,7 @@ def main():
     torch.cuda.set_device(device)
     want = [int(x) for x in a.batches.split(",")]
     tmp = tempfile.mkdtemp(prefix="mlst_chk_")
-    w = bench.build_workload("cfg3", args, lambda: Engine(0), torch, device, 0, max(want) + 1, tmp)
+    w = bench.build_workload(a.workload, args, lambda: Engine(0), torch, device, 0, max(want) + 1, tmp)
     eng = w.engines[0]
     orc = oracle_lib.Oracle(w.idx, threads=os.cpu_count() or 1)
     matcher = EngineMatcher(eng, w.idx)
@@ -94,7 +95,7 @@ def main():
                 for k in p:
                     po[k] = po[k] + p[k]
             sys.stderr.write("batch %d oracle pile-up: %d / %d reads, %.0f s\n" % (b, first + cnt, n_total, time.time() - t0))
-        rec = {"batch": b, "reads": n_total, "engine_s": round(t_eng, 1), "oracle_s": round(time.time() - t0, 1),
+        rec = {"workload": a.workload, "batch": b, "reads": n_total, "engine_s": round(t_eng, 1), "oracle_s": round(time.time() - t0, 1),
                "sum_score_equal": bool(np.array_equal(sg.sum_score, so.sum_score)), "n_hits_equal": bool(np.array_equal(sg.n_hits, so.n_hits)),
                "locus_len_equal": bool(np.array_equal(sg.locus_len_sum, so.locus_len_sum)), "locus_first_equal": bool(np.array_equal(sg.locus_first, so.locus_first)),
                "chosen_equal": ch == cho, "pileup_equal": bool(ch == cho and all(np.array_equal(pg[k], po[k]) for k in ch)),
