@@ -584,3 +584,36 @@ def test_loci_longer_than_1024_columns(tmp_path):
         assert int(s.counters[0]) > 1000
         chosen, pc = check_pileup(eng, orc, idx, s)
         assert len(chosen) == 3 and all(int(pc[a].sum()) > 0 for a in chosen)
+
+
+def test_deep_amplicon_sample_refills_the_pileup_queue():
+    """1.3 M reads that all come from the seven loci: every (locus, slice) workgroup of k_pileup finds more of its own items
+    than its LDS queue takes at once (7 loci x 73 slices, 2,048 entries between two drains) and goes round several times."""
+    db, idx = fx.ecoli_small(20)
+    rng = np.random.default_rng(33)
+    n, L = 1_300_000, 150
+    seqs = [np.frombuffer(idx.sequence(int(idx.locus_begin[l]) + 3).encode(), np.uint8) for l in range(idx.n_loci)]
+    which = rng.integers(0, len(seqs), n)
+    b = np.empty((n, L), np.uint8)
+    for l, sq in enumerate(seqs):
+        rows = np.nonzero(which == l)[0]
+        at = rng.integers(0, len(sq) - L + 1, rows.size)
+        b[rows] = sq[at[:, None] + np.arange(L)[None, :]]
+    comp = np.zeros(256, np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    rev = rng.random(n) < 0.5
+    b[rev] = comp[b[rev][:, ::-1]]
+    q = np.full((n, L), 40 + 33, np.uint8)
+    fb, fq, off = synth.flatten_reads(b, q)
+    p = default_params()
+    p.max_retained_reads = p.max_items = 1_500_000
+    p.max_pair_results = 1_500_000 * 64
+    eng = Engine(0, p)
+    eng.load_reference(idx)
+    orc = oracle_lib.Oracle(idx, p)
+    eng.submit_reads(fb, fq, off)
+    orc.submit_reads(fb, fq, off)
+    s, so = eng.stats(), orc.stats()
+    fx.assert_stats_equal(s, so)
+    assert int(s.counters[4]) == n                    # every read retained
+    check_pileup(eng, orc, idx, s)
