@@ -170,7 +170,7 @@ struct EngineDev {
     GP<Counters> ctr;
     GP<u32> ret_bases; GP<u8> ret_quals; GP<u16> ret_len; GP<u64> ret_ridx; GP<u32> ret_nrec;
     GP<u32> ret_mate; GP<u32> ret_item0; GP<u8> ret_nitems;      // Q3: slot of the mate (or ~0), first work item and number of items of the read
-    GP<ItemDev> items; GP<u8> item_state; GP<u32> item_locus; GP<u32> res; GP<u64> dp_list;
+    GP<ItemDev> items; GP<u8> item_state; GP<u32> res; GP<u64> dp_list;
     u64 cap_ret, cap_items, cap_res, cap_dp;
 };
 
@@ -1250,7 +1250,6 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             itd.strand = items[u].strand; itd.votes = items[u].votes;
             E.items[ib + u] = itd;
             E.item_state[ib + u] = (u8)(no == 1 ? IS_SINGLE : 0);
-            E.item_locus[ib + u] = items[u].locus;         // the loci alone, 4 bytes per item: what k_pileup scans
             ro += np;
         }
     }
@@ -1943,93 +1942,67 @@ __device__ inline void pile_base(const EngineDev& E, const KParams& P, const Ite
     atomicAdd(&counts[(colbase + (u64)j) * 4 + b], 1u);
 }
 
-// One workgroup per (chosen locus, slice of the item list).  The counters of the locus (4 per column) live in LDS and are
-// flushed once at the end: the pile-up is one atomic per aligned base (18 M per cfg3 step), and as device atomics those WERE
-// the kernel -- four structurally different versions around them (LDS-staged reads with 64 redundant lanes, bit planes,
-// batched loads, one lane per item) all ran 190-215 us.  The workgroup
-//  (0) stages the chosen allele (bit planes, N mask) in LDS and scans its slice of the 4-byte locus list for its own items;
-//  (1) one LANE per item found: the single ungapped alignment against the chosen allele (same recurrence as
-//      ungapped_planes<., true, .>), the gap-trigger policy and the tag filter.  The read stays in source order; for the
-//      reverse strand the allele window is taken mirrored (words in descending order, bit-reversed, complemented) and the
-//      Kadane pass walks the mismatches from the top bit down;
-//  (2) one WAVE per item that passed: its aligned columns go to the LDS counters 64 at a time.
-// NB = 32-base blocks of the longest read, MAXL = columns of the longest locus the instantiation holds.
-template <int NB, int MAXL>
-__device__ __forceinline__ void pileup_locus_body(const EngineDev* __restrict__ Ep, const KParams& P, const int* __restrict__ locus_chosen,
-                                                  const u64* __restrict__ locus_colbase, u32* __restrict__ counts, u64* __restrict__ pl_list, u32 S) {
+// Two phases per batch of 64 items.
+//  (1) one LANE per item: the item's descriptors, its single ungapped alignment against the chosen allele of its locus
+//      (value-identical to ungapped_planes<., true, .>), the gap-trigger policy and the tag filter.  The read stays in
+//      source order; for the reverse strand it is the allele window that is fetched mirrored (words in descending order,
+//      bit-reversed, complemented), and the Kadane pass walks the mismatches from the top bit down.
+//  (2) one WAVE per item that passed: its aligned columns are piled up 64 at a time.
+// One-wave workgroups, 128 bytes of LDS, device atomics into the counters -- on purpose: a version that kept the counters of a
+// locus in LDS (one 1024-thread workgroup per locus and slice of the item list, 49 KB of LDS) was no faster alone (116-121 us)
+// and cost the pipelined step 0.24 ms: a CU that holds one of its workgroups cannot take a k_route_probe workgroup (147 KB).
+// History of the 207 us this kernel took on cfg3: LDS-staged reads with 64 redundant lanes, bit planes, batched loads, one
+// lane per item -- all 190-215 us, until builds that stop after one stage each showed 84 us in the Kadane loops of the 1.4 %
+// of items that disagree with the chosen allele in dozens of columns (see `hopeless` below).
+template <int NB>
+__device__ __forceinline__ void pileup_body(const EngineDev* __restrict__ Ep, const KParams& P, const int* __restrict__ locus_chosen,
+                                            const u64* __restrict__ locus_colbase, u32* __restrict__ counts, u64* __restrict__ pl_list) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
-    constexpr int QC = 4096, STR = 2;                                  // queue entries; strides of 1024 items scanned between two looks at its fill
+    __shared__ u8 s_pentab[128];
+    const int lane = threadIdx.x;
+    int pmin = P.n_penalty;                                            // smallest penalty a mismatch can cost (score bound below)
+    for (int i = lane; i < 128; i += 64) { const u8 v = E.pen_tab[i]; s_pentab[i] = v; pmin = (int)v < pmin ? (int)v : pmin; }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(pmin, o); pmin = y < pmin ? y : pmin; }
+    __syncthreads();
+    const u64 end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
     constexpr int NI = (32 * NB + 63) / 64;                            // sweeps of 64 columns that cover one read
-    constexpr int PB = MAXL / 32 + 2;
-    __shared__ u32 s_cnt[MAXL * 4]; __shared__ u32 s_queue[QC]; __shared__ u32 s_pile[QC][3]; __shared__ u32 s_al[PB]; __shared__ u32 s_ah[PB]; __shared__ u32 s_an[PB];
-    __shared__ u8 s_pentab[128]; __shared__ u32 s_qn; __shared__ u32 s_pn; __shared__ int s_pmin;
-    const u32 l = blockIdx.x / S, slice = blockIdx.x % S;
-    const int ca = locus_chosen[l];
-    if (ca < 0) return;                                                // block-uniform
-    const LocusDev L = E.loci[l];
-    const u32 a = (u32)ca - L.a_begin;
-    const int m = (int)E.allele_len[ca];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pblocks = (int)L.pblocks < PB ? (int)L.pblocks : PB;
-    for (int i = tid; i < m * 4; i += 1024) s_cnt[i] = 0;
-    {
-        auto pbase = E.planes.g() + L.plane_off; auto nbase = E.nmask.g() + L.nmask_off;
-        for (int i = tid; i < pblocks; i += 1024) {
-            s_al[i] = pbase[(u64)(2u * i) * L.n_pad + a]; s_ah[i] = pbase[(u64)(2u * i + 1u) * L.n_pad + a];
-            s_an[i] = L.has_n ? nbase[(u64)i * L.n_pad + a] : 0u;
-        }
-    }
-    if (tid < 128) s_pentab[tid] = E.pen_tab[tid];
-    if (tid == 0) { int pm = P.n_penalty; for (int i = 0; i < 128; i++) { const int v = (int)E.pen_tab[i]; pm = v < pm ? v : pm; } s_pmin = pm; }
-    const u64 n_items = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
-    const u64 per = (n_items + S - 1) / S, begin = (u64)slice * per, end = begin + per < n_items ? begin + per : n_items;
     const int MA = P.match_bonus << MLST_P_SHIFT;
-    u64 pos = begin;
-    while (pos < end) {                                                // block-uniform
-        if (tid == 0) { s_qn = 0; s_pn = 0; }
-        __syncthreads();
-        // ---- (0) own items of the slice -> queue (as offsets from `begin`), until the slice ends or the queue may overflow
-        for (;;) {
-            u32 lv[STR];
-            #pragma unroll
-            for (int u = 0; u < STR; u++) { const u64 i = pos + (u64)u * 1024 + tid; lv[u] = i < end ? E.item_locus[i] : 0xFFFFFFFFu; }
-            #pragma unroll
-            for (int u = 0; u < STR; u++) if (lv[u] == l) s_queue[atomicAdd(&s_qn, 1u)] = (u32)(pos + (u64)u * 1024 + tid - begin);
-            pos += (u64)STR * 1024;
-            __syncthreads();
-            const u32 fill = s_qn;
-            __syncthreads();                                           // everyone has read the fill before the next stride changes it
-            if (pos >= end || fill > QC - STR * 1024) break;
-        }
-        const u32 qn = s_qn;
-        // ---- (1) full waves over the queue; what passes goes to the pile list: {read slot, diagonal | length | span}
-        for (u32 r0 = 0; r0 < qn; r0 += 1024) {
-            const u32 q = r0 + (u32)tid;
-            if (q < qn) {
-                const u64 my = begin + s_queue[q];
-                const ItemDev it = E.items[my];
+    for (u64 base = blockIdx.x; base < end; base += (u64)gridDim.x * 64) {       // the item of lane k: base + k * gridDim.x
+        const u64 my = base + (u64)lane * gridDim.x;
+        u32 f_ret = 0, f_strand = 0; int f_diag = 0, f_n = 0, f_bs = 0, f_be = 0; u64 f_col = 0; bool f_pile = false;
+        if (my < end) {
+            const ItemDev it = E.items[my];
+            const int ca = locus_chosen[it.locus];
+            if (ca >= 0) {
+                const LocusDev L = E.loci[it.locus];
                 const u32 lw = E.ret_len[it.ret];
                 const int n = (int)(lw & 0x7FFFu), d = it.diag; const bool read_has_n = (lw & 0x8000u) != 0, rev = it.strand != 0;
-                const int floor_n = E.floor_tab[n];
+                const int m = (int)E.allele_len[ca]; const int floor_n = E.floor_tab[n];
+                f_ret = it.ret; f_strand = it.strand; f_diag = d; f_n = n; f_col = locus_colbase[it.locus];
+                const u32 a = (u32)ca - L.a_begin;
                 auto rb = E.ret_bases.g() + (u64)it.ret * RW;
                 auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
-                u32 xw[2 * NB];
-                #pragma unroll
-                for (int w = 0; w < 2 * NB; w++) xw[w] = rb[w];
-                tie_all<2 * NB>(xw);
                 // allele window: block w of the read (source positions 32w..32w+31) meets allele bits pbit - 32w .. +31 going
-                // down (reverse) or pbit + 32w .. +31 going up (forward); NB + 1 consecutive words cover all blocks.  Words
-                // outside the allele are clamped: they only meet read positions outside the overlap, which the mask removes.
+                // down (reverse) or pbit + 32w .. +31 going up (forward); NB + 1 consecutive words cover all blocks
                 const int pbit = rev ? n + d - 32 : d;
                 const int q0 = pbit >> 5, r = pbit & 31, qlow = rev ? q0 - (NB - 1) : q0;
+                auto pbase = E.planes.g() + L.plane_off; auto nbase = E.nmask.g() + L.nmask_off;
                 u32 Wl[NB + 1], Wh[NB + 1], Wn[NB + 1];
                 #pragma unroll
                 for (int t = 0; t <= NB; t++) {
-                    const int qq = qlow + t; const int qc = qq < 0 ? 0 : (qq >= pblocks ? pblocks - 1 : qq);
-                    Wl[t] = s_al[qc]; Wh[t] = s_ah[qc]; Wn[t] = s_an[qc];
+                    const int q = qlow + t; const u32 qc = (u32)(q < 0 ? 0 : (q >= (int)L.pblocks ? (int)L.pblocks - 1 : q));
+                    Wl[t] = pbase[(u64)(2u * qc) * L.n_pad + a]; Wh[t] = pbase[(u64)(2u * qc + 1u) * L.n_pad + a];
+                    Wn[t] = 0;
+                    if (L.has_n) Wn[t] = nbase[(u64)qc * L.n_pad + a];
                 }
-                const int i0 = d < 0 ? -d : 0, i1 = (m - d) < n ? (m - d) : n;       // overlap, oriented coordinates
-                const int slo = rev ? n - i1 : i0, shi = rev ? n - i0 : i1;          // the same in source coordinates
+                u32 xw[2 * NB];
+                #pragma unroll
+                for (int w = 0; w < 2 * NB; w++) xw[w] = rb[w];
+                tie_all<NB + 1>(Wl); tie_all<NB + 1>(Wh); tie_all<2 * NB>(xw);
+                // columns of the overlap, in source coordinates
+                const int i0 = d < 0 ? -d : 0, i1 = (m - d) < n ? (m - d) : n;
+                const int slo = rev ? n - i1 : i0, shi = rev ? n - i0 : i1;
                 u32 M[NB], AN[NB]; int mm = 0;
                 #pragma unroll
                 for (int w = 0; w < NB; w++) {
@@ -2057,7 +2030,7 @@ __device__ __forceinline__ void pileup_locus_body(const EngineDev* __restrict__ 
                 // stays under the floor is dropped here: below the floor an item is neither piled up nor sent to the banded SW.
                 bool hopeless = false;
                 if (mm > 8 && P.trig >= 0) {
-                    const int pmin = s_pmin, ma = P.match_bonus;
+                    const int ma = P.match_bonus;
                     int c2 = 0, b2 = 0, last2 = slo;
                     #pragma unroll
                     for (int w = 0; w < NB; w++) {
@@ -2071,16 +2044,15 @@ __device__ __forceinline__ void pileup_locus_body(const EngineDev* __restrict__ 
                     c2 += (shi - last2) * ma; b2 = c2 > b2 ? c2 : b2;
                     hopeless = b2 < floor_n;
                 }
-                if (hopeless) continue;
-                // The quality byte under a mismatch decides its penalty.  Fetched inside the Kadane loops below, every mismatch of
-                // every word was a round trip of its own (the loops run for the worst lane of the wave: ~115 us of this
-                // kernel); so the bytes under the first two mismatches of each word -- in walking order -- are requested here,
-                // all in one batch, and only a third mismatch in the same 32 columns still waits for its own.
+                // The quality byte under a mismatch decides its penalty.  Fetched inside the Kadane loops, every mismatch of every
+                // word is a round trip of its own (the loops run for the worst lane of the wave); so the bytes under the first two
+                // mismatches of each word -- in walking order -- are requested here, all in one batch, and only a third mismatch
+                // in the same 32 columns still waits for its own.
                 u32 qa[NB], qb2[NB];
                 #pragma unroll
                 for (int w = 0; w < NB; w++) {
                     qa[w] = 0; qb2[w] = 0;
-                    u32 Mw = M[w];
+                    u32 Mw = hopeless ? 0u : M[w];
                     if (Mw) {
                         const int b1 = rev ? 31 - __clz(Mw) : __ffs(Mw) - 1;
                         qa[w] = rq[32 * w + b1];
@@ -2090,7 +2062,7 @@ __device__ __forceinline__ void pileup_locus_body(const EngineDev* __restrict__ 
                 }
                 tie_all<NB>(qa); tie_all<NB>(qb2);
                 int cur = P0, best = P0, cs = i0, last = i0, blen = 0, bend = i0;
-                if (i1 > i0) {
+                if (i1 > i0 && !hopeless) {
                     // one mismatch at oriented position i (qb: the read's quality byte there; an_bit: the allele has N there)
                     auto step = [&](int i, u32 qb, u32 an_bit) {
                         cur += (i - last) * MA;
@@ -2127,68 +2099,61 @@ __device__ __forceinline__ void pileup_locus_body(const EngineDev* __restrict__ 
                 }
                 const int be = bend, bs = bend - blen;
                 const int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF);
-                if (gap_trigger(P, mm, xm, score, floor_n, m, n, d, bs, be)) { const u64 slot = atomicAdd(&E.ctr->n_pl_dp, 1ull); pl_list[slot] = my; }
-                else if (!(score < floor_n || score <= 0 || score < P.minscore || xm > P.max_xm) && be > bs) {      // BAM_tagFilter AS, XM
-                    const u32 pp = atomicAdd(&s_pn, 1u);
-                    s_pile[pp][0] = it.ret; s_pile[pp][1] = (u32)(d + 8192) | ((u32)n << 14) | ((u32)bs << 23); s_pile[pp][2] = (u32)be | ((u32)it.strand << 9);
+                if (hopeless) { }
+                else if (gap_trigger(P, mm, xm, score, floor_n, m, n, d, bs, be)) { const u64 slot = atomicAdd(&E.ctr->n_pl_dp, 1ull); pl_list[slot] = my; }
+                else if (!(score < floor_n || score <= 0 || score < P.minscore || xm > P.max_xm)) {      // BAM_tagFilter AS, XM
+                    f_pile = be > bs; f_bs = bs; f_be = be;
                 }
             }
         }
-        __syncthreads();
-        // ---- (2) every wave takes its share of the pile list, four items at a time: their rows are requested together
-        // (one round trip), then their columns go to the counters
-        {
-            const u32 pn = s_pn;
-            constexpr int G = 4;
-            for (u32 p0 = (u32)wave * G; p0 < pn; p0 += 16u * G) {     // wave-uniform
-                u32 qv[G][NI], wv[G][NI]; int c_n[G], c_bs[G], c_be[G], c_d[G]; u32 c_strand[G];
-                #pragma unroll
-                for (int g = 0; g < G; g++) {
-                    c_n[g] = 0; c_bs[g] = 0; c_be[g] = 0; c_d[g] = 0; c_strand[g] = 0;
-                    #pragma unroll
-                    for (int t = 0; t < NI; t++) { qv[g][t] = 0x80u; wv[g][t] = 0; }
-                    if (p0 + g >= pn) continue;
-                    const u32 ret = s_pile[p0 + g][0], w1 = s_pile[p0 + g][1], w2 = s_pile[p0 + g][2];
-                    c_d[g] = (int)(w1 & 0x3FFFu) - 8192; c_n[g] = (int)((w1 >> 14) & 0x1FFu); c_bs[g] = (int)(w1 >> 23);
-                    c_be[g] = (int)(w2 & 0x1FFu); c_strand[g] = (w2 >> 9) & 1u;
-                    auto rb = E.ret_bases.g() + (u64)ret * RW; auto rq = E.ret_quals.g() + (u64)ret * RQ;
-                    #pragma unroll
-                    for (int t = 0; t < NI; t++) {
-                        const int i = c_bs[g] + 64 * t + lane;
-                        if (i < c_be[g]) { const int sp = c_strand[g] ? c_n[g] - 1 - i : i; qv[g][t] = rq[sp]; wv[g][t] = rb[sp >> 4]; }
-                    }
-                }
-                #pragma unroll
-                for (int g = 0; g < G; g++) {
-                    #pragma unroll
-                    for (int t = 0; t < NI; t++) {
-                        const int i = c_bs[g] + 64 * t + lane;
-                        if (i >= c_be[g]) continue;
-                        const u32 qb = qv[g][t];
-                        if ((qb & 0x80u) || (int)(qb & 0x7Fu) < P.minqual) continue;
-                        const int sp = c_strand[g] ? c_n[g] - 1 - i : i;
-                        u32 b = (wv[g][t] >> (2 * (sp & 15))) & 3u; if (c_strand[g]) b ^= 3u;
-                        atomicAdd(&s_cnt[(i + c_d[g]) * 4 + (int)b], 1u);
-                    }
-                }
+        // ---- phase 2: the wave piles up the columns of one item after the other; the rows of the next item are requested
+        // before the atomics of this one go out (on gfx9 the loads behind an atomic wait for its acknowledgement)
+        u64 todo = __ballot(f_pile);
+        u32 qv[NI], wv[NI]; int c_n = 0, c_bs = 0, c_be = 0, c_d = 0; u32 c_strand = 0; u64 c_col = 0;
+        auto fetch = [&](int k) {
+            c_n = __builtin_amdgcn_readlane(f_n, k); c_bs = __builtin_amdgcn_readlane(f_bs, k); c_be = __builtin_amdgcn_readlane(f_be, k);
+            c_d = __builtin_amdgcn_readlane(f_diag, k); c_strand = (u32)__builtin_amdgcn_readlane((int)f_strand, k);
+            c_col = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)f_col, k) | ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(f_col >> 32), k) << 32);
+            const u32 ret = (u32)__builtin_amdgcn_readlane((int)f_ret, k);
+            auto rb = E.ret_bases.g() + (u64)ret * RW; auto rq = E.ret_quals.g() + (u64)ret * RQ;
+            #pragma unroll
+            for (int t = 0; t < NI; t++) {
+                const int i = c_bs + 64 * t + lane; qv[t] = 0x80u; wv[t] = 0;
+                if (i < c_be) { const int sp = c_strand ? c_n - 1 - i : i; qv[t] = rq[sp]; wv[t] = rb[sp >> 4]; }
             }
+        };
+        if (todo) { const int k = __ffsll((long long)todo) - 1; todo &= todo - 1; fetch(k); }
+        else continue;
+        for (;;) {                                                      // block-uniform
+            u32 q0v[NI], w0v[NI];
+            #pragma unroll
+            for (int t = 0; t < NI; t++) { q0v[t] = qv[t]; w0v[t] = wv[t]; }
+            const int p_n = c_n, p_bs = c_bs, p_be = c_be, p_d = c_d; const u32 p_strand = c_strand; const u64 p_col = c_col;
+            const bool more = todo != 0;
+            if (more) { const int k = __ffsll((long long)todo) - 1; todo &= todo - 1; fetch(k); }
+            #pragma unroll
+            for (int t = 0; t < NI; t++) {
+                const int i = p_bs + 64 * t + lane;
+                if (i >= p_be) continue;
+                const u32 qb = q0v[t];
+                if ((qb & 0x80u) || (int)(qb & 0x7Fu) < P.minqual) continue;
+                const int sp = p_strand ? p_n - 1 - i : i;
+                u32 b = (w0v[t] >> (2 * (sp & 15))) & 3u; if (p_strand) b ^= 3u;
+                atomicAdd(&counts[(p_col + (u64)(i + p_d)) * 4 + b], 1u);
+            }
+            if (!more) break;
         }
-        __syncthreads();                                                // the queue is free again
     }
-    __syncthreads();
-    const u64 colbase = locus_colbase[l];
-    for (int c = tid; c < m * 4; c += 1024) { const u32 v = s_cnt[c]; if (v) atomicAdd(&counts[colbase * 4 + (u64)c], v); }
 }
-#define PILEUP_KERNEL(NAME, NB, MAXL) \
-    __global__ __launch_bounds__(1024) void NAME(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen, \
-                                                 const u64* __restrict__ locus_colbase, u32* __restrict__ counts, u64* __restrict__ pl_list, u32 S) { \
-        pileup_locus_body<NB, MAXL>(Ep, P, locus_chosen, locus_colbase, counts, pl_list, S); }
-// reads up to 160 bases / up to MLST_MAX_READ_LEN (the host knows the longest row width submitted for the sample) x loci up
-// to 1024 columns / up to 4096 (positions are 12 bits)
-PILEUP_KERNEL(k_pileup_160, 5, 1024)
-PILEUP_KERNEL(k_pileup_320, RW / 2, 1024)
-PILEUP_KERNEL(k_pileup_160_long, 5, 4096)
-PILEUP_KERNEL(k_pileup_320_long, RW / 2, 4096)
+// reads up to 160 bases / up to MLST_MAX_READ_LEN (the host knows the longest row width submitted for the sample)
+__global__ __launch_bounds__(64) void k_pileup_160(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen,
+                                                   const u64* __restrict__ locus_colbase, u32* __restrict__ counts, u64* __restrict__ pl_list) {
+    pileup_body<5>(Ep, P, locus_chosen, locus_colbase, counts, pl_list);
+}
+__global__ __launch_bounds__(64) void k_pileup_320(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen,
+                                                   const u64* __restrict__ locus_colbase, u32* __restrict__ counts, u64* __restrict__ pl_list) {
+    pileup_body<RW / 2>(Ep, P, locus_chosen, locus_colbase, counts, pl_list);
+}
 
 __global__ __launch_bounds__(64) void k_pileup_dp(const EngineDev* __restrict__ Ep, KParams P, const int* __restrict__ locus_chosen,
                                                   const u64* __restrict__ locus_colbase, u32* __restrict__ counts,
@@ -2399,7 +2364,6 @@ struct mlst_handle {
     u8* d_in_bases = nullptr; u8* d_in_quals = nullptr; u64* d_in_off = nullptr; u64 cap_in_bytes = 0, cap_in_reads = 0;
     u32* d_packed = nullptr; u8* d_qrows = nullptr; u16* d_lens = nullptr; u64 cap_packed_words = 0, cap_qrow_bytes = 0, cap_lens = 0;
     u64 reads_seen = 0;
-    u32 max_locus_len = 0;                       // longest allele of the loaded reference (picks the k_pileup instantiation)
     u32 max_wpr = 0;                             // widest read rows submitted since the last reset (picks the k_pileup instantiation)
     int ext_threads = 256, ext_blocks = 1024;    // k_extend launch shape (set in mlst_load_reference)
     int sieve_g_blocks = 256 * 5;                // k_sieve_q<.,false> grid (MLST_SIEVE_BLOCKS overrides it)
@@ -2554,10 +2518,10 @@ static void free_state(mlst_handle* h) {
     hipFree(h->d_stats); h->d_stats = nullptr; if (h->h_stats) { hipHostFree(h->h_stats); h->h_stats = nullptr; }
     hipFree(E.ret_bases); hipFree(E.ret_quals); hipFree(E.ret_len); hipFree(E.ret_ridx); hipFree(E.ret_nrec);
     hipFree(E.ret_mate); hipFree(E.ret_item0); hipFree(E.ret_nitems); E.ret_mate = nullptr; E.ret_item0 = nullptr; E.ret_nitems = nullptr;
-    hipFree(E.items); hipFree(E.item_state); hipFree(E.item_locus); hipFree(E.res); hipFree(E.dp_list);
+    hipFree(E.items); hipFree(E.item_state); hipFree(E.res); hipFree(E.dp_list);
     hipFree(h->d_locus_chosen); hipFree(h->d_locus_colbase); hipFree(h->d_pl_list); hipFree(h->d_tb);
     E.sum_score = nullptr; E.n_hits = nullptr; E.locus_len = E.locus_first = nullptr; E.ctr = nullptr; E.ret_bases = nullptr; E.ret_quals = nullptr;
-    E.ret_len = nullptr; E.ret_ridx = nullptr; E.ret_nrec = nullptr; E.items = nullptr; E.item_state = nullptr; E.item_locus = nullptr; E.res = nullptr; E.dp_list = nullptr;
+    E.ret_len = nullptr; E.ret_ridx = nullptr; E.ret_nrec = nullptr; E.items = nullptr; E.item_state = nullptr; E.res = nullptr; E.dp_list = nullptr;
     h->d_locus_chosen = nullptr; h->d_locus_colbase = nullptr; h->d_pl_list = nullptr; h->d_tb = nullptr;
     h->have_state = false;
 }
@@ -2891,8 +2855,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     {   // device-side typing: allele numbers, one slot of max_len columns per locus
         HIPCHK(h, dmalloc(&h->d_allele_no, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_no, allele_no, (u64)n_alleles * 4, hipMemcpyHostToDevice));
         h->fixed_colbase.assign(n_loci + 1, 0);
-        h->max_locus_len = 0;
-        for (u32 l = 0; l < n_loci; l++) { h->fixed_colbase[l + 1] = h->fixed_colbase[l] + loci[l].max_len; h->max_locus_len = std::max(h->max_locus_len, loci[l].max_len); }
+        for (u32 l = 0; l < n_loci; l++) h->fixed_colbase[l + 1] = h->fixed_colbase[l] + loci[l].max_len;
         h->fixed_cols = h->fixed_colbase[n_loci];
         HIPCHK(h, dmalloc(&h->d_fixed_colbase, (u64)n_loci + 1)); HIPCHK(h, hipMemcpy(h->d_fixed_colbase, h->fixed_colbase.data(), ((u64)n_loci + 1) * 8, hipMemcpyHostToDevice));
         HIPCHK(h, dmalloc(&h->d_auto_chosen, (u64)n_loci));
@@ -2924,7 +2887,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&E.ret_bases, E.cap_ret * RW)); HIPCHK(h, dmalloc(&E.ret_quals, E.cap_ret * RQ));
     HIPCHK(h, dmalloc(&E.ret_len, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_ridx, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_nrec, E.cap_ret));
     HIPCHK(h, dmalloc(&E.ret_mate, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_item0, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_nitems, E.cap_ret));
-    HIPCHK(h, dmalloc(&E.items, E.cap_items)); HIPCHK(h, dmalloc(&E.item_state, E.cap_items)); HIPCHK(h, dmalloc(&E.item_locus, E.cap_items)); HIPCHK(h, dmalloc(&E.res, E.cap_res)); HIPCHK(h, dmalloc(&E.dp_list, E.cap_dp));
+    HIPCHK(h, dmalloc(&E.items, E.cap_items)); HIPCHK(h, dmalloc(&E.item_state, E.cap_items)); HIPCHK(h, dmalloc(&E.res, E.cap_res)); HIPCHK(h, dmalloc(&E.dp_list, E.cap_dp));
     HIPCHK(h, dmalloc(&h->d_locus_colbase, (u64)n_loci * 2 + 2));   // [colbase u64 x L][chosen int x L]
     HIPCHK(h, dmalloc(&h->d_pl_list, E.cap_items));
     HIPCHK(h, dmalloc(&h->d_tb, (u64)64 * 64 * MLST_MAX_READ_LEN * (2 * MAX_W + 1)));
@@ -3376,19 +3339,11 @@ static int ensure_pin(mlst_handle* h, u64 bytes) {
     return MLST_OK;
 }
 
-// k_pileup: one workgroup per (locus, slice of the item list); workgroups of loci without a chosen allele leave at once.
-// Slices per locus: enough workgroups to fill the chip when few loci are in play (an isolate: 7 loci x 73 slices), fewer
-// when many are (every slice flushes the locus's counters once: 4 x columns device atomics) -- but still eight for a
-// 1,050-locus database: the loci of the most abundant genome of a metagenome hold several times the average number of items.
+// k_pileup: one wave per workgroup, 8192 of them (64 VGPRs-class kernels fill the chip's wave slots with that many); the
+// instantiation follows the widest read rows submitted for the sample.
 static void launch_pileup(mlst_handle* h, const int* d_chosen, const u64* d_colbase, u32* d_counts) {
-    const u64 nl = h->n_loci ? h->n_loci : 1;
-    u32 S = (u32)(8400 / nl); if (S < 1) S = 1; if (S > 73) S = 73;
-    const dim3 grid((unsigned)(nl * S)), block(1024);
-    const bool wide = h->max_wpr > 10, lng = h->max_locus_len > 1024;
-    if (!wide && !lng) hipLaunchKernelGGL(k_pileup_160, grid, block, 0, h->stream, h->d_E, h->kp, d_chosen, d_colbase, d_counts, h->d_pl_list, S);
-    else if (wide && !lng) hipLaunchKernelGGL(k_pileup_320, grid, block, 0, h->stream, h->d_E, h->kp, d_chosen, d_colbase, d_counts, h->d_pl_list, S);
-    else if (!wide) hipLaunchKernelGGL(k_pileup_160_long, grid, block, 0, h->stream, h->d_E, h->kp, d_chosen, d_colbase, d_counts, h->d_pl_list, S);
-    else hipLaunchKernelGGL(k_pileup_320_long, grid, block, 0, h->stream, h->d_E, h->kp, d_chosen, d_colbase, d_counts, h->d_pl_list, S);
+    if (h->max_wpr <= 10) hipLaunchKernelGGL(k_pileup_160, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, d_chosen, d_colbase, d_counts, h->d_pl_list);
+    else hipLaunchKernelGGL(k_pileup_320, dim3(8192), dim3(64), 0, h->stream, h->d_E, h->kp, d_chosen, d_colbase, d_counts, h->d_pl_list);
 }
 
 // launches pass 2; tables go through pinned memory (laid out [colbase u64 x L][chosen int x L]); no sync here

@@ -570,8 +570,8 @@ def test_read_lengths_from_36_to_300_through_every_sieve(monkeypatch, kind):
 
 
 def test_loci_longer_than_1024_columns(tmp_path):
-    """k_pileup keeps the counters of one locus in LDS: loci up to 1,024 columns and up to MLST_MAX_ALLELE_LEN (4,095) are
-    separate instantiations.  Three long loci, both row widths, against the oracle (statistics, items, pile-up, consensus)."""
+    """Loci up to MLST_MAX_ALLELE_LEN (4,095 columns; positions are 12 bits in the seed postings, allele windows are clamped
+    at both ends).  Three long loci, both row widths, against the oracle (statistics, items, pile-up, consensus)."""
     from metamlst_amd.index import load_index
     db = synth.make_db(str(tmp_path / "long.db"), {"lg": [("g0", 1500), ("g1", 3000), ("g2", 4095)]}, alleles_per_locus=12, n_profiles=6)
     idx = load_index(db.path)
@@ -586,9 +586,9 @@ def test_loci_longer_than_1024_columns(tmp_path):
         assert len(chosen) == 3 and all(int(pc[a].sum()) > 0 for a in chosen)
 
 
-def test_deep_amplicon_sample_refills_the_pileup_queue():
-    """1.3 M reads that all come from the seven loci: every (locus, slice) workgroup of k_pileup finds more of its own items
-    than its LDS queue takes at once (7 loci x 73 slices, 2,048 entries between two drains) and goes round several times."""
+def test_deep_amplicon_sample():
+    """1.3 M reads that all come from the seven loci (every read retained, ~160 items per k_pileup wave in three batches of
+    64 lanes, ~80,000-fold columns): statistics and pile-up counts against the oracle."""
     db, idx = fx.ecoli_small(20)
     rng = np.random.default_rng(33)
     n, L = 1_300_000, 150
