@@ -2192,6 +2192,13 @@ __global__ __launch_bounds__(64) void k_pileup_dp(const EngineDev* __restrict__ 
 }
 
 // majority base per column (cmseq reference_free_consensus [NOT IN TREE]: ties alphabetical, < mincov -> none_char)
+// Zero-fill as a kernel of its own.  The launch sequences that are replayed as hipGraphs hold kernel nodes only: a replayed
+// graph with memset / memcpy nodes faulted just past the end of the counts buffer once foreign copies and fills (torch
+// tensors moved by the same process) had run between its capture and its replay (profiles/check_batch.py, three samples on
+// one engine); with MLST_GRAPHS=0 the same sequence was clean.
+__global__ __launch_bounds__(256) void k_zero(u32* __restrict__ p, u64 n_words) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (u64)gridDim.x * blockDim.x) p[i] = 0u;
+}
 __global__ __launch_bounds__(256) void k_consensus(const u32* __restrict__ counts, u64 n_cols, u32 mincov, u8 none_char, u8* __restrict__ out) {
     for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < n_cols; c += (u64)gridDim.x * blockDim.x) {
         const uint4 v = reinterpret_cast<const uint4*>(counts)[c];
@@ -2928,6 +2935,10 @@ extern "C" int mlst_reset_sample(mlst_handle* h) {
 static int grid_for(u64 n_units, int per_block, int cap = 2048) {
     u64 g = (n_units + per_block - 1) / per_block; if (g < 1) g = 1; if (g > (u64)cap) g = cap; return (int)g;
 }
+static void zero_words(mlst_handle* h, void* p, u64 n_words) {
+    if (!n_words) return;
+    hipLaunchKernelGGL(k_zero, dim3(grid_for((n_words + 255) / 256, 1, 1024)), dim3(256), 0, h->stream, (u32*)p, n_words);
+}
 
 extern "C" int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals, const uint64_t* d_off,
                                       uint64_t n_reads, uint32_t* d_packed, uint8_t* d_qrows, uint16_t* d_lens,
@@ -3004,7 +3015,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
 #undef SIEVE_CASE
       } else if (h->sieve_kind == MLST_SIEVE_ROUTED) {      // seeds routed to the CU that owns their filter slice (K1c)
         const u64 n_flag_words = (n_reads + 31) >> 5;
-        HIPCHK(h, hipMemsetAsync(h->d_bin_flags, 0, n_flag_words * 4, h->stream));
+        zero_words(h, h->d_bin_flags, n_flag_words);
         RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags;
         R.cap = h->rt_cap; R.n_prod = h->rt_prod; R.tiles_max = h->rt_tiles_max; R.nw = h->rt_nw;
         { Prof pa(h, 9);
@@ -3491,36 +3502,47 @@ extern "C" int mlst_typing_choose_pileup(mlst_handle* h, int32_t penalty, uint32
     const u64 nl = h->n_loci, ncols = h->fixed_cols;
     u32* cnt = d_counts ? d_counts : h->d_auto_counts;
     if (nl) hipLaunchKernelGGL(k_choose, dim3((unsigned)nl), dim3(256), 0, h->stream, h->d_E, h->d_allele_no, (int)penalty, h->d_auto_chosen);
-    HIPCHK(h, hipMemsetAsync(cnt, 0, (ncols ? ncols : 1) * 16, h->stream));
-    HIPCHK(h, hipMemsetAsync(&h->E.ctr.p->n_pl_dp, 0, 8, h->stream));
+    zero_words(h, cnt, (ncols ? ncols : 1) * 4);
+    zero_words(h, &h->E.ctr.p->n_pl_dp, 2);
     { Prof pf(h, 5);
       launch_pileup(h, h->d_auto_chosen, h->d_fixed_colbase, cnt);
       hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list, h->d_tb); }
     HIPCHK(h, hipGetLastError());
     return MLST_OK;
 }
-extern "C" int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_char, const uint32_t* d_counts) {
-    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
-    hipSetDevice(h->device);
-    const u64 nl = h->n_loci, ncols = h->fixed_cols;
+// the kernels of phase 2 (inside the replayed graph) and its copies into pinned memory (issued directly, every time)
+static int typing_finish_kernels(mlst_handle* h, uint32_t mincov, char none_char, const uint32_t* d_counts) {
+    const u64 ncols = h->fixed_cols;
     const u32* cnt = d_counts ? d_counts : h->d_auto_counts;
     if (ncols) hipLaunchKernelGGL(k_consensus, dim3(grid_for(ncols, 256, 256)), dim3(256), 0, h->stream, cnt, (u64)ncols, mincov, (u8)none_char, h->d_auto_letters);
     HIPCHK(h, hipGetLastError());
+    return MLST_OK;
+}
+static int typing_finish_copies(mlst_handle* h) {
+    const u64 nl = h->n_loci, ncols = h->fixed_cols;
     HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, h->stats_bytes, hipMemcpyDeviceToHost, h->stream));
     if (nl) HIPCHK(h, hipMemcpyAsync(h->h_auto, h->d_auto_chosen, nl * 4, hipMemcpyDeviceToHost, h->stream));
     if (ncols) HIPCHK(h, hipMemcpyAsync(h->h_auto + ((nl * 4 + 15) & ~15ull), h->d_auto_letters, ncols, hipMemcpyDeviceToHost, h->stream));
     h->auto_pending = true;
     return MLST_OK;
 }
+extern "C" int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_char, const uint32_t* d_counts) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    hipSetDevice(h->device);
+    int rc = typing_finish_kernels(h, mincov, none_char, d_counts);
+    return rc ? rc : typing_finish_copies(h);
+}
 extern "C" int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);
     const int gs = graph_enter(h, h->g_typing, {(u64)(u32)penalty, (u64)mincov, (u64)(u8)none_char, (u64)(h->max_wpr <= 10)});
-    if (gs == 1) { h->auto_pending = true; return MLST_OK; }
-    int rc = mlst_typing_choose_pileup(h, penalty, nullptr);
-    if (!rc) rc = mlst_typing_finish(h, mincov, none_char, nullptr);
-    if (gs == 2) { int rc2 = graph_leave(h, h->g_typing); if (!rc) rc = rc2; }
-    return rc;
+    int rc = MLST_OK;
+    if (gs != 1) {
+        rc = mlst_typing_choose_pileup(h, penalty, nullptr);
+        if (!rc) rc = typing_finish_kernels(h, mincov, none_char, nullptr);
+        if (gs == 2) { int rc2 = graph_leave(h, h->g_typing); if (!rc) rc = rc2; }
+    }
+    return rc ? rc : typing_finish_copies(h);        // the copies stay outside the graph (kernel nodes only, see k_zero)
 }
 
 // Run the engine on a caller's HIP stream (e.g. the stream a torch.distributed collective is ordered against), or

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batches", default="0,1")
     ap.add_argument("--chunk", type=int, default=4_000_000)
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--engine-only", action="store_true", help="skip the oracle (diagnostics of the engine-side sequence)")
     a = ap.parse_args()
     import __graft_entry__ as ge
     ge.build()
@@ -51,12 +52,22 @@ def main():
     for b in want:
         packed, qrows, lens, n_total = w.batches[b]
         t0 = time.time()
+        def stage(name):
+            torch.cuda.synchronize(device)
+            eng.synchronize()
+            sys.stderr.write("batch %d engine: %s done\n" % (b, name))
+            sys.stderr.flush()
+
         eng.reset_sample()
+        stage("reset")
         eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), n_total, w.wpr, w.qstride)
+        stage("pass 1")
         eng.typing_enqueue(penalty=100)
         sg, chosen_dev, letters_dev = eng.typing_fetch()
+        stage("typing")
         ch = sorted(pick_alleles_fast(w.idx, sg, 100).values())
         pg = eng.pileup(ch)
+        stage("explicit pile-up")
         sessions = {sp: SpeciesSession(w.database, sp, 5, matcher, cache) for sp in w.planted}
         res = type_sample(w.idx, sg, None, w.database, "sample", fast=True, cache=cache, typed=(chosen_dev, letters_dev))
         calls = {}
@@ -65,7 +76,11 @@ def main():
                 organism, (bacteriumLine, sampleRecord) = parse_nfo_line(r.nfo_line)
                 if organism in sessions:
                     calls[organism] = sessions[organism].add_sample(bacteriumLine, sampleRecord)
+        stage("ST calls")
         t_eng = time.time() - t0
+        if a.engine_only:
+            print(json.dumps({"workload": a.workload, "batch": b, "st_calls_engine": calls, "engine_s": round(t_eng, 1)}), flush=True)
+            continue
         # the oracle over every read of the batch, chunk by chunk
         t0 = time.time()
         so = None
