@@ -617,3 +617,34 @@ def test_deep_amplicon_sample():
     fx.assert_stats_equal(s, so)
     assert int(s.counters[4]) == n                    # every read retained
     check_pileup(eng, orc, idx, s)
+
+
+def test_replayed_typing_graph_with_foreign_copies_in_between():
+    """The device-side typing tail is replayed as a hipGraph from the third identical call on.  Other users of the GPU in the
+    same process (here: torch fills and copies of a few hundred MB between the samples) must not disturb it: four samples on
+    one engine, every one = the host's statement of the choice and the explicit pile-up (the graphs hold
+    kernel nodes only since a replay with memset / memcpy nodes faulted in exactly this kind of sequence)."""
+    import torch
+    db, idx = fx.ecoli_small(80)
+    eng = Engine(0)
+    eng.load_reference(idx)
+    dev = torch.device("cuda:0")
+    for k in range(4):
+        fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 3 + k, n_reads=30000, seed=100 + k)
+        eng.reset_sample()
+        eng.submit_reads(fb, fq, off)
+        eng.typing_enqueue(penalty=100)
+        st, chosen, letters = eng.typing_fetch()
+        want = pick_alleles_fast(idx, st, 100)
+        assert chosen == want and len(want) == 7
+        cons = eng.consensus(sorted(want.values()))
+        assert {a: bytes(v) for a, v in letters.items()} == {a: bytes(v) for a, v in cons.items()}
+        # foreign traffic: allocations, fills and copies both ways
+        t = torch.empty(96 << 20, dtype=torch.int32, device=dev)
+        t.fill_(k)
+        h = t[: 16 << 20].cpu()
+        u = torch.zeros_like(t)
+        u.copy_(t)
+        v = h.to(dev)
+        torch.cuda.synchronize(dev)
+        del t, u, v, h
