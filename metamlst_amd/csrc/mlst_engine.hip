@@ -849,7 +849,9 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
                                                       const uint4* __restrict__ sieve, u32 smask, const RouteDev R, Counters* __restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) u32 s_f[RT_FWORDS];
     __shared__ u64 s_q[16][128];                  // per-wave queue of entries that passed the filter: read | hash << 32
-    constexpr int PF = 4;                         // 16-byte loads per lane in flight: 4 KiB per wave, 64 KiB per CU
+    constexpr int PF = 2;                         // 16-byte loads per lane in flight: 2 KiB per wave, 32 KiB per CU.  (Four were no faster --
+                                                  // 0.94-0.98 against 0.90-0.93 ms in alternating runs -- and cost 20 VGPRs: ~100 against ~80, the
+                                                  // difference between one and two waves of another kernel per SIMD next to this one)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 owner = blockIdx.x, P = R.n_prod;
     const u32 sshift = (u32)__clz((int)smask);
