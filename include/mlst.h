@@ -85,6 +85,11 @@ int mlst_load_reference(mlst_handle* h, const uint8_t* ascii_concat, const uint6
                         const uint32_t* locus_id, const uint32_t* species_id,
                         const int32_t* allele_no, uint32_t n_alleles);
 
+/* The host-side index built by the last mlst_load_reference of the process is kept (a second engine on the same
+ * database only uploads it: 0.5 s instead of 13 s for the full database); this releases it (~0.6 GB for the full
+ * database).  MLST_INDEX_CACHE=0 in the environment disables the cache. */
+void mlst_release_index_cache(void);
+
 /* Pass 1 over one batch of reads held in HOST memory (FASTQ fields as read from the file):
  * seed sieve -> exact seeds -> extension against every allele of the hit locus ->
  * per-allele {sum AS, hits}.  Replaces bowtie2 -a ... | samtools view + the hit
@@ -100,8 +105,21 @@ int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uint8_t* quals
  * bowtie2 [NOT IN TREE].  n_reads_out (optional) receives the number of records found. */
 int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int paired, uint64_t* n_reads_out);
 
+/* One chunk of an OPEN FASTQ stream: the text continues what the calls before left over (a partial record at the end of
+ * a chunk is kept on the device and completed by the next call, whichever of mlst_submit_fastq_stream /
+ * mlst_submit_fastq_bgzf it is: text and BGZF chunks of one stream may alternate); a chunk may be cut anywhere.  The last
+ * chunk is passed with final_chunk != 0 and must end with a whole record (n_bytes may be 0 then).  Used for the head and
+ * tail of a BGZF byte range, which the host inflates itself to find the record boundary (metamlst_amd/fastq.py). */
+int mlst_submit_fastq_stream(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out);
+
+/* Two chunks of FASTQ text from the two files of a paired-end sample, holding the SAME number of whole records each:
+ * record k of text1 and record k of text2 are mates.  They are interleaved on the GPU (reads 2k, 2k+1) and submitted as
+ * pairs, i.e. one QNAME per pair for sequenceBank (metamlst.py:127, Q3) -- bowtie2 itself sees them as unpaired reads
+ * (-U r1,r2, README.md:20).  n_reads_out receives the number of reads (2 x records per file). */
+int mlst_submit_fastq_pair(mlst_handle* h, const uint8_t* text1, uint64_t n1, const uint8_t* text2, uint64_t n2, uint64_t* n_reads_out);
+
 /* The same from BGZF-compressed FASTQ (bgzip; a series of independent <= 64 KiB deflate blocks): the COMPRESSED bytes
- * cross PCIe, every block is inflated by one GPU thread (csrc/inflate_dev.h), the text is parsed as above.  A chunk is
+ * cross PCIe, every block is inflated by one GPU wave (csrc/inflate_wave.h), the text is parsed as above.  A chunk is
  * a run of whole BGZF blocks cut anywhere between blocks; a record that straddles two chunks is completed by the next
  * call; the last chunk of a file is passed with final_chunk != 0 and must end with a whole record.  Block CRCs are
  * not verified (the inflated size is).  With n_consumed_out != NULL a non-final buffer may also end inside a block:
@@ -114,6 +132,9 @@ int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes
 /* Test hook: the deflate decoder of the call above run on the HOST on one raw deflate stream (returns 0 or a negative
  * code of csrc/inflate_dev.h; *produced = bytes written).  Not a data path. */
 int mlst_selftest_inflate(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced);
+
+/* Test hook of the DEVICE decoder (csrc/inflate_wave.h): whole BGZF blocks in, their inflated text out (host buffers). */
+int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, uint8_t* out, uint64_t cap, uint64_t* produced);
 
 /* Same, with the three arrays already in DEVICE memory (GPU-side FASTQ decode feeds this). */
 int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
@@ -128,6 +149,7 @@ int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8
  * owning the 64 reads of a group load every unit with one coalesced 512-byte access: words 2u and
  * 2u+1 of read r are the uint32 at
  *     (r / 64) * 64 * words_per_read  +  ((u * 64 + r % 64) * 2)   and the one after it.
+ * qual_stride must be a multiple of 4 (rows are written as 32-bit words) and d_qual_rows 4-byte aligned.
  * d_packed must hold ceil(n_reads / 64) * 64 * words_per_read words (the rows that pad the last
  * group are written as zeros) and be 16-byte aligned; a batch that is packed in pieces must cut the
  * pieces at multiples of 64 reads. */
@@ -278,6 +300,16 @@ int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]);
  * memory, 3 = CU-routed filter slices in LDS; chosen by database size, MLST_SIEVE=lds / global / routed forces one), [1] = distinct canonical seeds, [2] = longest overflow walk of a key in the
  * fingerprint sieve (the kernels follow a chain for 64 buckets; the build keeps it <= 32), [3] = sieve buckets. */
 int mlst_get_sieve_info(mlst_handle* h, uint64_t out[4]);
+/* Diagnostics of the routed sieve (profiles/route_modes.py; no reference counterpart, not a data path).
+ * mlst_get_route_trace: the first call switches the trace on; later calls wait for the stream and return, for the last
+ * submission, out[0] = producer workgroups P, [1] = arena address, [2] = packed-row address, [3] = wall-clock kHz,
+ * [4] = region capacity, [5] = filter address, [6] = flag address, [7] = arena capacity in entries, then four words per
+ * workgroup (P producers, then the 256 consumers): XCC_ID | HW_ID << 32, wall clock at start, at end, 0.
+ * *n_words = words needed (0 while nothing has been traced).
+ * mlst_debug_route_realloc: free the routing arena (the next submission allocates it again), keeping pad_bytes of
+ * device memory allocated in between so that the new arena lands elsewhere. */
+int mlst_get_route_trace(mlst_handle* h, uint64_t* out, uint64_t cap_words, uint64_t* n_words);
+int mlst_debug_route_realloc(mlst_handle* h, uint64_t pad_bytes);
 /* Block until all work queued on the engine's stream is done. */
 int mlst_synchronize(mlst_handle* h);
 

@@ -17,7 +17,7 @@ import time
 
 from . import db as mdb
 from .engine import Engine, default_params
-from .fastq import is_bgzf, text_chunks, tile_fasta
+from .fastq import is_bgzf, mates_share_names, pair_chunks, prefetch, text_chunks, tile_fasta
 from .index import load_index
 from .merge import EngineMatcher, merge_folder
 from .typing import TypingArgs, log_table, sample_name, type_sample
@@ -25,7 +25,11 @@ from .typing import TypingArgs, log_table, sample_name, type_sample
 
 def _type_parser(sub):
     p = sub.add_parser("type", help="reconstruct the MLST loci of one sample from its reads (counterpart of metamlst.py)")
-    p.add_argument("READS", help="FASTQ file (plain or .gz); with --alignments: a SAM (plain or .gz) or BAM file")
+    p.add_argument("READS", nargs="+",
+                   help="FASTQ file (plain, .gz or bgzip; `a.fq,b.fq` = two files of one sample, as bowtie2 -U takes them); with "
+                        "--alignments: a SAM (plain or .gz) or BAM file.  Several files, or a folder of FASTQ files: every one is a "
+                        "sample of its own, typed one after the other (with --gpus N: whole samples dealt to the GPUs, rank 0 "
+                        "gathers the .nfo lines) -- the many-samples-into-one-folder use that metamlst-merge.py reads")
     p.add_argument("--alignments", action="store_true",
                    help="READS is a SAM / BAM made by `bowtie2 --very-sensitive-local -a --no-unal` against the database's "
                         "alleles (the reference's own input): hit accumulation as metamlst.py:101-130, pileup on the GPU")
@@ -33,7 +37,11 @@ def _type_parser(sub):
                    help="READS is a FASTA of contigs or an assembled genome (the input of the reference's mlst.py): it is cut into "
                         "overlapping windows (--tile LEN,STEP) that go through the same path as reads")
     p.add_argument("--tile", default="150,25", metavar="LEN,STEP")
-    p.add_argument("-2", dest="mates", help="second FASTQ of a paired-end sample")
+    p.add_argument("-2", dest="mates",
+                   help="second FASTQ of a paired-end sample: record k of it is the mate of record k of READS.  Mates are aligned as "
+                        "unpaired reads (the documented pipeline is bowtie2 -U r1,r2); when the two files give a pair ONE read name "
+                        "(checked on the first record) the pair counts once per locus in the coverage figures, as in the "
+                        "reference's sequenceBank (metamlst.py:127)")
     p.add_argument("-o", metavar="OUTPUT FOLDER", default="./out")
     p.add_argument("-d", "--database", metavar="DB PATH", required=True)
     p.add_argument("--filter", metavar="species1,species2...")
@@ -105,7 +113,30 @@ def run_index(a) -> int:
     return 0
 
 
+FASTQ_SUFFIXES = (".fastq", ".fq", ".fastq.gz", ".fq.gz", ".fastq.bgz", ".fq.bgz")
+
+
+def expand_samples(reads: list[str]) -> list[list[str]]:
+    """READS arguments -> one list of files per sample (a folder contributes its FASTQ files in name order)."""
+    out = []
+    for r in reads:
+        if os.path.isdir(r):
+            out += [[os.path.join(r, f)] for f in sorted(os.listdir(r)) if f.endswith(FASTQ_SUFFIXES)]
+        else:
+            out.append(r.split(",") if "," in r and not os.path.exists(r) else [r])
+    return out
+
+
 def run_type(a, argv=None) -> int:
+    samples = expand_samples(a.READS)
+    if not samples:
+        print("no FASTQ file found in " + ", ".join(a.READS))
+        return 1
+    many = len(samples) > 1
+    if many and (a.alignments or a.contigs or a.mates):
+        print("several samples at once: FASTQ input only (use `r1.fq,r2.fq` for a sample made of two files)")
+        return 1
+    a.READS, extra_files = samples[0][0], samples[0][1:]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world == 1:
         if a.alignments or a.contigs:
@@ -131,6 +162,13 @@ def run_type(a, argv=None) -> int:
     eng.load_reference(idx)
     targs = TypingArgs(penalty=a.penalty, minscore=a.minscore, max_xM=a.max_xM, min_read_len=a.min_read_len,
                        min_accuracy=a.min_accuracy, nloci=a.nloci, a=a.a, quiet=a.quiet, filter=a.filter, log=a.log)
+    chunk_bytes = int(os.environ.get("MLST_FASTQ_CHUNK", str(256 << 20)))
+    if many:
+        from .multigpu import type_many_samples
+        rc = type_many_samples(eng, idx, database, targs, samples, rank, world, a.o, a.log, chunk_bytes,
+                               printer=None if a.quiet else (lambda results: _print_results(a, results)))
+        database.closeConnection()
+        return rc
     if a.alignments:
         from .samin import AlignmentSample
         smp = AlignmentSample(idx, targs).add_file(a.READS)
@@ -140,10 +178,13 @@ def run_type(a, argv=None) -> int:
         for chunk in tile_fasta(a.READS, read_len, stride, a.min_read_len):
             eng.submit_fastq(chunk, paired=False)
         return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)
-    chunk_bytes = int(os.environ.get("MLST_FASTQ_CHUNK", str(256 << 20)))
-    if world > 1:      # this rank's chunks, then the two all-reduces; rank 0 writes (metamlst_amd/multigpu.py)
+    # Mates are unpaired reads for the aligner (bowtie2 -U r1,r2).  What a shared read name changes is sequenceBank
+    # (metamlst.py:127: one entry per QNAME and locus): pairs whose files name both mates alike are submitted as pairs.
+    paired = bool(a.mates) and mates_share_names(a.READS, a.mates)
+    paths = [a.READS] + extra_files + ([a.mates] if a.mates else [])
+    if world > 1:      # this rank's share of the files, then the two all-reduces; rank 0 writes (metamlst_amd/multigpu.py)
         from .multigpu import submit_fastq_shard, type_sharded
-        submit_fastq_shard(eng, [a.READS] + ([a.mates] if a.mates else []), rank, world, chunk_bytes)
+        submit_fastq_shard(eng, paths, rank, world, chunk_bytes, paired=paired)
         fileName = sample_name(a.READS)
         if rank == 0 and not os.path.isdir(a.o):
             os.mkdir(a.o)
@@ -155,15 +196,23 @@ def run_type(a, argv=None) -> int:
         import torch.distributed as dist
         dist.destroy_process_group()
         return 0
-    # FASTQ text goes to the GPU as is and is parsed there (mlst_submit_fastq).  Mates are unpaired reads for this
-    # pipeline (bowtie2 -U), so a second file is simply submitted after the first.
-    for path in [a.READS] + ([a.mates] if a.mates else []):
+    # FASTQ text goes to the GPU as is and is parsed there (mlst_submit_fastq); a reader thread stays two chunks ahead
+    submit_sample_files(eng, paths, paired, chunk_bytes)
+    return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)
+
+
+def submit_sample_files(eng, paths, paired: bool, chunk_bytes: int) -> None:
+    """All reads of one sample's FASTQ file(s) into one engine."""
+    if paired:
+        for c1, c2 in prefetch(pair_chunks(paths[0], paths[1], chunk_bytes // 2)):
+            eng.submit_fastq_pair(c1, c2)
+        return
+    for path in paths:
         if is_bgzf(path):      # bgzip'd FASTQ: the compressed blocks go to the GPU and are inflated there
             eng.submit_fastq_bgzf_file(path, paired=False)
             continue
-        for chunk in text_chunks(path, chunk_bytes):
+        for chunk in prefetch(text_chunks(path, chunk_bytes)):
             eng.submit_fastq(chunk, paired=False)
-    return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)
 
 
 def _finish_type(a, idx, database, targs, st, pileup_fn) -> int:

@@ -26,6 +26,7 @@
 
 #include "mlst.h"
 #include "inflate_dev.h"
+#include "inflate_wave.h"
 #include "mlst_policy.h"
 
 typedef unsigned long long u64;
@@ -124,6 +125,7 @@ struct Counters {
     u64 err;             // bit0 retained overflow, bit1 item overflow, bit2 result overflow, bit3 dp overflow
     u64 sv_t0n, sv_t1;   // sieve execution window in wall-clock ticks: max over workgroups of ~start and of end (profiling)
     u64 sv_wgmax;        // longest residency of one sieve workgroup (end - start), wall-clock ticks
+    u64 rt_next;         // routed sieve: tiles handed out beyond every producer's first one (zero between submissions)
     u64 cnt[MLST_CNT_N];
 };
 // item_state bits
@@ -566,8 +568,8 @@ __device__ inline bool bin_exact(u32 w0, u32 w1, const uint4* __restrict__ sieve
 //                  lines (the open lines of an XCD's workgroups are ~2 MiB).  A 4-byte entry = first-of-(owner, wave)
 //                  flag | lane | 25 hash bits; the read index is implied by the position in the region: the
 //                  consumer counts the flags (every (owner, wave) pair of a tile contributes at least a dummy entry).
-//   k_route_probe  one workgroup per owner holds the owner's 128 KiB filter slice in LDS (four bits in each of two 32-bit
-//                  words per key: ~0.3 % of foreign seeds pass, hash collisions included), streams the owner's regions 16 bytes per lane, and sends the
+//   k_route_probe  one workgroup per owner holds the owner's 128 KiB filter slice in LDS (three bits in each of two 32-bit
+//                  words per key, rt_filter_addr: ~0.3 % of foreign seeds pass, 0.2 % of them collisions of the 33 hash bits), streams the owner's regions 16 bytes per lane, and sends the
 //                  entries that pass the exact way: the read's seeds are re-hashed, the one(s) equal to the entry's hash
 //                  probe the fingerprint sieve, a hit sets the read's candidate flag.
 //   k_flag_compact candidate flags -> candidate list.
@@ -576,36 +578,43 @@ __device__ inline bool bin_exact(u32 w0, u32 w1, const uint4* __restrict__ sieve
 // list of emitted tiles tells the consumer which tile a flag count belongs to.
 #define RT_OWNERS 256
 #define RT_FWORDS 32768                // 32-bit words of one owner's filter slice (128 KiB)
-#define RT_DUMMY_CAP 2048              // dummy + padding entries a tile may hold (empty (owner, wave) runs: ~400 of 4096 at nine seeds per read; padding ~400)
 #define RT_MAXP  2048                  // most producer workgroups (regions per owner) a submission may use
 #define RT_FLAG  0x80000000u           // entry = RT_FLAG | lane << 25 | 25 hash bits; RT_DUMMY in the hash bits = "no seed here"
 #define RT_HMASK 0x01FFFFFFu
 #define RT_DUMMY 0x01FFFFFFu
 // 33 hash bits of a canonical key: 8 choose the owner, 25 travel in the entry (a real key that hashes to RT_DUMMY takes
 // the value below it -- in the filter build, in k_route and in the re-hash of k_route_probe alike).
-__host__ __device__ inline u32 rt_parity(u32 x) {
+// One 32 x 32 -> 64-bit multiply of the key folded to 32 bits; the 33 bits are taken from the MIDDLE of the product
+// (bits 15..47: every one of them depends on the key bits below it and, through the carries, on most of those above
+// bit 15; the map key -> product is injective, so two folded keys collide in these 33 bits with probability 2^-33 like
+// with any other hash).  Round 2 ran table_hash here (two multiplies, two xor-shifts) plus a parity: ~22 VALU
+// instructions per seed, three of them quarter rate; this is 7 with one multiply, and k_route hashes 450 M seeds per batch.
+__host__ __device__ inline void rt_hash(u32 lo, u32 hi, u32& owner, u32& h25) {
+    const u32 m = lo ^ (hi * 0x9E3779u);          // hi < 256: a 24-bit multiply (full rate)
+    const u64 P = (u64)m * 0x9E3779B1u;
+    owner = (u32)(P >> 40) & 0xFFu;
+    h25 = (u32)(P >> 15) & RT_HMASK;
+    h25 = h25 < RT_DUMMY - 1u ? h25 : RT_DUMMY - 1u;
+}
+// Filter slice = 2^15 words of 32 bits (128 KiB).  A key sets three bits in each of TWO words: a pair of bits 13 apart,
+// rotated by five hash bits, and one more bit chosen by five others (one v_alignbit + one v_bfe + one v_lshl_or per word;
+// six independent bit positions cost 22 instructions per entry, and the consumer is bound by instruction issue: 48
+// VALU instructions per entry in round 2).  ~6 of 32 bits per word are set (65 k keys per owner): a foreign seed
+// passes one word with p ~ 0.015, both with ~2 * 10^-4 -- an order of magnitude under the 0.19 % of seeds that share all 33 hash bits
+// with a database key, which is what sends an entry to the exact check for nothing.
+__host__ __device__ inline u32 rt_rotr(u32 x, u32 r) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (u32)__popc(x) & 1u;
+    return __builtin_amdgcn_alignbit(x, x, r);     // uses r & 31
 #else
-    return (u32)__builtin_popcount(x) & 1u;
+    r &= 31u; return r ? (x >> r) | (x << (32u - r)) : x;
 #endif
 }
-__host__ __device__ inline void rt_hash(u32 lo, u32 hi, u32& owner, u32& h25) {
-    const u32 a = table_hash(lo, hi);
-    owner = a >> 24;
-    h25 = ((a & 0xFFFFFFu) << 1) | rt_parity(lo ^ (lo >> 13) ^ (hi * 0x2Du));      // one more bit, taken from the key itself
-    if (h25 == RT_DUMMY) h25 = RT_DUMMY - 1u;
-}
-// Filter slice = 2^15 words of 32 bits (128 KiB).  A key sets three bits in each of TWO words (~0.02 % of foreign seeds pass
-// both; one 64-bit block of four bits passed 0.45 %, and every entry that passes costs the consumer ~0.8 KB of row and
-// bucket traffic -- more than the 4-byte entry stream itself at that rate).  32-bit words and one multiply: the consumer
-// is bound by instruction issue (PMC: 531 M VALU wave-instructions with 64-bit masks and two multiplies per entry).
 __host__ __device__ inline void rt_filter_addr(u32 h25, u32& word0, u32& mask0, u32& word1, u32& mask1) {
     const u32 m = h25 * 0x9E3779B1u;               // top bits of a product are the well mixed ones
     word0 = h25 >> 10;
-    mask0 = (1u << (m >> 27)) | (1u << ((m >> 22) & 31u)) | (1u << ((m >> 17) & 31u));
-    word1 = ((m >> 9) ^ h25) & 0x7FFFu;
-    mask1 = (1u << ((m >> 12) & 31u)) | (1u << ((m >> 7) & 31u)) | (1u << ((m >> 2) & 31u));
+    mask0 = rt_rotr(0x2001u, m >> 27) | (1u << ((m >> 22) & 31u));
+    word1 = ((m >> 7) ^ h25) & 0x7FFFu;
+    mask1 = rt_rotr(0x2001u, m >> 17) | (1u << ((m >> 12) & 31u));
 }
 struct RouteDev {
     GP<u32> arena;                   // [owner][producer][cap] entries
@@ -613,8 +622,18 @@ struct RouteDev {
     GP<u32> emitted;                 // [producer][1 + tiles_max]: number of tiles routed, then their iteration numbers
     GP<const u32> filter;            // [owner][RT_FWORDS]
     GP<u32> flags;                   // candidate flag per read (zeroed per submission)
+    GP<u64> trace;                   // diagnostics (mlst_get_route_trace), NULL when off: four words per workgroup
     u32 cap, n_prod, tiles_max, nw;  // nw = waves per producer workgroup = groups of 64 reads per tile
 };
+// where and when a workgroup ran: XCC id | HW_ID << 32, wall clock at its start; the end is stored by rt_trace_end
+__device__ inline void rt_trace_begin(const RouteDev& R, u32 slot) {
+    if (R.trace.p) {
+        const u32 xcc = (u32)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);      // HW_REG_XCC_ID[3:0]
+        const u32 hw = (u32)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_REG_HW_ID
+        R.trace[(u64)slot * 4] = (u64)xcc | ((u64)hw << 32); R.trace[(u64)slot * 4 + 1] = (u64)wall_clock64();
+    }
+}
+__device__ inline void rt_trace_end(const RouteDev& R, u32 slot) { if (R.trace.p) R.trace[(u64)slot * 4 + 2] = (u64)wall_clock64(); }
 // inclusive prefix sum over the 64 lanes with DPP lane moves (no LDS traffic, unlike __shfl_up)
 __device__ inline u32 wave_incl_scan_dpp(u32 v) {
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR(1), 0xF, 0xF, false);
@@ -650,7 +669,7 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // the wave number in a scalar register
     const u32 p = blockIdx.x, P = gridDim.x;
     const u32 so = (u32)tid & 255u, sq = (u32)tid >> 8;
-    if (tid == 0) atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64());
+    if (tid == 0) { atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64()); rt_trace_begin(R, p); }
     #pragma unroll
     for (int v = 0; v < 4; v++) s_cnt[sq * 4 + v][so] = 0;
     if (tid < RT_OWNERS) s_cur[tid] = 0;
@@ -666,8 +685,23 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
         for (int t2 = 0; t2 < WPR / 2; t2++) xn[t2] = __builtin_nontemporal_load(row + t2 * 64);
         len_raw = lens[r0 < n_reads ? r0 : 0];
     }
-    u32 n_emit = 0, k = 0;                        // tiles routed so far (thread 0 keeps the list), iteration number
-    for (u64 tile = p; tile < n_tiles; tile += P, k++) {
+    // Tiles are handed out by a counter (ctr->rt_next), not dealt in a fixed stride: with a fixed share the workgroups of one
+    // launch finished between 0.91 and 1.33 ms (profiles/round3/route_modes.md: same work, different CUs and partners) and
+    // the launch took as long as the slowest.  A workgroup's first tile is its own number; while it works on tile i it holds
+    // the number of tile i+1 (whose rows are being prefetched) and has asked for that of tile i+2 (thread 0, answer parked in
+    // LDS by the end of the iteration), so the counter's latency never shows.  The consumer learns the tile numbers from
+    // the producer's list (R.emitted).
+    __shared__ u32 s_tile;
+    u32 n_emit = 0;                               // tiles routed so far (thread 0 keeps the list)
+    u64 t_nxt;
+    {
+        if (tid == 0) s_tile = P + (u32)atomicAdd(&ctr->rt_next, 1ull);
+        __syncthreads();
+        t_nxt = s_tile;
+        __syncthreads();
+    }
+    u32 n_taken = 2;                              // tiles this workgroup has claimed (thread 0's copy decides)
+    for (u64 tile = p; tile < n_tiles; ) {
         // Per-thread addresses (LDS slots, rows, regions) are all functions of the thread index.  Left alone, the compiler
         // computes dozens of them once, keeps them across the tile loop and spills them at 64 registers; every scratch
         // reload then carries an s_waitcnt vmcnt(0), which (vmcnt is in order) also waits for the prefetched rows and for
@@ -675,6 +709,10 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
         // operations per phase, no spill.
         int td = tid; asm volatile("" : "+v"(td));
         const int ln = td & 63; const u32 so_ = (u32)td & 255u, sq_ = (u32)td >> 8;
+        // the tile after next: asked for now, parked in LDS at the end of the iteration.  A workgroup whose list of tiles or
+        // whose regions are nearly full stops asking (the others take what is left).
+        u32 t_nn = 0xFFFFFFFFu;
+        if (td == 0 && n_taken < R.tiles_max) { t_nn = P + (u32)atomicAdd(&ctr->rt_next, 1ull); n_taken++; }
         auto prefetch_rows = [&](u64 tn) {          // rows of this workgroup's next tile into xn / len_raw
             const u64 gn = tn * NW + wave, gc = gn < n_groups ? gn : 0, rn = gc * 64 + ln;
             const v2u* row = reinterpret_cast<const v2u*>(packed) + gc * (32 * WPR) + ln;
@@ -704,16 +742,30 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
         #pragma unroll
         for (int t = 0; t < NT; t++) {
             const u32 rb_nxt = revc(w[t + 1]);
-            hv[t] = 0; rk[t] = 0xFFFFFFFFu;
-            if (t < nseeds) {      // (a branch per seed keeps the nine hashes from being scheduled side by side, which spills)
-                const u32 slo = w[t], shi = w[t + 1] & 0xFFu;
-                const u32 rlo = __builtin_amdgcn_alignbit(rb_cur, rb_nxt, 24), rhi = rb_cur >> 24;
-                const bool rc_less = rhi < shi || (rhi == shi && rlo < slo);
-                u32 ow, hh; rt_hash(rc_less ? rlo : slo, rc_less ? rhi : shi, ow, hh);
-                hv[t] = hh;
-                rk[t] = (ow << 16) | atomicAdd(&s_cnt[wave][ow], 1u);      // a run holds at most 64 * NT entries
-            }
+            const u32 slo = w[t], shi = w[t + 1] & 0xFFu;
+            const u32 rlo = __builtin_amdgcn_alignbit(rb_cur, rb_nxt, 24), rhi = rb_cur >> 24;
+            const bool rc_less = rhi < shi || (rhi == shi && rlo < slo);
+            u32 ow; rt_hash(rc_less ? rlo : slo, rc_less ? rhi : shi, ow, hv[t]);
+            rk[t] = ow;
             rb_cur = rb_nxt;
+            asm volatile("" : "+v"(hv[t]), "+v"(rk[t]), "+v"(rb_cur));      // one hash after the other: side by side they need more than 64 registers
+        }
+        // the counting atomics in two batches, one wait per batch (one after the other, each waited for, they were a chain of
+        // nine LDS round trips per tile; all nine at once need more than the 64 registers of this kernel)
+        {
+            constexpr int H = (NT + 1) / 2;
+            u32 ra[H];
+            #pragma unroll
+            for (int t = 0; t < H; t++) { ra[t] = 0; if (t < nseeds) ra[t] = atomicAdd(&s_cnt[wave][rk[t]], 1u); }      // a run holds at most 64 * NT entries
+            tie_all<H>(ra);
+            #pragma unroll
+            for (int t = 0; t < H; t++) rk[t] = t < nseeds ? ((rk[t] << 16) | ra[t]) : 0xFFFFFFFFu;
+            u32 rb[NT - H > 0 ? NT - H : 1];
+            #pragma unroll
+            for (int t = H; t < NT; t++) { rb[t - H] = 0; if (t < nseeds) rb[t - H] = atomicAdd(&s_cnt[wave][rk[t]], 1u); }
+            tie_all<(NT - H > 0 ? NT - H : 1)>(rb);
+            #pragma unroll
+            for (int t = H; t < NT; t++) rk[t] = t < nseeds ? ((rk[t] << 16) | rb[t - H]) : 0xFFFFFFFFu;
         }
         lds_barrier();
         // ---- run lengths and starts.  Thread (sq_, so_) owns the runs of waves 4 sq_ .. 4 sq_ + 3 for owner so_.  An empty run
@@ -757,9 +809,11 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
             }
             #pragma unroll
             for (int v = 0; v < 4; v++) s_cnt[sq_ * 4 + v][so_] = 0;
-            prefetch_rows(tile + P);
+            prefetch_rows(t_nxt);
+            if (td == 0) s_tile = t_nn;
             lds_barrier();
             if (td == 0) s_over = 0;
+            tile = t_nxt; t_nxt = s_tile;
             lds_barrier();
             continue;
         }
@@ -777,7 +831,7 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
             }
         }
         lds_barrier();
-        prefetch_rows(tile + P);      // requested here, when the seeds' registers are free again; in flight during the write-out
+        prefetch_rows(t_nxt);         // requested here, when the seeds' registers are free again; in flight during the write-out
         // ---- append every owner's segment to its region; wave v serves owners OPW v .. OPW v + OPW - 1, four at a time:
         // 16 lanes per owner, 16 bytes per ln (segments and regions are multiples of four entries)
         {
@@ -809,11 +863,12 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
         }
         #pragma unroll
         for (int v = 0; v < 4; v++) s_cnt[sq_ * 4 + v][so_] = 0;
-        if (td == 0) { R.emitted[(u64)p * (R.tiles_max + 1) + 1 + n_emit] = k; n_emit++; }
+        if (td == 0) { R.emitted[(u64)p * (R.tiles_max + 1) + 1 + n_emit] = (u32)tile; n_emit++; s_tile = t_nn; }
         lds_barrier();
+        tile = t_nxt; t_nxt = s_tile;      // (s_tile is next written behind the first barrier of the following iteration)
     }
     if (tid < RT_OWNERS) R.counts[(u64)tid * P + p] = s_cur[tid];
-    if (tid == 0) R.emitted[(u64)p * (R.tiles_max + 1)] = n_emit;
+    if (tid == 0) { R.emitted[(u64)p * (R.tiles_max + 1)] = n_emit; rt_trace_end(R, p); }
 }
 
 // examine up to 64 parked survivors of one wave: re-hash the read's seeds, probe the fingerprint sieve with those whose
@@ -821,13 +876,22 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
 // that walked its seeds one load at a time held its wave for a dozen memory latencies per survivor.  The read's length is
 // not fetched: rows hold zeros beyond the read, and a window of them that happened to reproduce the entry's 33 hash
 // bits AND sat in the fingerprint sieve would add a candidate, which k_seed looks up exactly like every other.
+// A parked entry: hash (25 bits) | lane << 25 | producer wave << 31 | position of the tile in the producer's list << 35 |
+// producer << 51.  The tile's number is looked up here, not where the entry passed the filter: a dependent global load
+// there stalled the streaming loop in three iterations out of four (0.90 -> 1.00 ms).
+__device__ inline u64 rt_park(u32 entry, u32 wv, u32 jt, u32 p) {
+    return (u64)(entry & (RT_HMASK | (63u << 25))) | ((u64)wv << 31) | ((u64)jt << 35) | ((u64)p << 51);
+}
 template <int WPR>
-__device__ inline void rt_examine(const u64* q, u32 cnt, int lane, u32 owner, const u32* __restrict__ packed,
+__device__ inline void rt_examine(const u64* q, u32 cnt, int lane, u32 owner, const u32* __restrict__ packed, u64 n_reads, const RouteDev& R, u32 NWP,
                                   const uint4* __restrict__ sieve, u32 smask, u32 sshift, u32* flags) {
     constexpr int NT = WPR - 1;
     if ((u32)lane >= cnt) return;
     const u64 e = q[lane];
-    const u64 rr = e & 0xFFFFFFFFull; const u32 want = (u32)(e >> 32);
+    const u32 want = (u32)e & RT_HMASK, ln = ((u32)e >> 25) & 63u, wv = (u32)(e >> 31) & 15u, jt = (u32)(e >> 35) & 0xFFFFu, p = (u32)(e >> 51);
+    const u32 tile = R.emitted[(u64)p * (R.tiles_max + 1) + 1 + jt];
+    const u64 rr = ((u64)tile * NWP + wv) * 64 + ln;
+    if (rr >= n_reads) return;
     const u32* row = packed + packed_index(rr, WPR, 0);      // word c of the row: row[(c >> 1) * 128 + (c & 1)]
     u32 w[WPR];
     #pragma unroll
@@ -845,7 +909,7 @@ __device__ inline void rt_examine(const u64* q, u32 cnt, int lane, u32 owner, co
     if (hit) atomicOr(&flags[rr >> 5], 1u << (rr & 31));
 }
 template <int WPR>
-__global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ packed, const u16* __restrict__ lens, u64 n_reads,
+__global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ packed, u64 n_reads,
                                                       const uint4* __restrict__ sieve, u32 smask, const RouteDev R, Counters* __restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) u32 s_f[RT_FWORDS];
     __shared__ u64 s_q[16][128];                  // per-wave queue of entries that passed the filter: read | hash << 32
@@ -855,6 +919,7 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 owner = blockIdx.x, P = R.n_prod;
     const u32 sshift = (u32)__clz((int)smask);
+    if (tid == 0) rt_trace_begin(R, P + owner);
     {
         const v4u* g4 = reinterpret_cast<const v4u*>(R.filter.p + (u64)owner * RT_FWORDS); v4u* s4 = reinterpret_cast<v4u*>(s_f);
         #pragma unroll
@@ -862,27 +927,22 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
     }
     __syncthreads();
     const u32 NWP = R.nw;                          // runs per tile in a region (one per producer wave)
-    const u64 n_tiles = (n_reads + (u64)NWP * 64 - 1) / ((u64)NWP * 64);
     u64* const q = s_q[wave]; u32 qn = 0, n_pass = 0;      // wave-uniform: parked entries; entries that passed the filter so far
     const u64 lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     const v4u none4 = {RT_DUMMY, RT_DUMMY, RT_DUMMY, RT_DUMMY};      // lanes beyond a region's end: neither a seed nor a run start
-    // the entry counts and routed-tile counts of this wave's regions (lane i: region wave + 16 i), fetched once: read
-    // region by region they cost two dependent round trips in front of every region's first load
-    u32 my_n[RT_MAXP / 1024], my_em[RT_MAXP / 1024];
+    // the entry counts of this wave's regions (lane i: region wave + 16 i), fetched once: read region by region they cost a
+    // dependent round trip in front of every region's first load
+    u32 my_n[RT_MAXP / 1024];
     #pragma unroll
     for (int c = 0; c < RT_MAXP / 1024; c++) {
         const u32 pp = (u32)wave + 16u * ((u32)lane + 64u * c);
         my_n[c] = pp < P ? R.counts[(u64)owner * P + pp] : 0u;
-        my_em[c] = pp < P ? R.emitted[(u64)pp * (R.tiles_max + 1)] : 0u;
     }
     for (u32 p = (u32)wave, pi = 0; p < P; p += 16, pi++) {      // this wave's regions
-        u32 n = 0, em0 = 0;
+        u32 n = 0;
         #pragma unroll
-        for (int c = 0; c < RT_MAXP / 1024; c++) if ((pi >> 6) == (u32)c) { n = (u32)__shfl((int)my_n[c], (int)(pi & 63)); em0 = (u32)__shfl((int)my_em[c], (int)(pi & 63)); }
+        for (int c = 0; c < RT_MAXP / 1024; c++) if ((pi >> 6) == (u32)c) n = (u32)__shfl((int)my_n[c], (int)(pi & 63));
         n = (u32)__builtin_amdgcn_readfirstlane((int)n);
-        const auto emit = R.emitted.g() + (u64)p * (R.tiles_max + 1);
-        const u32 n_mine = p < n_tiles ? (u32)((n_tiles - p + P - 1) / P) : 0u;      // tiles the producer was dealt
-        const bool ident = (u32)__builtin_amdgcn_readfirstlane((int)em0) == n_mine;      // every one of them was routed
         const auto ent4 = reinterpret_cast<const v4u GLOBAL_AS*>(R.arena.g() + ((u64)owner * P + p) * R.cap);
         int seq = -1;                               // flags seen so far - 1 = sequence number of the current (tile, wave) run
         v4u en[PF];
@@ -924,21 +984,14 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     run += fg[j] ? 1 : 0;
-                    bool pass = sd[j] && (((f0[j] & k0[j]) ^ k0[j]) | ((f1[j] & k1[j]) ^ k1[j])) == 0u;
-                    u64 rr = 0;
-                    if (pass) {
-                        const u32 jt = NWP == 16 ? (u32)run >> 4 : (u32)run >> 3, wv = (u32)run & (NWP - 1u);
-                        const u32 kk = ident ? jt : emit[1 + jt];
-                        rr = (((u64)p + (u64)kk * P) * NWP + wv) * 64 + ((ev[u][j] >> 25) & 63u);
-                        pass = rr < n_reads;
-                    }
+                    const bool pass = sd[j] && (((f0[j] & k0[j]) ^ k0[j]) | ((f1[j] & k1[j]) ^ k1[j])) == 0u;
                     const u64 pm = __ballot(pass);
                     if (pm) {
-                        if (pass) q[qn + (u32)__popcll(pm & lt)] = rr | ((u64)(ev[u][j] & RT_HMASK) << 32);
+                        if (pass) q[qn + (u32)__popcll(pm & lt)] = rt_park(ev[u][j], (u32)run & (NWP - 1u), NWP == 16 ? (u32)run >> 4 : (u32)run >> 3, p);
                         qn += (u32)__popcll(pm);
                         if (qn >= 64) {
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            rt_examine<WPR>(q + (qn - 64), 64, lane, owner, packed, sieve, smask, sshift, R.flags.p);
+                            rt_examine<WPR>(q + (qn - 64), 64, lane, owner, packed, n_reads, R, NWP, sieve, smask, sshift, R.flags.p);
                             qn -= 64; n_pass += 64;
                         }
                     }
@@ -948,11 +1001,11 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    rt_examine<WPR>(q, qn, lane, owner, packed, sieve, smask, sshift, R.flags.p);
+    rt_examine<WPR>(q, qn, lane, owner, packed, n_reads, R, NWP, sieve, smask, sshift, R.flags.p);
     n_pass += qn;
     if (lane == 0 && n_pass) atomicAdd(&ctr->cnt[MLST_CNT_SIEVE_PASS], (u64)n_pass);
     __syncthreads();
-    if (tid == 0) atomicMax(&ctr->sv_t1, (u64)wall_clock64());
+    if (tid == 0) { atomicMax(&ctr->sv_t1, (u64)wall_clock64()); rt_trace_end(R, P + owner); }
 }
 
 // candidate flags -> candidate list (one atomic per 1024-thread workgroup that holds candidates)
@@ -960,6 +1013,7 @@ __global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ f
     __shared__ u32 s_cnt[16]; __shared__ u64 s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u64 n_words = (n_reads + 31) >> 5;
+    if (blockIdx.x == 0 && tid == 0) ctr->rt_next = 0;      // the producers' tile counter, for the next submission
     for (u64 w0 = (u64)blockIdx.x * 1024; w0 < n_words; w0 += (u64)gridDim.x * 1024) {
         const u64 wi = w0 + tid;
         u32 f = wi < n_words ? flags[wi] : 0u;
@@ -985,36 +1039,22 @@ __global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ f
 }
 
 // ------------------------------------------------------------------ BGZF -> text (one wave per <= 64 KiB deflate block)
-// Every lane of the wave runs the decoder on the same stream, so control flow is wave-uniform (64 different streams in
-// one wave would each wait for the longest match copy of the others) and reads are broadcasts; what the lanes share out
-// is the copying: lane k moves byte k of a match or of a stored block.  A match may overlap its own output
-// (dist < len): source byte k is then byte k mod dist of the period, which lies entirely before the write position.
 struct BgzfBlk { u64 in_off, out_off; u32 in_len, out_len; };
-struct OutWave {
-    u8* out; uint64_t op; int lane;
-    uint64_t safe;        // bytes below this position were stored before the last fence
-    __device__ void put(u8 c) { if (lane == 0) out[op] = c; op++; }
-    __device__ void copy(u32 dist, u32 len) {
-        // source bytes that other lanes of this wave stored since the last fence have to be done before they are read
-        // back; most matches reach further back than that and need no wait
-        if (op - dist + (dist < len ? dist : len) > safe) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); safe = op; }
-        const u8* src = out + op - dist;
-        for (u32 k = (u32)lane; k < len; k += 64) out[op + k] = src[dist >= len ? k : k % dist];
-        op += len;
-    }
-    __device__ void raw(const u8* src, u32 len) { for (u32 k = (u32)lane; k < len; k += 64) out[op + k] = src[k]; op += len; }
-};
-__attribute__((amdgpu_waves_per_eu(6, 6)))      // the decoder is a chain of dependent loads: six waves per SIMD measured best (4: -10 %)
-__global__ __launch_bounds__(64) void k_inflate(const u8* __restrict__ comp, const BgzfBlk* __restrict__ blk, u32 n_blk, u8* __restrict__ out, u32* __restrict__ err /* [0] = 1 + first bad block, [1] = its code */) {
-    __shared__ mlst_inflate::Tables s_tb;         // Huffman tables of the stream: LDS latency per code, not scratch-memory latency
+// one wave per block (csrc/inflate_wave.h); comp_bytes = size of the compressed buffer (the input windows stop there)
+__global__ __launch_bounds__(64) void k_inflate(const u8* __restrict__ comp, u64 comp_bytes, const BgzfBlk* __restrict__ blk, u32 n_blk, u8* __restrict__ out,
+                                                u32* __restrict__ err /* [0] = 1 + first bad block, [1] = its code */) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ inflate_wave::Tabs s_tb;           // Huffman tables of the stream
+    const int lane = (int)threadIdx.x;
     for (u32 i = blockIdx.x; i < n_blk; i += gridDim.x) {     // wave-uniform
         const BgzfBlk B = blk[i];
-        OutWave o; o.out = out + B.out_off; o.op = 0; o.lane = (int)threadIdx.x; o.safe = 0;
-        int rc = mlst_inflate::inflate_stream(comp + B.in_off, (uint64_t)B.in_len, o, (uint64_t)B.out_len, &s_tb);
-        if (rc == mlst_inflate::OK && o.op != B.out_len) rc = mlst_inflate::E_SHORT;
-        if (rc != mlst_inflate::OK && threadIdx.x == 0 && atomicCAS(&err[0], 0u, i + 1u) == 0u) err[1] = (u32)(-rc);
-        __syncthreads();                          // the tables are rebuilt for the next stream
+        u32 produced = 0;
+        int rc = inflate_wave::inflate_stream(comp + B.in_off, (u64)B.in_len, comp + comp_bytes, out + B.out_off, B.out_len, s_tb, lane, &produced);
+        if (rc == mlst_inflate::OK && produced != B.out_len) rc = mlst_inflate::E_SHORT;
+        if (rc != mlst_inflate::OK && lane == 0 && atomicCAS(&err[0], 0u, i + 1u) == 0u) err[1] = (u32)(-rc);
+        inflate_wave::wave_sync();                // the tables are rebuilt for the next stream
     }
+#endif
 }
 // ------------------------------------------------------------------ FASTQ text -> packed reads (GPU parser)
 #define FQ_BLOCK 4096        // bytes of text per workgroup
@@ -1059,8 +1099,11 @@ __global__ __launch_bounds__(256) void k_fq_lines(const u8* __restrict__ text, u
     }
 }
 // pass D: per record the byte ranges of the sequence line (4r+1) and the quality line (4r+3); CR stripped
+// pair_k != 0: the text is two files of mates one after the other, pair_k records each; record j of the first becomes read
+// 2j, record j of the second read 2j + 1 (mates side by side, the order a paired submission expects)
 __global__ __launch_bounds__(256) void k_fq_records(const u8* __restrict__ text, u64 n_bytes, const u64* __restrict__ line_start, u64 n_lines, u64 n_reads,
-                                                     u64* __restrict__ seq_off, u64* __restrict__ qual_off, u16* __restrict__ lens, u32* __restrict__ flags /* [0]=max len, [1]=errors */) {
+                                                     u64* __restrict__ seq_off, u64* __restrict__ qual_off, u16* __restrict__ lens, u32* __restrict__ flags /* [0]=max len, [1]=errors */,
+                                                     u64 pair_k) {
     u32 mx = 0, err = 0;
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (u64)gridDim.x * blockDim.x) {
         u64 s0 = line_start[4 * r + 1], s1 = line_start[4 * r + 2], q0 = line_start[4 * r + 3];
@@ -1072,7 +1115,8 @@ __global__ __launch_bounds__(256) void k_fq_records(const u8* __restrict__ text,
         u64 ls = se - s0, lq = qe - q0;
         if (text[line_start[4 * r]] != '@' || ls != lq) err = 1;
         if (ls > MLST_MAX_READ_LEN) { err |= 2; ls = MLST_MAX_READ_LEN; }
-        seq_off[r] = s0; qual_off[r] = q0; lens[r] = (u16)ls;
+        const u64 o = pair_k ? (r < pair_k ? 2 * r : 2 * (r - pair_k) + 1) : r;
+        seq_off[o] = s0; qual_off[o] = q0; lens[o] = (u16)ls;
         if ((u32)ls > mx) mx = (u32)ls;
     }
     if (mx) atomicMax(&flags[0], mx);
@@ -2369,6 +2413,8 @@ struct mlst_handle {
     int sieve_kind = 0; u32 sieve_chain = 0; u64 n_keys = 0;
     u32* d_rfilter = nullptr; u32* d_rt_arena = nullptr; u64 cap_rt_arena = 0; u32* d_rt_counts = nullptr; u32* d_rt_emitted = nullptr; u64 cap_rt_emitted = 0;
     u32 rt_prod = 0, rt_cap = 0, rt_tiles_max = 0, rt_nw = 16;
+    u64* d_rt_trace = nullptr; bool rt_trace_on = false; const void* rt_last_packed = nullptr;      // mlst_get_route_trace
+    std::vector<void*> dbg_pads;                 // mlst_debug_route_realloc: allocations kept to move the arena elsewhere
     u32* d_bin_flags = nullptr; u64 cap_bin_flags = 0;      // candidate flag per read of the current submission
     u8* d_in_bases = nullptr; u8* d_in_quals = nullptr; u64* d_in_off = nullptr; u64 cap_in_bytes = 0, cap_in_reads = 0;
     u32* d_packed = nullptr; u8* d_qrows = nullptr; u16* d_lens = nullptr; u64 cap_packed_words = 0, cap_qrow_bytes = 0, cap_lens = 0;
@@ -2521,7 +2567,9 @@ static void free_ref(mlst_handle* h) {
 static void free_state(mlst_handle* h) {
     EngineDev& E = h->E;
     hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; h->cap_bin_flags = 0;
-    hipFree(h->d_rt_arena); hipFree(h->d_rt_counts); hipFree(h->d_rt_emitted);
+    hipFree(h->d_rt_arena); hipFree(h->d_rt_counts); hipFree(h->d_rt_emitted); hipFree(h->d_rt_trace); h->d_rt_trace = nullptr;
+    for (void* q : h->dbg_pads) hipFree(q);
+    h->dbg_pads.clear();
     h->d_rt_arena = nullptr; h->d_rt_counts = nullptr; h->d_rt_emitted = nullptr; h->cap_rt_arena = 0; h->cap_rt_emitted = 0; h->rt_prod = 0;
     hipFree(h->d_E); h->d_E = nullptr;
     hipFree(h->d_stats); h->d_stats = nullptr; if (h->h_stats) { hipHostFree(h->h_stats); h->h_stats = nullptr; }
@@ -2788,7 +2836,7 @@ static std::shared_ptr<HostIndex> build_host_index(const uint8_t* ascii, const u
 // The last host index built in this process: a second engine that loads the same database (several engines per GPU,
 // several GPUs per process) uploads it without building it again.
 static std::mutex g_index_mu;
-static std::shared_ptr<HostIndex> g_index_last; static u64 g_index_key[3] = {0, 0, 0};
+static std::shared_ptr<HostIndex> g_index_last; static u64 g_index_key[5] = {0, 0, 0, 0, 0};      // hashes of the inputs + their sizes
 
 static int sieve_kind_from_env() {
     const char* s = getenv("MLST_SIEVE");
@@ -2811,18 +2859,21 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     const int want_kind = sieve_kind_from_env();
     std::shared_ptr<HostIndex> HI;
     {
-        u64 key[3];
+        u64 key[5];
+        key[3] = n_alleles; key[4] = off[n_alleles];
         key[0] = fnv1a(off, ((u64)n_alleles + 1) * 8, 0xCBF29CE484222325ull ^ n_alleles);
         key[1] = fnv1a(ascii, off[n_alleles], fnv1a(locus_id, (u64)n_alleles * 4, 0x9E3779B97F4A7C15ull));
         key[2] = (u64)(want_kind + 2);
         for (const char* v : {"MLST_GBM_BITS"}) { const char* e = getenv(v); if (e) key[2] = fnv1a(e, strlen(e), key[2]); }
         if (species_id) key[2] = fnv1a(species_id, (u64)n_alleles * 4, key[2]);
         std::lock_guard<std::mutex> lk(g_index_mu);
-        if (g_index_last && g_index_key[0] == key[0] && g_index_key[1] == key[1] && g_index_key[2] == key[2]) HI = g_index_last;
+        const char* nocache = getenv("MLST_INDEX_CACHE");
+        if (nocache && nocache[0] == '0') g_index_last.reset();
+        if (g_index_last && memcmp(g_index_key, key, sizeof key) == 0) HI = g_index_last;
         else {
             HI = build_host_index(ascii, off, locus_id, species_id, n_alleles, want_kind);
             if (HI->err_code) return fail(h, HI->err_code, "%s", HI->err.c_str());
-            g_index_last = HI; g_index_key[0] = key[0]; g_index_key[1] = key[1]; g_index_key[2] = key[2];
+            if (!(nocache && nocache[0] == '0')) { g_index_last = HI; memcpy(g_index_key, key, sizeof key); }
         }
     }
     const u32 n_loci = HI->n_loci; h->n_loci = n_loci;
@@ -2948,7 +2999,9 @@ extern "C" int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, co
     if (!h) return MLST_E_INVALID;
     hipSetDevice(h->device);
     if (wpr == 0 || wpr > RW || (wpr & 1)) return fail(h, MLST_E_INVALID, "words_per_read must be even and in 2..%d", RW);
-    if (qstride < 1 || qstride > RQ) return fail(h, MLST_E_INVALID, "qual_stride must be in 1..%d", RQ);
+    // (k_pack stores quality rows as 32-bit words: a stride that is not a multiple of four would tear neighbouring rows)
+    if (qstride < 4 || qstride > RQ || (qstride & 3)) return fail(h, MLST_E_INVALID, "qual_stride must be a multiple of 4 in 4..%d", RQ);
+    if (((uintptr_t)d_qrows & 3) != 0) return fail(h, MLST_E_INVALID, "quality rows must be 4-byte aligned");
     if (n_reads == 0) return MLST_OK;
     Prof pf(h, 6);
     hipLaunchKernelGGL(k_pack, dim3(grid_for((n_reads + 63) / 64, 1, 8192)), dim3(256), 0, h->stream, d_bases, d_quals, (const u64*)d_off, (u64)n_reads,
@@ -2966,10 +3019,12 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     { const char* e = getenv("MLST_ROUTE_BLOCKS"); if (e && atoi(e) > 0) prod = (u32)atoi(e); }
     if (prod > RT_MAXP) prod = RT_MAXP;
     if (prod > n_tiles) prod = (u32)(n_tiles ? n_tiles : 1);
-    const u64 tiles_max = (n_tiles + prod - 1) / prod;
+    // tiles are handed out dynamically: a workgroup may take up to half as many again as its even share (the spread seen
+    // is +-20 %); the capacities below (list of tiles, regions) are sized for that and a workgroup stops asking at the bound
+    const u64 tiles_max = (n_tiles + prod - 1) / prod * 3 / 2 + 8;
     // expected entries per (owner, tile): tile * seeds / 256 + dummies (~10 % of nw) + ~2 of padding; 25 % and a constant on top
     u64 cap = (u64)((double)tiles_max * ((double)tile / 256.0 * (wpr - 1) + 0.15 * nw + 2.0) * 1.25) + 256; cap = (cap + 3) & ~3ull;
-    if (cap >= (1ull << 31)) return fail(h, MLST_E_LIMIT, "batch too large for the routed sieve");
+    if (cap >= (1ull << 31) || tiles_max > 0xFFFFull) return fail(h, MLST_E_LIMIT, "batch too large for the routed sieve (%llu tiles per producer workgroup)", (unsigned long long)tiles_max);
     const u64 need = (u64)RT_OWNERS * prod * cap;
     if (h->cap_rt_arena < need || h->rt_prod != prod || h->rt_cap != (u32)cap) {
         hipStreamSynchronize(h->stream);
@@ -2980,6 +3035,7 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     const u64 need_e = (u64)prod * (tiles_max + 1);
     if (h->cap_rt_emitted < need_e) { hipStreamSynchronize(h->stream); hipFree(h->d_rt_emitted); h->d_rt_emitted = nullptr; HIPCHK(h, dmalloc(&h->d_rt_emitted, need_e)); h->cap_rt_emitted = need_e; }
     h->rt_tiles_max = (u32)tiles_max; h->rt_nw = nw;
+    if (h->rt_trace_on && !h->d_rt_trace) { hipStreamSynchronize(h->stream); HIPCHK(h, dmalloc(&h->d_rt_trace, (u64)(RT_MAXP + RT_OWNERS) * 4)); HIPCHK(h, hipMemset(h->d_rt_trace, 0, (u64)(RT_MAXP + RT_OWNERS) * 32)); }
     const u64 n_flag_words = (n_reads + 31) >> 5;
     if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words; }
     return MLST_OK;
@@ -3006,7 +3062,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
                                                (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand,
                                                (u64)(uintptr_t)h->d_bin_flags, (u64)(uintptr_t)h->d_rt_arena, (u64)(uintptr_t)h->d_rt_counts,
-                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw, (u64)paired});
+                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw, (u64)paired, (u64)(uintptr_t)h->d_rt_trace});
     if (gs == 1) { h->reads_seen += n_reads; return MLST_OK; }
     { Prof pf(h, 0);
       if (h->sieve_kind == MLST_SIEVE_LDS) {      // LDS first level: one 1024-thread workgroup per CU
@@ -3018,7 +3074,8 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       } else if (h->sieve_kind == MLST_SIEVE_ROUTED) {      // seeds routed to the CU that owns their filter slice (K1c)
         const u64 n_flag_words = (n_reads + 31) >> 5;
         zero_words(h, h->d_bin_flags, n_flag_words);
-        RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags;
+        RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags; R.trace = h->d_rt_trace;
+        h->rt_last_packed = d_packed;
         R.cap = h->rt_cap; R.n_prod = h->rt_prod; R.tiles_max = h->rt_tiles_max; R.nw = h->rt_nw;
         { Prof pa(h, 9);
 #define SIEVE_CASE(W) case W: if (h->rt_nw == 8) hipLaunchKernelGGL((k_route<W, 8>), dim3(h->rt_prod), dim3(512), 0, h->stream, d_packed, d_lens, (u64)n_reads, R, E.ctr); \
@@ -3028,7 +3085,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
 #undef SIEVE_CASE
         }
         { Prof pb(h, 10);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_route_probe<W>, dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); break;
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_route_probe<W>, dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
@@ -3139,7 +3196,9 @@ static int next_text_slot(mlst_handle* h, u64 bytes) {
 
 // FASTQ text in h->d_fq_text[0 .. n_bytes) -> packed reads -> pass 1.  whole: the text consists of whole records; else
 // the partial record at its end is kept (h->d_fq_carry) for the next chunk.
-static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, uint64_t* n_reads_out) {
+// pair_boundary != 0 (whole text only): the text is two mate files back to back, the second starting at that byte; both
+// must hold the same number of records, which are then interleaved (k_fq_records) and submitted as pairs.
+static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, uint64_t* n_reads_out, u64 pair_boundary = 0) {
     const u64 n_blocks = (n_bytes + FQ_BLOCK - 1) / FQ_BLOCK;
     if (h->cap_fq_blk < n_blocks) { hipFree(h->d_fq_blk); h->d_fq_blk = nullptr; HIPCHK(h, dmalloc(&h->d_fq_blk, n_blocks + 1)); h->cap_fq_blk = n_blocks; }
     HIPCHK(h, hipMemsetAsync(h->d_fq_meta, 0, 16, h->stream));
@@ -3169,13 +3228,23 @@ static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, u
         n_bytes = end_off; n_lines = 4 * n_reads;
     }
     if (n_reads == 0) { HIPCHK(h, hipEventRecord(h->ev_packed[h->fq_slot], h->stream)); return MLST_OK; }
+    u64 pair_k = 0;
+    if (pair_boundary) {
+        if (n_reads & 1) return fail(h, MLST_E_INVALID, "mate files hold different numbers of records (%llu records in all)", (unsigned long long)n_reads);
+        pair_k = n_reads / 2;
+        u64 second = 0;
+        HIPCHK(h, hipMemcpyAsync(&second, h->d_fq_lines + 4 * pair_k, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (second != pair_boundary) return fail(h, MLST_E_INVALID, "mate files hold different numbers of records (record %llu starts at byte %llu, the second file at %llu)",
+                                                 (unsigned long long)pair_k, (unsigned long long)second, (unsigned long long)pair_boundary);
+    }
     if (h->cap_fq_reads < n_reads) { hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); h->d_fq_soff = h->d_fq_qoff = nullptr;
                                      HIPCHK(h, dmalloc(&h->d_fq_soff, n_reads)); HIPCHK(h, dmalloc(&h->d_fq_qoff, n_reads)); h->cap_fq_reads = n_reads; }
     // lengths are needed before the packed buffers can be sized: worst-case row width first, then the real one
     int rc = ensure_pack_buffers(h, n_reads, 2, 8); if (rc) return rc;
     u32* d_flags = reinterpret_cast<u32*>(h->d_fq_meta + 1);
     hipLaunchKernelGGL(k_fq_records, dim3(grid_for(n_reads, 256)), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_lines, n_lines, n_reads,
-                       h->d_fq_soff, h->d_fq_qoff, h->d_lens, d_flags);
+                       h->d_fq_soff, h->d_fq_qoff, h->d_lens, d_flags, pair_k);
     u32 flags[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(flags, d_flags, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -3213,6 +3282,39 @@ extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n
     if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
     { int rc = h2d_overlapped(h, h->d_fq_text, text, n_bytes, h->ev_packed[h->fq_slot]); if (rc) return rc; }
     return fastq_pipeline(h, n_bytes, paired, true, n_reads_out);
+}
+
+extern "C" int mlst_submit_fastq_stream(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (n_reads_out) *n_reads_out = 0;
+    if (n_bytes && !text) return fail(h, MLST_E_INVALID, "NULL argument");
+    const u64 total = h->fq_carry_len + n_bytes;
+    if (total == 0) return MLST_OK;
+    if (total >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
+    hipSetDevice(h->device);
+    { int rc = next_text_slot(h, total); if (rc) return rc; }
+    if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
+    const u64 carry = h->fq_carry_len;
+    if (carry) HIPCHK(h, hipMemcpyAsync(h->d_fq_text, h->d_fq_carry, carry, hipMemcpyDeviceToDevice, h->stream));
+    { int rc = h2d_overlapped(h, h->d_fq_text + carry, text, n_bytes, h->ev_packed[h->fq_slot]); if (rc) return rc; }
+    return fastq_pipeline(h, total, paired, final_chunk != 0, n_reads_out);
+}
+
+extern "C" int mlst_submit_fastq_pair(mlst_handle* h, const uint8_t* text1, uint64_t n1, const uint8_t* text2, uint64_t n2, uint64_t* n_reads_out) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (n_reads_out) *n_reads_out = 0;
+    if (n1 == 0 && n2 == 0) return MLST_OK;
+    if (!text1 || !text2 || n1 == 0 || n2 == 0) return fail(h, MLST_E_INVALID, "mate files hold different numbers of records (one chunk is empty)");
+    if (h->fq_carry_len) return fail(h, MLST_E_INVALID, "a FASTQ stream is open (its last chunk was not marked final)");
+    const u64 pad = text1[n1 - 1] != '\n' ? 1 : 0, total = n1 + pad + n2;
+    if (total >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
+    hipSetDevice(h->device);
+    { int rc = next_text_slot(h, total); if (rc) return rc; }
+    if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
+    { int rc = h2d_overlapped(h, h->d_fq_text, text1, n1, h->ev_packed[h->fq_slot]); if (rc) return rc; }
+    if (pad) HIPCHK(h, hipMemsetAsync(h->d_fq_text + n1, '\n', 1, h->stream));
+    { int rc = h2d_overlapped(h, h->d_fq_text + n1 + pad, text2, n2, nullptr); if (rc) return rc; }
+    return fastq_pipeline(h, total, 1, true, n_reads_out, n1 + pad);
 }
 
 // BGZF framing (SAM spec 4.1): gzip member with an extra subfield 'B','C' holding the block size - 1; deflate data; CRC32, ISIZE
@@ -3269,13 +3371,47 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
         HIPCHK(h, hipMemcpyAsync(h->d_bgzf_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->stream));
         u32* d_err = reinterpret_cast<u32*>(h->d_fq_meta + 2);
         HIPCHK(h, hipMemsetAsync(d_err, 0, 8, h->stream));
-        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(blks.size(), 1u << 20)), dim3(64), 0, h->stream, h->d_bgzf, (const BgzfBlk*)h->d_bgzf_blk, (u32)blks.size(), h->d_fq_text, d_err);
+        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(blks.size(), 1u << 20)), dim3(64), 0, h->stream, h->d_bgzf, (u64)h->cap_bgzf + 16, (const BgzfBlk*)h->d_bgzf_blk, (u32)blks.size(), h->d_fq_text, d_err);
         u32 err[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));      // also: blks / data may be released by the caller after this
         if (err[0]) return fail(h, MLST_E_INVALID, "corrupt deflate data in BGZF block %u of the chunk (code %u)", err[0] - 1, err[1]);
     }
     return fastq_pipeline(h, text_bytes, paired, final_chunk != 0, n_reads_out);
+}
+
+// k_inflate itself on whole BGZF blocks, text back to the host: the test hook of the DEVICE decoder (tests/test_inflate.py
+// compares it with zlib block by block on the GPU box)
+extern "C" int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, uint8_t* out, uint64_t cap, uint64_t* produced) {
+    if (!h) return MLST_E_INVALID;
+    if (produced) *produced = 0;
+    if (!data || !out) return fail(h, MLST_E_INVALID, "NULL argument");
+    hipSetDevice(h->device);
+    std::vector<BgzfBlk> blks; u64 text_bytes = 0;
+    for (u64 off = 0; off < n_bytes; ) {
+        u64 total, coff, clen; u32 isize;
+        if (!bgzf_block(data + off, n_bytes - off, total, coff, clen, isize)) return fail(h, MLST_E_INVALID, "not a whole BGZF block at byte %llu", (unsigned long long)off);
+        if (isize > 65536) return fail(h, MLST_E_INVALID, "BGZF block claims %u bytes of data", isize);
+        if (isize) { BgzfBlk b; b.in_off = off + coff; b.in_len = (u32)clen; b.out_off = text_bytes; b.out_len = isize; blks.push_back(b); text_bytes += isize; }
+        off += total;
+    }
+    if (text_bytes > cap) return fail(h, MLST_E_LIMIT, "output buffer too small (%llu bytes needed)", (unsigned long long)text_bytes);
+    if (produced) *produced = text_bytes;
+    if (blks.empty()) return MLST_OK;
+    u8* d_in = nullptr; u8* d_out = nullptr; BgzfBlk* d_blk = nullptr; u32* d_err = nullptr;
+    int rc = MLST_OK; u32 err[2] = {0, 0};
+    if (dmalloc(&d_in, n_bytes + 16) != hipSuccess || dmalloc(&d_out, text_bytes + 16) != hipSuccess || dmalloc(&d_blk, (u64)blks.size()) != hipSuccess || dmalloc(&d_err, (u64)2) != hipSuccess)
+        rc = fail(h, MLST_E_HIP, "device allocation failed");
+    if (!rc && (hipMemcpy(d_in, data, n_bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice) != hipSuccess
+                || hipMemset(d_err, 0, 8) != hipSuccess || hipMemset(d_out, 0xEE, text_bytes) != hipSuccess)) rc = fail(h, MLST_E_HIP, "copy to the device failed");
+    if (!rc) {
+        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(blks.size(), 1u << 20)), dim3(64), 0, h->stream, d_in, (u64)n_bytes + 16, (const BgzfBlk*)d_blk, (u32)blks.size(), d_out, d_err);
+        if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(err, d_err, 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out, d_out, text_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(h, MLST_E_HIP, "k_inflate failed: %s", hipGetErrorString(hipGetLastError()));
+        else if (err[0]) rc = fail(h, MLST_E_INVALID, "corrupt deflate data in BGZF block %u (code %u)", err[0] - 1, err[1]);
+    }
+    hipFree(d_in); hipFree(d_out); hipFree(d_blk); hipFree(d_err);
+    return rc;
 }
 
 // the decoder of k_inflate run on the host: a test hook (tests/test_inflate.py compares it with zlib without a GPU)
@@ -3661,5 +3797,31 @@ extern "C" int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]) {
 extern "C" int mlst_get_sieve_info(mlst_handle* h, uint64_t out[4]) {
     if (!h || !out || !h->have_ref) return fail(h, MLST_E_INVALID, "no reference loaded");
     out[0] = (u64)h->sieve_kind; out[1] = h->n_keys; out[2] = h->sieve_chain; out[3] = (u64)h->E.sieve_mask + 1; return MLST_OK;
+}
+extern "C" void mlst_release_index_cache(void) { std::lock_guard<std::mutex> lk(g_index_mu); g_index_last.reset(); memset(g_index_key, 0, sizeof g_index_key); }
+// ---- diagnostics of the routed sieve (profiles/route_modes.py; not a data path)
+extern "C" int mlst_get_route_trace(mlst_handle* h, uint64_t* out, uint64_t cap_words, uint64_t* n_words) {
+    if (!h) return MLST_E_INVALID;
+    hipSetDevice(h->device);
+    if (n_words) *n_words = 0;
+    if (!h->rt_trace_on) { h->rt_trace_on = true; return MLST_OK; }      // first call: switch the trace on (allocated at the next submission)
+    if (!h->d_rt_trace || !h->rt_prod) return MLST_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const u64 n_wg = (u64)h->rt_prod + RT_OWNERS, need = 8 + n_wg * 4;
+    if (n_words) *n_words = need;
+    if (!out || cap_words < need) return MLST_OK;
+    out[0] = h->rt_prod; out[1] = (u64)(uintptr_t)h->d_rt_arena; out[2] = (u64)(uintptr_t)h->rt_last_packed; out[3] = (u64)h->wall_khz;
+    out[4] = h->rt_cap; out[5] = (u64)(uintptr_t)h->d_rfilter; out[6] = (u64)(uintptr_t)h->d_bin_flags; out[7] = h->cap_rt_arena;
+    HIPCHK(h, hipMemcpy(out + 8, h->d_rt_trace, n_wg * 32, hipMemcpyDeviceToHost));
+    return MLST_OK;
+}
+extern "C" int mlst_debug_route_realloc(mlst_handle* h, uint64_t pad_bytes) {
+    if (!h) return MLST_E_INVALID;
+    hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->g_submit.exec) { hipGraphExecDestroy(h->g_submit.exec); h->g_submit.exec = nullptr; h->g_submit.sig.clear(); }
+    hipFree(h->d_rt_arena); h->d_rt_arena = nullptr; h->cap_rt_arena = 0;
+    if (pad_bytes) { void* q = nullptr; HIPCHK(h, hipMalloc(&q, pad_bytes)); h->dbg_pads.push_back(q); }
+    return MLST_OK;
 }
 extern "C" int mlst_synchronize(mlst_handle* h) { if (!h) return MLST_E_INVALID; hipSetDevice(h->device); HIPCHK(h, hipStreamSynchronize(h->stream)); return MLST_OK; }

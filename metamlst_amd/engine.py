@@ -89,6 +89,7 @@ def load_library(path: str | None = None):
         "mlst_submit_fastq": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
         "mlst_submit_fastq_bgzf": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mlst_selftest_inflate": (C.c_int, [u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "mlst_selftest_inflate_device": (C.c_int, [H, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
         "mlst_submit_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_int]),
         "mlst_pack_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, u32p, u8p, u16p, C.c_uint32, C.c_uint32]),
         "mlst_submit_packed_device": (C.c_int, [H, u32p, u8p, u16p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
@@ -121,6 +122,11 @@ def load_library(path: str | None = None):
         "mlst_reset_kernel_time": (C.c_int, [H]),
         "mlst_get_index_bytes": (C.c_int, [H, C.POINTER(C.c_uint64)]),
         "mlst_get_sieve_info": (C.c_int, [H, C.POINTER(C.c_uint64)]),
+        "mlst_release_index_cache": (None, []),
+        "mlst_submit_fastq_stream": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+        "mlst_submit_fastq_pair": (C.c_int, [H, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "mlst_get_route_trace": (C.c_int, [H, u64p, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "mlst_debug_route_realloc": (C.c_int, [H, C.c_uint64]),
         "mlst_synchronize": (C.c_int, [H]),
     }
     for name, (res, args) in sig.items():
@@ -218,6 +224,62 @@ class Engine:
                     return total
                 carry = data[int(used.value):]
                 block = nxt
+
+    def inflate_bgzf(self, data) -> bytes:
+        """Test hook: whole BGZF blocks -> their text, inflated by the device kernel."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+        out = np.empty(max(1, (buf.size // 18 + 1) * 65536), np.uint8)
+        n = C.c_uint64()
+        self._check(self.lib.mlst_selftest_inflate_device(self._h, _ptr(buf), buf.size, _ptr(out), out.size, C.byref(n)), "mlst_selftest_inflate_device")
+        return out[:int(n.value)].tobytes()
+
+    def submit_fastq_stream(self, text, final: bool, paired: bool = False) -> int:
+        """One chunk of an open FASTQ stream (cut anywhere; a partial record at its end is completed by the next chunk, text or
+        BGZF); final marks the last one.  Returns the number of records completed."""
+        buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+        n = C.c_uint64()
+        self._check(self.lib.mlst_submit_fastq_stream(self._h, _ptr(buf) if buf.size else None, buf.size, int(final), int(paired), C.byref(n)),
+                    "mlst_submit_fastq_stream")
+        return int(n.value)
+
+    def submit_fastq_pair(self, text1, text2) -> int:
+        """Two FASTQ chunks with the same number of whole records (fastq.pair_chunks): mates are interleaved on the GPU and
+        submitted as pairs.  Returns the number of reads."""
+        b1 = np.frombuffer(text1, dtype=np.uint8) if not isinstance(text1, np.ndarray) else np.ascontiguousarray(text1, np.uint8)
+        b2 = np.frombuffer(text2, dtype=np.uint8) if not isinstance(text2, np.ndarray) else np.ascontiguousarray(text2, np.uint8)
+        n = C.c_uint64()
+        self._check(self.lib.mlst_submit_fastq_pair(self._h, _ptr(b1) if b1.size else None, b1.size, _ptr(b2) if b2.size else None, b2.size, C.byref(n)),
+                    "mlst_submit_fastq_pair")
+        return int(n.value)
+
+    def submit_fastq_bgzf_range(self, path: str, lo: int, hi: int, chunk_bytes: int = 256 << 20) -> int:
+        """The records of a bgzip'd FASTQ that start in the BGZF blocks starting in compressed bytes [lo, hi): the boundary
+        blocks are inflated on the host to find the record boundaries (fastq.bgzf_range_plan), everything between goes to
+        the GPU compressed.  N ranks given consecutive ranges read every record exactly once."""
+        from .fastq import bgzf_range_plan
+        plan = bgzf_range_plan(path, lo, hi)
+        total = 0
+        first, end = plan["mid"]
+        if plan["head"]:
+            total += self.submit_fastq_stream(plan["head"], final=(first >= end and not plan["tail"]))
+        with open(path, "rb") as f:
+            f.seek(first)
+            at = first
+            n, used = C.c_uint64(), C.c_uint64()
+            carry = b""
+            while at < end:
+                block = f.read(min(chunk_bytes, end - at))
+                at += len(block)
+                data = carry + block if carry else block
+                buf = np.frombuffer(data, dtype=np.uint8)
+                last = at >= end
+                self._check(self.lib.mlst_submit_fastq_bgzf(self._h, _ptr(buf) if buf.size else None, buf.size, int(last and not plan["tail"]), 0,
+                                                            C.byref(n), None if last else C.byref(used)), "mlst_submit_fastq_bgzf")
+                total += int(n.value)
+                carry = b"" if last else data[int(used.value):]
+        if plan["tail"]:
+            total += self.submit_fastq_stream(plan["tail"], final=True)
+        return total
 
     def submit_reads_device(self, d_bases: int, d_quals: int, d_off: int, n_reads: int, max_len: int, paired: bool = False):
         self._check(self.lib.mlst_submit_reads_device(self._h, d_bases, d_quals, d_off, n_reads, max_len, int(paired)),
@@ -413,6 +475,23 @@ class Engine:
         out = (C.c_uint64 * 4)()
         self._check(self.lib.mlst_get_sieve_info(self._h, out), "mlst_get_sieve_info")
         return {"kind": SIEVE_KINDS[int(out[0])], "n_seeds": int(out[1]), "longest_chain": int(out[2]), "buckets": int(out[3])}
+
+    def route_trace(self):
+        """Diagnostics of the routed sieve's last submission (None until the trace, switched on by the first call, has
+        seen one): {P, arena, packed, khz, cap, filter, flags, arena_entries, wg: uint64[P + 256][4]}."""
+        n = C.c_uint64()
+        self._check(self.lib.mlst_get_route_trace(self._h, None, 0, C.byref(n)), "mlst_get_route_trace")
+        if not n.value:
+            return None
+        out = np.zeros(int(n.value), np.uint64)
+        self._check(self.lib.mlst_get_route_trace(self._h, _ptr(out), out.size, C.byref(n)), "mlst_get_route_trace")
+        keys = ("P", "arena", "packed", "khz", "cap", "filter", "flags", "arena_entries")
+        d = {k: int(out[i]) for i, k in enumerate(keys)}
+        d["wg"] = out[8:].reshape(-1, 4)
+        return d
+
+    def debug_route_realloc(self, pad_bytes: int = 0):
+        self._check(self.lib.mlst_debug_route_realloc(self._h, int(pad_bytes)), "mlst_debug_route_realloc")
 
     def synchronize(self):
         self._check(self.lib.mlst_synchronize(self._h), "mlst_synchronize")

@@ -5,6 +5,7 @@ reader so the engine can be fed the same files.  Plain or gzip, 4-line records, 
 from __future__ import annotations
 
 import gzip
+import os
 
 import numpy as np
 
@@ -55,28 +56,185 @@ def interleave(path1: str, path2: str, batch_pairs: int = 1_000_000, max_len: in
         yield _pack(seqs, quals, [x for p in zip(n1, n2) for x in p])
 
 
-def text_chunks(path: str, chunk_bytes: int = 256 << 20):
+def record_start(buf, pos: int = 0) -> int:
+    """Offset of the first FASTQ record that starts at or after `pos` in `buf` (bytes-like), -1 if none can be told.
+    A record starts at a line that begins with '@' whose next-but-one line begins with '+': a quality line may begin
+    with '@' too, but then the line two further on is a sequence line, which never begins with '+' (4-line records)."""
+    n = len(buf)
+    if pos <= 0:
+        p = 0
+    else:
+        p = buf.find(b"\n", pos - 1) + 1          # first line start at or after pos (pos itself when buf[pos-1] is a newline)
+        if p == 0:
+            return -1
+    while p < n:
+        e1 = buf.find(b"\n", p)
+        if e1 < 0:
+            return -1
+        e2 = buf.find(b"\n", e1 + 1)
+        if e2 < 0 or e2 + 1 >= n:
+            return -1
+        if buf[p] == 0x40 and buf[e2 + 1] == 0x2B:
+            return p
+        p = e1 + 1
+    return -1
+
+
+def last_record_start(buf, window: int = 1 << 16) -> int:
+    """Offset of the last record that starts in `buf` (so that buf[:offset] holds whole records), -1 if none.  Only the
+    tail of the buffer is looked at: the window doubles until it holds a record start."""
+    n = len(buf)
+    w = min(window, n)
+    while True:
+        lo = n - w
+        best, p = -1, record_start(buf, lo) if lo else record_start(buf, 0)
+        while p >= 0:
+            best = p
+            nxt = buf.find(b"\n", p)
+            p = record_start(buf, nxt + 1) if nxt >= 0 else -1
+        if best >= 0 or w == n:
+            return best
+        w = min(n, w * 4)
+
+
+def text_chunks(path: str, chunk_bytes: int = 256 << 20, start: int = 0, end: int | None = None):
     """Yield byte chunks of an uncompressed (or .gz) FASTQ that each hold whole records, for Engine.submit_fastq.
-    The only host work is cutting after a multiple of four lines; parsing happens on the GPU."""
+    The host never scans the text: a chunk is cut at the last record start found in its tail (record_start); parsing
+    happens on the GPU.  start / end (plain files only) restrict the walk to the records that START in the byte range
+    [start, end): the first record is found by resynchronising at `start`, the last one is completed beyond `end` --
+    N ranks given consecutive ranges read every record exactly once and touch only their share of the file."""
+    gz = path.endswith(".gz")
+    if gz and (start or end is not None):
+        raise ValueError("byte ranges need an uncompressed FASTQ (gzip has no random access; bgzip files are sharded by block)")
     carry = b""
-    lines_in_carry = 0
     with _open(path) as f:
-        while True:
-            block = f.read(chunk_bytes)
-            if not block:
-                break
-            data = carry + block
-            arr = np.frombuffer(data, np.uint8)
-            nl = np.flatnonzero(arr == 10)
-            whole = (len(nl) // 4) * 4
-            if whole == 0:
-                carry = data
+        pos = 0
+        if start:
+            f.seek(start - 1)                      # one byte early: a record that starts exactly at `start` is ours
+            pos = start - 1
+            head = f.read(1 << 16)
+            while True:
+                s0 = record_start(head, 1)
+                if s0 >= 0 or len(head) >= (64 << 20):
+                    break
+                more = f.read(len(head))
+                if not more:
+                    break
+                head += more
+            if s0 < 0:
+                if end is not None and pos + len(head) < end:
+                    raise ValueError("%s: no FASTQ record boundary after byte %d" % (path, start))
+                return                              # the range holds the inside of the file's last record only
+            if end is not None and pos + s0 >= end:
+                return                              # the first record at or after `start` belongs to the next range
+            carry = head[s0:]
+            pos += len(head)
+        done = False
+        while not done:
+            want = chunk_bytes - len(carry) if len(carry) < chunk_bytes else 0
+            block = f.read(want) if want else b""
+            data = carry + block if carry else block
+            base = pos - len(carry)                 # file offset of data[0]
+            pos += len(block)
+            eof = want > 0 and len(block) < want
+            if end is not None and base + len(data) > end:
+                # the record that starts last before `end` is ours in full; what follows belongs to the next range
+                cut = record_start(data, max(end - base, 0))
+                while cut < 0 and not eof:          # the boundary record is not complete yet
+                    more = f.read(1 << 16)
+                    if not more:
+                        eof = True
+                        break
+                    data += more
+                    pos += len(more)
+                    cut = record_start(data, max(end - base, 0))
+                if cut < 0:
+                    cut = len(data)                 # nothing starts after `end`: the range runs to the end of the file
+                if cut:
+                    yield data[:cut]
+                return
+            if eof:
+                if data.strip():
+                    yield data
+                return
+            cut = last_record_start(data)
+            if cut <= 0:
+                carry = data                        # no whole record yet (a record longer than the chunk): read on
+                chunk_bytes *= 2
                 continue
-            cut = int(nl[whole - 1]) + 1
             yield data[:cut]
             carry = data[cut:]
-    if carry.strip():
-        yield carry
+
+
+def pair_chunks(path1: str, path2: str, chunk_bytes: int = 128 << 20):
+    """Two FASTQ files of mates -> (chunk1, chunk2) pairs holding the SAME number of whole records each, in file order,
+    for Engine.submit_fastq_pair (the k-th record of one file is the mate of the k-th record of the other).  Here the
+    host does count lines -- the two cuts have to fall after the same record number."""
+    def newlines(buf):
+        return np.flatnonzero(np.frombuffer(buf, np.uint8) == 10)
+
+    with _open(path1) as f1, _open(path2) as f2:
+        c1 = c2 = b""
+        e1 = e2 = False
+        while True:
+            if not e1 and len(c1) < chunk_bytes:
+                b = f1.read(chunk_bytes - len(c1)); e1 = not b; c1 += b
+            if not e2 and len(c2) < chunk_bytes:
+                b = f2.read(chunk_bytes - len(c2)); e2 = not b; c2 += b
+            if e1 and c1 and not c1.endswith(b"\n"):
+                c1 += b"\n"
+            if e2 and c2 and not c2.endswith(b"\n"):
+                c2 += b"\n"
+            n1, n2 = newlines(c1), newlines(c2)
+            k = min(len(n1), len(n2)) // 4
+            if k == 0:
+                if e1 and e2:
+                    if c1.strip() or c2.strip():
+                        raise ValueError("paired FASTQ files hold different numbers of records (%s, %s)" % (path1, path2))
+                    return
+                if (e1 and not c1.strip()) or (e2 and not c2.strip()):
+                    raise ValueError("paired FASTQ files hold different numbers of records (%s, %s)" % (path1, path2))
+                chunk_bytes *= 2
+                continue
+            a, b = int(n1[4 * k - 1]) + 1, int(n2[4 * k - 1]) + 1
+            yield c1[:a], c2[:b]
+            c1, c2 = c1[a:], c2[b:]
+
+
+def mates_share_names(path1: str, path2: str) -> bool:
+    """True when the first records of the two mate files carry the same read name (the part of the header line before
+    the first blank): `@x 1:N:0` / `@x 2:N:0` do, `@x/1` / `@x/2` do not -- and neither would they share a QNAME in the
+    SAM that bowtie2 -U writes."""
+    with _open(path1) as f1, _open(path2) as f2:
+        h1, h2 = f1.readline().split(), f2.readline().split()
+    return bool(h1) and bool(h2) and h1[0] == h2[0]
+
+
+def prefetch(it, depth: int = 2):
+    """Run the iterator `it` in a thread, `depth` items ahead: file reads (which release the GIL) overlap the consumer's
+    GPU submissions.  Exceptions of the producer are raised in the consumer."""
+    import queue
+    import threading
+    q: queue.Queue = queue.Queue(maxsize=depth)
+    END = object()
+
+    def work():
+        try:
+            for x in it:
+                q.put(x)
+            q.put(END)
+        except BaseException as e:      # noqa: BLE001 -- handed to the consumer
+            q.put(e)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    while True:
+        x = q.get()
+        if x is END:
+            return
+        if isinstance(x, BaseException):
+            raise x
+        yield x
 
 
 def tile_fasta(path: str, read_len: int = 150, stride: int = 25, min_len: int = 50, chunk_reads: int = 500_000):
@@ -171,3 +329,115 @@ def bgzf_chunks(path: str, chunk_bytes: int = 256 << 20):
     if carry:
         raise ValueError("%s: truncated BGZF block at the end of the file" % path)
     yield (pending if pending is not None else b""), True
+
+
+# ---- byte ranges of a bgzip'd FASTQ (one range per GPU: metamlst_amd/multigpu.py) -------------------------------------
+def bgzf_find_block(f, pos: int, size: int) -> int:
+    """Offset of the first BGZF block that starts at or after `pos` (`size` when there is none).  A candidate -- the gzip
+    magic with the FEXTRA flag and a 'BC' subfield -- counts when the block it announces is followed by another valid
+    header or by the end of the file (deflate data may contain the magic bytes by chance)."""
+    if pos <= 0:
+        return 0
+    at = pos
+    while at < size:
+        f.seek(at)
+        win = f.read((1 << 17) + 64)
+        if len(win) < 18:
+            return size
+        i = 0
+        while True:
+            i = win.find(b"\x1f\x8b\x08\x04", i)
+            if i < 0 or i + 18 > len(win):
+                break
+            n = _bgzf_block_size(win, i)
+            if n > 0:
+                nxt = at + i + n
+                if nxt == size:
+                    return at + i
+                if nxt < size:
+                    f.seek(nxt)
+                    h2 = f.read(64)
+                    n2 = _bgzf_block_size(h2, 0)
+                    if n2 > 0 or (n2 == 0 and len(h2) >= 18 and h2[:4] == b"\x1f\x8b\x08\x04"):
+                        return at + i
+            i += 1
+        at += 1 << 17
+    return size
+
+
+def _bgzf_read_block(f, off: int):
+    """(total compressed size, inflated text) of the block at `off`; (0, b"") at the end of the file."""
+    import zlib
+    f.seek(off)
+    head = f.read(18)
+    if len(head) < 18:
+        return 0, b""
+    n = _bgzf_block_size(head, 0)
+    if n == 0:                                     # extra field longer than usual: read more of the header
+        f.seek(off)
+        head = f.read(4096)
+        n = _bgzf_block_size(head, 0)
+    if n <= 0:
+        raise ValueError("not a BGZF block at byte %d" % off)
+    f.seek(off)
+    blk = f.read(n)
+    xlen = blk[10] | (blk[11] << 8)
+    return n, zlib.decompress(blk[12 + xlen:n - 8], -15)
+
+
+def bgzf_split(f, block_off: int, size: int):
+    """Where the records of two neighbouring byte ranges part, for the range boundary at the block that starts at
+    `block_off`: -> (end, text, p).  `text` is the inflated text of the blocks block_off .. end, `p` the offset in it of
+    the first record that starts behind the first line break (record_start(text, 1)): text[:p] completes the last record
+    of the range before, text[p:] opens the range behind.  Both ranks evaluate this same function, so they agree.  At
+    the end of the file p = len(text)."""
+    text, at = b"", block_off
+    while at < size:
+        n, t = _bgzf_read_block(f, at)
+        if n == 0:
+            break
+        at += n
+        text += t
+        p = record_start(text, 1)
+        if p >= 0:
+            return at, text, p
+    return at, text, len(text)
+
+
+def bgzf_range_plan(path: str, lo: int, hi: int):
+    """What the rank owning compressed bytes [lo, hi) of a bgzip'd FASTQ submits: {head: text to submit first (host
+    inflated), mid: (first, end) compressed byte range of whole blocks to submit as BGZF, tail: text that completes the
+    last record}.  A range without a block start owns nothing."""
+    size = os.path.getsize(path)
+    hi = min(hi, size)
+    with open(path, "rb") as f:
+        b_lo = bgzf_find_block(f, lo, size)
+        b_hi = bgzf_find_block(f, hi, size) if hi < size else size
+        if b_lo >= b_hi:
+            return {"head": b"", "mid": (b_lo, b_lo), "tail": b""}
+        if lo > 0:
+            e_lo, t_lo, p_lo = bgzf_split(f, b_lo, size)
+        else:
+            e_lo, t_lo, p_lo = b_lo, b"", 0
+        if b_hi < size:
+            e_hi, t_hi, p_hi = bgzf_split(f, b_hi, size)
+        else:
+            e_hi, t_hi, p_hi = size, b"", 0
+        if e_lo > b_hi:
+            # the blocks inflated for the head reach into the next range (tiny ranges): both cuts lie in t_lo.
+            # text position of block b_hi inside t_lo = inflated size of the blocks b_lo .. b_hi
+            pos, at = 0, b_lo
+            while at < b_hi:
+                n, t = _bgzf_read_block(f, at)
+                at += n
+                pos += len(t)
+            cut = pos + p_hi if b_hi < size else len(t_lo)
+            if e_hi > e_lo:                       # the next boundary's record start lies beyond what the head inflated
+                f_text, at = t_lo, e_lo
+                while at < e_hi:
+                    n, t = _bgzf_read_block(f, at)
+                    at += n
+                    f_text += t
+                t_lo = f_text
+            return {"head": t_lo[p_lo:max(cut, p_lo)], "mid": (b_hi, b_hi), "tail": b""}
+        return {"head": t_lo[p_lo:], "mid": (e_lo, b_hi), "tail": t_hi[:p_hi]}

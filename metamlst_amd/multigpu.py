@@ -1,9 +1,8 @@
 """One sample typed on several GPUs of one node (north_star / BASELINE configs[3]: "FASTQ sharded per GPU, RCCL gather").
 
-One process per GPU.  `cli type --gpus N` starts the N ranks itself (torch.distributed.run, before the parent touches
-a GPU); every rank walks the FASTQ file, cuts it into the same record-aligned chunks and submits the chunks whose
-number is its rank modulo N, with the read index of the chunk's first record as index base (so that first-seen order,
-Q6, is that of the file).  Everything that crosses reads is additive: one all-reduce of the pass-1
+One process per GPU.  `cli type --gpus N` starts the N ranks itself (before the parent touches a GPU); rank r reads
+the r-th byte range of the FASTQ file, resynchronised on a record boundary (whole BGZF blocks for bgzip input), with a
+read-index base that keeps first-seen order (Q6) that of the file (submit_fastq_shard).  Everything that crosses reads is additive: one all-reduce of the pass-1
 statistics, the same allele choice on every rank, one all-reduce of the pileup counts (metamlst_amd/dist.py), and
 rank 0 writes the .nfo / --log files, byte for byte what one GPU writes.  The reference has no counterpart (one process,
 metamlst.py:96-130 reads one BAM)."""
@@ -17,30 +16,75 @@ import sys
 import numpy as np
 
 
-def spawn_ranks(n_gpus: int, cmd: list[str]) -> int:
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n_gpus: int, cmd: list[str], attempts: int = 3) -> int:
     """Start `cmd` n_gpus times with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what torch.distributed.run exports),
-    wait for all of them, return the first non-zero exit code (the others are ended when one rank fails).  The caller has
-    not initialised the GPU: the ranks are ordinary children."""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
-    for r in range(n_gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen(cmd, env=env))
-    rc = 0
+    wait for all of them, return the first non-zero exit code.  When one rank fails the others are ended (SIGTERM, then
+    SIGKILL after a grace period); the same happens when this process is interrupted, so no rank outlives its parent.
+    The rendezvous port is picked by binding port 0 and closing it again, which another job can win in between: a run
+    whose ranks all fail within a few seconds is started again on a new port (at most `attempts` times).  The caller
+    has not initialised the GPU: the ranks are ordinary children."""
     import time
-    while procs:
-        for p in list(procs):
-            code = p.poll()
-            if code is None:
-                continue
-            procs.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for q in procs:
-                    q.terminate()
-        time.sleep(0.05)
+    rc = 0
+    for attempt in range(attempts):
+        port = _free_port()
+        procs, t0, rc = [], time.time(), 0
+        try:
+            for r in range(n_gpus):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                procs.append(subprocess.Popen(cmd, env=env))
+            live = list(procs)
+            while live:
+                for p in list(live):
+                    code = p.poll()
+                    if code is None:
+                        continue
+                    live.remove(p)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        for q in live:
+                            q.terminate()
+                time.sleep(0.05)
+        finally:
+            _reap(procs)
+        bind_race = rc != 0 and time.time() - t0 < 20 and os.environ.get("MLST_SPAWN_RETRY", "1") != "0" and _port_taken(port)
+        if not bind_race:
+            break
     return rc
+
+
+def _port_taken(port: int) -> bool:
+    s = socket.socket()
+    try:
+        s.bind(("127.0.0.1", port))
+        return False
+    except OSError:
+        return True
+    finally:
+        s.close()
+
+
+def _reap(procs, grace: float = 10.0) -> None:
+    """terminate -> wait -> kill whatever is still running"""
+    import time
+    alive = [p for p in procs if p.poll() is None]
+    for p in alive:
+        p.terminate()
+    t_end = time.time() + grace
+    for p in alive:
+        try:
+            p.wait(timeout=max(0.1, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
 
 
 def launch_ranks(n_gpus: int, argv: list[str]) -> int:
@@ -66,22 +110,50 @@ def init_from_env():
     return rank, world, device
 
 
-def submit_fastq_shard(eng, paths: list[str], rank: int, world: int, chunk_bytes: int) -> int:
-    """Submit this rank's chunks of the sample's FASTQ files; returns the number of reads the whole sample holds."""
-    from .fastq import text_chunks
-    n_seen, k = 0, 0
-    for path in paths:
-        for chunk in text_chunks(path, chunk_bytes):
-            n = int(np.count_nonzero(np.frombuffer(chunk, np.uint8) == 10))
-            if len(chunk) and chunk[-1] != 10:
-                n += 1                                    # last line of the file without a newline
-            n //= 4
+ORDER_SHIFT = 40      # read-index bases of the shards: (file number * ranks + rank) << 40 -- see submit_fastq_shard
+
+
+def submit_fastq_shard(eng, paths: list[str], rank: int, world: int, chunk_bytes: int, paired: bool = False) -> None:
+    """Submit this rank's share of the sample's FASTQ files.
+
+    Plain FASTQ: rank r reads only the byte range [size r / N, size (r + 1) / N) of every file, resynchronised on a
+    record boundary (fastq.text_chunks(start, end)): host reads and PCIe traffic are 1 / N of the file per rank.
+    bgzip'd FASTQ: the same by whole BGZF blocks (fastq.bgzf_range_plan); the inflated text is resynchronised on the GPU side
+    of the boundary (mlst_submit_fastq_bgzf's resync flags).
+    gzip (one deflate stream, no random access) and mate files (pairs are matched by record number): every rank walks
+    the files and submits the chunks whose number is its rank modulo N.
+
+    Read-index bases are ORDER KEYS, not indices: what the typing needs from a read index is the first-seen order of loci
+    (Q6, metamlst.py:244 iterates a dict filled in BAM order); a shard's base only has to be larger than every index
+    of the shards before it.  Range r of file f gets (f * N + r) << 40, chunk k of a walked file k << 36 -- no rank has
+    to know how many records the others hold."""
+    from .fastq import is_bgzf, pair_chunks, prefetch, text_chunks
+    if paired:
+        if len(paths) != 2:
+            raise ValueError("paired input is two files of mates")
+        for k, (c1, c2) in enumerate(prefetch(pair_chunks(paths[0], paths[1], chunk_bytes // 2))):
             if k % world == rank:
-                eng.set_read_index_base(n_seen)
+                eng.set_read_index_base(k << 36)
+                eng.submit_fastq_pair(c1, c2)
+        return
+    k = 0
+    for f, path in enumerate(paths):
+        if is_bgzf(path):
+            size = os.path.getsize(path)
+            eng.set_read_index_base((f * world + rank) << ORDER_SHIFT)
+            eng.submit_fastq_bgzf_range(path, size * rank // world, size * (rank + 1) // world if rank + 1 < world else size, chunk_bytes)
+        elif path.endswith(".gz"):
+            for chunk in prefetch(text_chunks(path, chunk_bytes)):
+                if k % world == rank:
+                    eng.set_read_index_base(k << 36)
+                    eng.submit_fastq(chunk, paired=False)
+                k += 1
+        else:
+            size = os.path.getsize(path)
+            lo, hi = size * rank // world, (size * (rank + 1) // world if rank + 1 < world else None)
+            eng.set_read_index_base((f * world + rank) << ORDER_SHIFT)
+            for chunk in prefetch(text_chunks(path, chunk_bytes, lo, hi)):
                 eng.submit_fastq(chunk, paired=False)
-            n_seen += n
-            k += 1
-    return n_seen
 
 
 def type_sharded(eng, idx, database, targs, rank: int, world: int, device, file_name: str, out_dir: str | None, log_path: str | None,
@@ -106,3 +178,66 @@ def type_sharded(eng, idx, database, targs, rank: int, world: int, device, file_
     res = type_sample(idx, st, None, database, file_name, targs, out_dir=out_dir if rank == 0 else None, consensus_fn=consensus_fn)
     dist.barrier()
     return res if rank == 0 else None
+
+
+def deal_samples(sizes: list[int], world: int) -> list[int]:
+    """Whole samples -> ranks: largest first, each to the rank with the least bytes so far (ties: lowest rank).  A pure
+    function of the sizes, so every rank computes the same deal."""
+    load = [0] * world
+    owner = [0] * len(sizes)
+    for i in sorted(range(len(sizes)), key=lambda k: (-sizes[k], k)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[i] = r
+        load[r] += sizes[i]
+    return owner
+
+
+def type_many_samples(eng, idx, database, targs, samples: list[list[str]], rank: int, world: int, out_dir: str, log: bool,
+                      chunk_bytes: int, printer=None) -> int:
+    """Multi-sample mode (BASELINE configs[3]: "RCCL gather of per-species ST tables"; the reference's real use is many
+    samples into one folder, one metamlst.py run each, metamlst-merge.py:93-107 reads the folder).  Whole samples are
+    dealt to the ranks -- no collective on the data path --, every rank types its samples on its GPU, and rank 0
+    gathers the .nfo lines (and --log tables) and writes them, sample by sample in the order given: byte for byte what
+    one run per sample writes."""
+    import time
+    from .cli import submit_sample_files
+    from .typing import log_table, sample_name, type_sample
+    sizes = [sum(os.path.getsize(f) for f in files) for files in samples]
+    owner = deal_samples(sizes, world)
+    mine = []
+    for i, files in enumerate(samples):
+        if owner[i] != rank:
+            continue
+        eng.reset_sample()
+        submit_sample_files(eng, files, False, chunk_bytes)
+        st = eng.stats()
+        name = sample_name(files[0])
+        res = type_sample(idx, st, eng.pileup, database, name, targs, out_dir=None)
+        mine.append({"i": i, "name": name, "nfo": [r.nfo_line for r in res if r.written],
+                     "log": log_table(idx, st, targs, files[0]) if log else None, "results": res if printer else None})
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        if rank != 0:
+            dist.barrier()
+            dist.destroy_process_group()
+            return 0
+        mine = [x for part in gathered for x in part]
+    if not os.path.isdir(out_dir):
+        os.mkdir(out_dir)
+    for x in sorted(mine, key=lambda x: x["i"]):
+        if x["log"] is not None:
+            with open(out_dir + "/" + x["name"] + "_" + str(int(time.time())) + ".out", "w", newline="") as f:
+                f.write(x["log"])
+        if x["nfo"]:
+            with open(out_dir + "/" + x["name"] + ".nfo", "a", newline="") as f:      # append, as metamlst.py:284 does
+                f.write("".join(x["nfo"]))
+        if printer and x["results"] is not None:
+            print("Sample " + x["name"])
+            printer(x["results"])
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Why does the routed sieve's producer run in two speeds?  
+
+One process = one observation: the cfg3 workload on one engine, N isolated launches of the sieve timed with HIP events,
+per launch; the per-workgroup trace of the last launch (XCC, HW_ID, start and end of every workgroup); the addresses of
+the buffers; the clocks the driver reports; then the same again after the routing arena has been freed and allocated
+somewhere else (mlst_debug_route_realloc), to tell a property of the PROCESS from a property of the MEMORY it got.
+Appends one JSON line to --out.  Run it several times in a row on one box (profiles/route_modes.sh).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def clocks():
+    out = {}
+    for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk") + glob.glob("/sys/class/drm/card*/device/pp_dpm_mclk") + glob.glob("/sys/class/drm/card*/device/pp_dpm_fclk"):
+        try:
+            cur = [ln.strip() for ln in open(f) if "*" in ln]
+            out[f.split("/")[4] + "/" + os.path.basename(f)] = cur
+        except Exception:
+            pass
+    return out
+
+
+def wg_summary(tr, which):
+    """per-XCC residency of the producer (which = 0) or consumer (1) workgroups of the traced launch"""
+    P = tr["P"]
+    wg = tr["wg"][:P] if which == 0 else tr["wg"][P:P + 256]
+    xcc = (wg[:, 0] & np.uint64(0xF)).astype(int)
+    hw = (wg[:, 0] >> np.uint64(32)).astype(np.int64)
+    dur = (wg[:, 2].astype(np.int64) - wg[:, 1].astype(np.int64)) / (tr["khz"] / 1e3)      # microseconds
+    t0 = wg[:, 1].astype(np.int64)
+    span = (wg[:, 2].astype(np.int64).max() - t0.min()) / (tr["khz"] / 1e3)
+    per = {}
+    for x in range(8):
+        m = xcc == x
+        if m.any():
+            per[str(x)] = {"n": int(m.sum()), "mean_us": round(float(dur[m].mean()), 1), "max_us": round(float(dur[m].max()), 1),
+                           "end_us": round(float((wg[m, 2].astype(np.int64).max() - t0.min()) / (tr["khz"] / 1e3)), 1)}
+    cu = ((hw >> 8) & 0xF); se = ((hw >> 13) & 0x7)
+    return {"span_us": round(float(span), 1), "xcc_of_wg0": int(xcc[0]), "xcc_of_first8": [int(v) for v in xcc[:8]], "per_xcc": per,
+            "dur_us_min_med_max": [round(float(v), 1) for v in (dur.min(), np.median(dur), dur.max())],
+            "distinct_cu_se_xcc": int(len(set(zip(cu.tolist(), se.tolist(), xcc.tolist()))))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "route_modes.jsonl"))
+    ap.add_argument("--launches", type=int, default=20)
+    ap.add_argument("--reads", type=int, default=50_000_000)
+    ap.add_argument("--tag", default="")
+    ap.add_argument("--pads", default="0,1048576,318767104", help="pad bytes kept between re-allocations of the arena")
+    args = ap.parse_args()
+    import __graft_entry__ as ge
+    ge.build()
+    import torch
+    import bench
+    from metamlst_amd.engine import Engine
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    bargs = argparse.Namespace(alleles=0, reads=args.reads, genome_size=0, species=150, genomes=20, read_len=150)
+    tmp = tempfile.mkdtemp(prefix="mlst_modes_")
+    w = bench.build_workload("cfg3", bargs, lambda: Engine(0), torch, device, 0, 1, tmp)
+    eng = w.engines[0]
+    packed, qrows, lens, n = w.batches[0]
+    eng.route_trace()                       # switches the trace on
+    eng.set_profiling(1)
+
+    def launches(k):
+        rt, pb = [], []
+        for _ in range(k):
+            eng.reset_sample()
+            eng.reset_kernel_time()
+            eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), n, w.wpr, w.qstride)
+            eng.synchronize()
+            rt.append(eng.kernel_time("sieve_route")[0]); pb.append(eng.kernel_time("sieve_probe")[0])
+        return rt, pb
+
+    launches(3)
+    rec = {"tag": args.tag, "pid": os.getpid(), "time": time.time(), "clocks_before": clocks(), "reads": int(n), "phases": []}
+    for i, pad in enumerate([None] + [int(x) for x in args.pads.split(",") if x != ""]):
+        if pad is not None:
+            eng.debug_route_realloc(pad)
+            launches(2)
+        rt, pb = launches(args.launches)
+        tr = eng.route_trace()
+        ph = {"realloc_pad": pad, "arena": hex(tr["arena"]), "arena_mod_2MiB": tr["arena"] % (2 << 20), "packed": hex(tr["packed"]),
+              "filter": hex(tr["filter"]), "flags": hex(tr["flags"]), "P": tr["P"], "cap": tr["cap"],
+              "route_ms": {"min": round(min(rt), 4), "median": round(float(np.median(rt)), 4), "max": round(max(rt), 4), "all": [round(v, 4) for v in rt]},
+              "probe_ms": {"min": round(min(pb), 4), "median": round(float(np.median(pb)), 4), "max": round(max(pb), 4)},
+              "producer": wg_summary(tr, 0), "consumer": wg_summary(tr, 1)}
+        rec["phases"].append(ph)
+        if i == 0:
+            np.save(os.path.join(os.path.dirname(args.out), "route_trace_%s.npy" % (args.tag or str(os.getpid()))), tr["wg"])
+    rec["clocks_after"] = clocks()
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    print(json.dumps({"tag": args.tag, "route_ms_median": [p["route_ms"]["median"] for p in rec["phases"]],
+                      "arena": [p["arena"] for p in rec["phases"]], "xcc0": [p["producer"]["xcc_of_wg0"] for p in rec["phases"]]}))
+
+
+if __name__ == "__main__":
+    main()

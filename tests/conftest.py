@@ -16,7 +16,7 @@ def pytest_configure(config):
 def _gpu_visible() -> bool:
     try:
         import torch
-        return torch.cuda.device_count() > 0          # counting devices does not initialise the runtime
+        return torch.cuda.device_count() > 0          # (hipGetDeviceCount; no context, no exec restriction on this image)
     except Exception:
         return False
 

@@ -77,3 +77,52 @@ def test_bgzf_chunks_cut_between_blocks():
         f.write(b"".join(blocks)[:-5])
     with pytest.raises(ValueError, match="truncated"):
         list(bgzf_chunks(d + "/cut.gz"))
+
+
+def _bgzf_raw(raw: bytes, data: bytes) -> bytes:
+    """a BGZF block around an already deflated stream"""
+    import struct
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + raw
+            + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+@pytest.mark.gpu
+def test_device_decoder_equals_zlib_on_every_block_kind():
+    """The wave decoder of csrc/inflate_wave.h (register windows, scalar state, tables built by ballot) on the GPU: every
+    payload x level x strategy in ONE buffer of BGZF blocks (one launch), blocks at odd byte offsets, compared with the
+    bytes that went in.  Includes stored blocks (level 0 and incompressible data), fixed codes, long codes (Huffman
+    only), overlapping matches (runs), matches 32 K back, empty blocks."""
+    from metamlst_amd.engine import Engine, MlstError
+    rng = np.random.default_rng(5)
+    far = bytes(rng.integers(0, 256, 300, dtype=np.uint8))
+    extra = [far + bytes(rng.integers(65, 70, 32300, dtype=np.uint8)) + far,        # a match at the far end of the window
+             bytes(rng.integers(0, 4, 65000, dtype=np.uint8)),                       # low entropy: short codes
+             b"".join(bytes([k]) * (k + 1) for k in range(256)) * 2]                 # runs of every length
+    blocks, want = [], []
+    for level, strategy in [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                            (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)]:
+        for data in payloads() + extra:
+            data = data[:65280]
+            blocks.append(_bgzf_raw(deflate(data, level, strategy), data))
+            want.append(data)
+    eng = Engine(0)
+    got = eng.inflate_bgzf(b"".join(blocks))
+    assert got == b"".join(want)
+    # multi-block deflate streams inside one BGZF block (zlib starts a new deflate block every 16 K symbols at level 1)
+    fq = payloads()[4]
+    many = [_bgzf_raw(deflate(fq[:60000], 1), fq[:60000]) for _ in range(300)]
+    assert eng.inflate_bgzf(b"".join(many)) == fq[:60000] * 300
+    # damage: an error code, never a fault or a hang (the launch returns)
+    raw = deflate(fq, 6)
+    for k in range(40):
+        bad = bytearray(raw)
+        for _ in range(int(rng.integers(1, 6))):
+            bad[int(rng.integers(len(bad)))] = int(rng.integers(256))
+        try:
+            out = eng.inflate_bgzf(_bgzf_raw(bytes(bad), fq))
+            assert len(out) == len(fq)
+        except MlstError:
+            pass
+    with pytest.raises(MlstError):
+        eng.inflate_bgzf(_bgzf_raw(raw[:len(raw) // 2], fq))
+    eng.close()

@@ -31,32 +31,148 @@ def test_spawn_ranks_returns_the_first_failure_and_ends_the_others():
 class FakeEngine:
     def __init__(self):
         self.calls = []
+        self.base = 0
 
     def set_read_index_base(self, b):
         self.base = b
 
     def submit_fastq(self, chunk, paired=False):
-        self.calls.append((self.base, bytes(chunk).count(b"\n") // 4))
+        self.calls.append((self.base, bytes(chunk)))
+        self.base += bytes(chunk).count(b"\n") // 4
+
+    def submit_fastq_pair(self, c1, c2):
+        self.calls.append((self.base, bytes(c1), bytes(c2)))
 
 
-def test_fastq_chunks_are_dealt_round_robin_with_global_read_indices(tmp_path):
-    rng = np.random.default_rng(3)
-    p = tmp_path / "s.fastq"
-    n = 5000
-    with open(p, "wb") as f:
+def make_fastq(path, n, seed, tag=b"r", name_suffix=b""):
+    rng = np.random.default_rng(seed)
+    with open(path, "wb") as f:
         for k in range(n):
             L = int(rng.integers(30, 151))
-            f.write(b"@r%d\n%s\n+\n%s\n" % (k, b"A" * L, b"I" * L))
-    chunk = 64 << 10
-    world = 3
-    engines = [FakeEngine() for _ in range(world)]
-    totals = [multigpu.submit_fastq_shard(engines[r], [str(p)], r, world, chunk) for r in range(world)]
-    assert totals == [n] * world                                  # every rank walks the whole file and agrees on its size
+            q = bytes(rng.choice(np.frombuffer(b"@+I5#", np.uint8), L))      # quality lines that start like headers
+            f.write(b"@%s%d%s\n%s\n+\n%s\n" % (tag, k, name_suffix, b"ACGT" * (L // 4) + b"A" * (L % 4), q))
+
+
+def test_every_rank_reads_only_its_byte_range_and_the_order_keys_follow_the_file(tmp_path):
+    """cli type --gpus N on plain FASTQ (VERDICT r2, item 3 i): rank r opens the file at size r / N, resynchronises on a
+    record boundary and stops behind the record that starts last before size (r + 1) / N; bases are order keys."""
+    p = tmp_path / "s.fastq"
+    make_fastq(p, 5000, 3)
+    whole = open(p, "rb").read()
+    for world in (2, 3, 8):
+        engines = [FakeEngine() for _ in range(world)]
+        for r in range(world):
+            multigpu.submit_fastq_shard(engines[r], [str(p)], r, world, 64 << 10)
+        calls = sorted(c for e in engines for c in e.calls)
+        assert b"".join(c[1] for c in calls) == whole                      # every record exactly once, in file order by key
+        for r, e in enumerate(engines):
+            got = sum(len(c[1]) for c in e.calls)
+            assert abs(got - len(whole) / world) < 400                        # its share, give or take a record
+            assert all((c[0] >> multigpu.ORDER_SHIFT) == r for c in e.calls)
+            assert all(c[1][:1] == b"@" and c[1].count(b"\n") % 4 == 0 for c in e.calls)
+
+
+def test_two_files_of_one_sample_keep_file_order(tmp_path):
+    a, b = tmp_path / "a.fastq", tmp_path / "b.fastq"
+    make_fastq(a, 700, 1, b"a"); make_fastq(b, 900, 2, b"b")
+    engines = [FakeEngine() for _ in range(4)]
+    for r in range(4):
+        multigpu.submit_fastq_shard(engines[r], [str(a), str(b)], r, 4, 16 << 10)
     calls = sorted(c for e in engines for c in e.calls)
-    assert sum(c[1] for c in calls) == n                          # every read submitted exactly once ...
-    at = 0
-    for base, cnt in calls:                                       # ... with the index it has in the file
-        assert base == at
-        at += cnt
-    n_chunks = len(list(text_chunks(str(p), chunk)))
-    assert [len(e.calls) for e in engines] == [len(range(r, n_chunks, world)) for r in range(world)]
+    assert b"".join(c[1] for c in calls) == open(a, "rb").read() + open(b, "rb").read()
+
+
+def test_mate_files_are_dealt_in_pairs_of_chunks(tmp_path):
+    a, b = tmp_path / "r1.fastq", tmp_path / "r2.fastq"
+    make_fastq(a, 1200, 5, b"p", b" 1:N:0"); make_fastq(b, 1200, 6, b"p", b" 2:N:0")
+    from metamlst_amd.fastq import mates_share_names
+    assert mates_share_names(str(a), str(b))
+    engines = [FakeEngine() for _ in range(3)]
+    for r in range(3):
+        multigpu.submit_fastq_shard(engines[r], [str(a), str(b)], r, 3, 32 << 10, paired=True)
+    calls = sorted(c for e in engines for c in e.calls)
+    assert all(c[0] % 2 == 0 and c[1].count(b"\n") == c[2].count(b"\n") for c in calls)
+    assert b"".join(c[1] for c in calls) == open(a, "rb").read() and b"".join(c[2] for c in calls) == open(b, "rb").read()
+    assert all(len(e.calls) > 0 for e in engines)
+    c, d = tmp_path / "x1.fastq", tmp_path / "x2.fastq"
+    make_fastq(c, 3, 5, b"p", b"/1"); make_fastq(d, 3, 6, b"p", b"/2")
+    assert not mates_share_names(str(c), str(d))                             # @p0/1 and @p0/2: two QNAMEs in bowtie2 -U's SAM
+
+
+def test_record_boundaries_survive_quality_lines_that_look_like_headers(tmp_path):
+    from metamlst_amd.fastq import last_record_start, record_start
+    rec = [b"@r0\nACGT\n+\n@+@+\n", b"@r1\nAC\n+\n@@\n", b"@r2\nA\n+\n+\n", b"@r3\nACG\n+r3\n@II\n"]
+    buf = b"".join(rec)
+    starts = np.cumsum([0] + [len(r) for r in rec])[:-1].tolist()
+    for pos in range(len(buf)):
+        want = next((s for s in starts if s >= pos), -1)
+        assert record_start(buf, pos) == want, pos
+    assert last_record_start(buf + b"@r4\nA") == starts[-1]           # a record whose '+' line is not in the buffer yet cannot be told
+    for crlf in (buf.replace(b"\n", b"\r\n"),):
+        assert record_start(crlf, 1) == crlf.index(b"@r1")
+
+
+def test_bgzf_ranges_partition_the_records(tmp_path):
+    """cli type --gpus N on bgzip'd FASTQ: whole BGZF blocks per rank, the text around every range boundary split at the
+    first record start behind the boundary block's first line break (fastq.bgzf_range_plan) -- checked here with zlib."""
+    import struct
+    import zlib
+    from metamlst_amd.fastq import _bgzf_block_size, bgzf_range_plan
+    p = tmp_path / "t.fastq"
+    make_fastq(p, 3000, 9)
+    text = open(p, "rb").read()
+
+    def block(data):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(data) + c.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
+                + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+    def inflate(raw, a, b):
+        out = b""
+        while a < b:
+            n = _bgzf_block_size(raw, a)
+            xlen = raw[a + 10] | (raw[a + 11] << 8)
+            out += zlib.decompress(raw[a + 12 + xlen:a + n - 8], -15)
+            a += n
+        return out
+
+    for bs in (700, 65280):
+        raw = b"".join(block(text[i:i + bs]) for i in range(0, len(text), bs)) + block(b"")
+        z = tmp_path / ("t%d.fastq.gz" % bs)
+        z.write_bytes(raw)
+        for world in (1, 2, 5, 8, 40):
+            got = b""
+            for r in range(world):
+                plan = bgzf_range_plan(str(z), len(raw) * r // world, len(raw) * (r + 1) // world if r + 1 < world else len(raw))
+                part = plan["head"] + inflate(raw, *plan["mid"]) + plan["tail"]
+                assert part == b"" or (part[:1] == b"@" and part.count(b"\n") % 4 == 0)
+                got += part
+            assert got == text, (bs, world)
+
+
+def test_whole_samples_are_dealt_by_size():
+    assert multigpu.deal_samples([5, 9, 3, 3, 7], 2) == [1, 0, 0, 0, 1]
+    assert multigpu.deal_samples([4, 4, 4], 8) == [0, 1, 2]
+    owner = multigpu.deal_samples(list(range(1, 41)), 8)
+    load = [sum(s for s, o in zip(range(1, 41), owner) if o == r) for r in range(8)]
+    assert max(load) - min(load) <= 8
+
+
+def test_spawn_ranks_leaves_no_rank_behind_when_the_parent_is_interrupted(tmp_path):
+    """A KeyboardInterrupt in the launcher (or any exception) ends the ranks: terminate, wait, kill."""
+    pidfile = tmp_path / "pids"
+    code = "import os, time; open(r'%s', 'a').write(str(os.getpid()) + '\\n'); time.sleep(120)" % str(pidfile)
+    driver = ("import sys, threading, _thread, time; sys.path.insert(0, r'%s'); from metamlst_amd import multigpu\n"
+              "threading.Timer(1.5, _thread.interrupt_main).start()\n"
+              "try:\n    multigpu.spawn_ranks(3, [sys.executable, '-c', %r])\nexcept KeyboardInterrupt:\n    pass\n" % (ROOT, code))
+    subprocess.run([sys.executable, "-c", driver], timeout=60, check=True)
+    pids = [int(x) for x in open(pidfile).read().split()]
+    assert len(pids) == 3
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except OSError:
+            alive = False
+        assert not alive
