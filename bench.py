@@ -45,7 +45,7 @@ ALG_BYTES_BASES = 40      # 2-bit bases of a 150 bp read, rounded to the 10-word
 ALG_BYTES_SURVEY = 188    # 38 B 2-bit bases + 150 B Phred per 150 bp read (reported beside, never used for frac)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GINSTR = 930.0  # measured simple-op issue rate of the whole chip, G wave-instructions/s (profiles/round1/valu_rate2.txt)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "round3")
 
 
 def parse_args():
@@ -274,12 +274,19 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
     from metamlst_amd.engine import KERNELS
     KNAMES = [k for k in KERNELS if k not in ("pack", "sieve_inkernel", "sieve_wg_longest")]
     engines[0].set_profiling(1)
-    engines[0].reset_kernel_time()
-    for k in range(5):
+    n_iso = 20
+    per_launch = {k: [] for k in KNAMES}
+    for k in range(n_iso):
+        engines[0].reset_kernel_time()
         submit(0)
         finish(0)
+        for name in KNAMES:
+            ms, n = engines[0].kernel_time(name)
+            if n:
+                per_launch[name].append(ms / n)
     fence()
-    isolated = {k: engines[0].kernel_time(k) for k in KNAMES}
+    isolated = {k: (float(np.median(v)) if v else 0.0, 1) for k, v in per_launch.items()}      # (median launch, 1): what the rooflines use
+    spread = {k: {"min": round(min(v), 4), "median": round(float(np.median(v)), 4), "max": round(max(v), 4), "n": len(v)} for k, v in per_launch.items() if v}
     engines[0].set_profiling(0)
     fence()
     t0 = time.perf_counter()
@@ -325,7 +332,7 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
     return {"ms_per_step": dt / args.steps * 1e3, "value": w.n_reads * world / (dt / args.steps) / 1e6,
             "blocks": len(blocks), "block_ms": [round(b[0] * 1e3, 3) for b in blocks], "timed_s": round(total, 3),
             "host_ms_per_step": {k: round(v / args.steps, 4) for k, v in hm.items()}, "serial_ms_per_step": serial_ms,
-            "iso_launch_ms": iso_launch, "stats": stats, "st_call": st_call, "typed_ok": typed_ok, "batches_checked": len(calls),
+            "iso_launch_ms": iso_launch, "iso_launch_spread": spread, "stats": stats, "st_call": st_call, "typed_ok": typed_ok, "batches_checked": len(calls),
             "collectives": ("streamed on a torch stream" if mode["streamed"] else "host-driven") if world > 1 else None}
 
 
@@ -357,8 +364,10 @@ def rooflines(w, res, eng):
         tr = pmc.get(kernel, {}).get("hbm_bytes_per_launch")
         return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": int(tr * w.n_reads / pmc.get("reads_per_launch", w.n_reads)) if tr else None,
+                "traffic_source": ("profiles/round3/pmc_%s.json: rocprofv3 --pmc passes of this command (profiles/pmc_round2.sh), committed -- not measured by this run" % w.name) if tr else None,
                 "alg_bytes_per_read": ALG_BYTES_BASES, "reads_per_launch": w.n_reads, "avg_launch_ms": round(ms, 4),
-                "duration_source": "HIP events on the engine's stream, serial steps (= rocprofv3 --kernel-trace average of --pipeline 1)"}
+                "launch_ms_spread": res.get("iso_launch_spread", {}).get(key),
+                "duration_source": "HIP events on the engine's stream around each of 20 serial launches, median (= rocprofv3 --kernel-trace average of --pipeline 1)"}
 
     if dom in stream_kernels:
         roof = hbm_roof(dom, stream_kernels[dom])
@@ -379,6 +388,7 @@ def rooflines(w, res, eng):
         scale = pairs / max(1, pmc.get("k_extend", {}).get("pairs_per_launch", pairs))
         rext["achieved"] = round(valu * scale / (ext_ms * 1e-3) / 1e9, 1)
         rext["frac"] = round(rext["achieved"] / VALU_PEAK_GINSTR, 4)
+        rext["valu_count_source"] = "profiles/round3/pmc_%s.json (SQ_INSTS_VALU of a rocprofv3 --pmc pass, committed); the duration is this run's" % w.name
     return roof, rext
 
 
@@ -460,6 +470,22 @@ def end_to_end(w, args, torch, device):
         t0 = time.perf_counter(); calls = run_bgzf(); ts.append(time.perf_counter() - t0)
     out["bgzip_to_st"] = {"reads": nz, "Mreads_per_s": round(nz / min(ts) / 1e6, 1), "compressed_bytes": int(comp.size), "seconds": round(min(ts), 4),
                           "species_called": len(calls)}
+    return out
+
+
+def literal_leg(w, args, torch, tmp):
+    """when bowtie2 + samtools are on PATH, the documented command (README.md:20) on cfg1's reads (the
+    first 100 k reads of the isolate) -> BAM -> this build's --alignments path, compared with the FASTQ path.  Untimed."""
+    from metamlst_amd import literal, synth
+    if literal.tools() is None:
+        return {"skipped": "bowtie2 / bowtie2-build / samtools not on PATH (the reference ships none of them)"}
+    packed, qrows, lens, n_total = w.batches[0]
+    n = min(100_000, n_total)
+    fq = os.path.join(tmp, "cfg1.fastq")
+    with open(fq, "wb") as f:
+        f.write(synth.resident_to_fastq_text(torch, packed, qrows, n_total, w.wpr, w.qstride, 0, n, args.read_len).cpu().numpy().tobytes())
+    out = literal.literal_parity(w.engines[0], w.idx, w.database, w.sdb.path, fq, threads=min(64, os.cpu_count() or 1))
+    out["reads"] = n
     return out
 
 
@@ -588,7 +614,7 @@ def main():
            "index_bytes": dict(zip(("allele_arena", "sieve", "seed_table"), eng.index_bytes()[:3])),
            "setup_s": {"database": round(w.t_db, 1), "index_host": round(w.t_index_host, 1), "index_device_x%d" % depth: round(w.t_index_dev, 1),
                        "resident_reads_x%d" % depth: round(w.t_reads, 1)},
-           "world_size_reported_by_backend": (dist.get_world_size() if world > 1 else 1)}
+           "world_size_reported_by_backend": (dist.get_world_size() if world > 1 else 1), "literal_parity_bowtie2": None}
     # ---- secondary block: cfg2 (configs[1]) in the same run, N = 1 only
     if world == 1 and not args.no_secondary and args.workload == "cfg3":
         for e in w.engines:
@@ -603,7 +629,9 @@ def main():
                      "ms_per_step": round(r2["ms_per_step"], 4), "serial_ms_per_step": round(r2["serial_ms_per_step"], 4),
                      "roofline": roof2, "roofline_extend": rext2, "st_match": all(r2["typed_ok"].values()),
                      "kernel_ms_per_launch_isolated": {k: round(v, 4) for k, v in r2["iso_launch_ms"].items()},
-                     "timed_region": {"blocks": r2["blocks"], "timed_s": r2["timed_s"]}}
+                     "timed_region": {"blocks": r2["blocks"], "timed_s": r2["timed_s"]},
+                     "end_to_end": end_to_end(w2, a2, torch, device)}
+        out["literal_parity_bowtie2"] = literal_leg(w2, a2, torch, tmp)
     out["secondary_cfg2"] = secondary
     out["wall_s"] = round(time.time() - t_start, 1)
     print(json.dumps(out))

@@ -290,10 +290,11 @@ __device__ __attribute__((always_inline)) inline int inflate_stream(const u8* in
                 wave_sync();
                 if (uni(T.len[256]) == 0) { rc = E_LENGTHS; break; }                        // no end-of-block code
             }
+            // (the fixed distance code is incomplete by definition, 30 of 32 codes: only a dynamic block's codes are checked)
             int e = build<LB>(T, 0, 0, nlen, T.lut, lane);
-            if (e < 0 || (e > 0 && nlen != (u32)uni(T.cnt[0][0]) + (u32)uni(T.cnt[0][1]))) { rc = E_LENGTHS; break; }
+            if (type == 2 && (e < 0 || (e > 0 && nlen != (u32)uni(T.cnt[0][0]) + (u32)uni(T.cnt[0][1])))) { rc = E_LENGTHS; break; }
             e = build<DBITS>(T, 1, nlen, ndist, T.dlut, lane);
-            if (e < 0 || (e > 0 && ndist != (u32)uni(T.cnt[1][0]) + (u32)uni(T.cnt[1][1]))) { rc = E_LENGTHS; break; }
+            if (type == 2 && (e < 0 || (e > 0 && ndist != (u32)uni(T.cnt[1][0]) + (u32)uni(T.cnt[1][1])))) { rc = E_LENGTHS; break; }
             rc = codes(in, T, o);
             if (rc != OK) break;
         } else { rc = E_BLOCKTYPE; break; }

@@ -970,14 +970,13 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
                     B[j] = __ballot(fg[j]);
                     before = __builtin_amdgcn_mbcnt_hi((u32)(B[j] >> 32), __builtin_amdgcn_mbcnt_lo((u32)B[j], before));      // run starts in the lanes below
                 }
-                // the filter words of the four entries in one batch of independent LDS reads (an entry without a seed reads word 0
-                // and fails on its own flag)
+                // the filter words of the four entries in one batch of independent LDS reads
                 u32 f0[4], f1[4], k0[4], k1[4]; bool sd[4];
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     sd[j] = (ev[u][j] & RT_HMASK) != RT_DUMMY;
                     u32 b0, b1; rt_filter_addr(ev[u][j] & RT_HMASK, b0, k0[j], b1, k1[j]);
-                    f0[j] = s_f[sd[j] ? b0 : 0u]; f1[j] = s_f[sd[j] ? b1 : 0u];
+                    f0[j] = s_f[b0]; f1[j] = s_f[b1];      // (an entry without a seed reads the words of the value RT_DUMMY and fails on sd)
                 }
                 tie_all<4>(f0); tie_all<4>(f1);
                 int run = seq + (int)before;

@@ -34,11 +34,12 @@ def create_schema(conn: sqlite3.Connection) -> None:
 
 
 def gen_locus_alleles(rng: np.random.Generator, length: int, n_alleles: int, max_div: float = 0.03,
-                      snp_lo: int = 1, snp_hi: int = 8, indel_every: int = 0) -> list[np.ndarray]:
-    """Alleles of one locus: a random root and a random tree with snp_lo..snp_hi SNPs per edge,
+                      snp_lo: int = 1, snp_hi: int = 8, indel_every: int = 0, root: np.ndarray | None = None) -> list[np.ndarray]:
+    """Alleles of one locus: a random root (or the one given) and a random tree with snp_lo..snp_hi SNPs per edge,
     every allele within max_div of the root, all distinct.  indel_every > 0 additionally gives
     every indel_every-th allele a 1-3 bp deletion (exercises the banded Smith-Waterman path)."""
-    root = rng.integers(0, 4, size=length, dtype=np.uint8)
+    root = rng.integers(0, 4, size=length, dtype=np.uint8) if root is None else np.asarray(root, dtype=np.uint8).copy()
+    length = len(root)
     alleles = [root]
     ndiff = [0]
     seen = {root.tobytes()}
@@ -77,10 +78,13 @@ class SynthDB:
     profiles: dict[str, np.ndarray] = field(default_factory=dict)   # species -> int array [n_st, n_loci] (allele numbers)
 
 
-def make_db(path: str, species_loci: dict[str, list[tuple[str, int]]], alleles_per_locus: int,
-            n_profiles: int, seed: int = SEED, indel_every: int = 0, max_div: float = 0.03) -> SynthDB:
-    """Write a schema-compatible SQLite database.  Allele numbers run 1..alleles_per_locus;
-    sequence type k (1-based) is a random allele tuple (profiles rows point at alleles.recID)."""
+def make_db(path: str, species_loci: dict[str, list[tuple[str, int]]], alleles_per_locus,
+            n_profiles: int, seed: int = SEED, indel_every: int = 0, max_div: float = 0.03, roots: dict | None = None) -> SynthDB:
+    """Write a schema-compatible SQLite database.  Allele numbers run 1..alleles_per_locus (an int, or a dict
+    {(species, gene): count}); sequence type k (1-based) is a random allele tuple (profiles rows point at alleles.recID).
+    roots = {(species, gene): (other species, other gene)}: the locus grows from a mutated copy of the other locus' root
+    (near-duplicate loci across species: their seeds collide in the index)."""
+    root_of: dict = {}
     rng = np.random.default_rng(seed)
     conn = sqlite3.connect(path)
     create_schema(conn)
@@ -91,7 +95,14 @@ def make_db(path: str, species_loci: dict[str, list[tuple[str, int]]], alleles_p
         recid = {}
         for gene, length in loci:
             cur.execute("INSERT INTO genes (geneName,bacterium) VALUES (?,?)", (gene, sp))
-            alleles = gen_locus_alleles(rng, length, alleles_per_locus, max_div=max_div, indel_every=indel_every)
+            n_here = alleles_per_locus[(sp, gene)] if isinstance(alleles_per_locus, dict) else alleles_per_locus
+            root = None
+            if roots and (sp, gene) in roots:
+                root = root_of[roots[(sp, gene)]].copy()
+                pos = rng.choice(len(root), size=max(1, len(root) // 100), replace=False)      # ~1 % apart from the locus it copies
+                root[pos] = (root[pos] + rng.integers(1, 4, size=len(pos), dtype=np.uint8)) % 4
+            alleles = gen_locus_alleles(rng, length, n_here, max_div=max_div, indel_every=indel_every, root=root)
+            root_of[(sp, gene)] = alleles[0]
             db.n_alleles[(sp, gene)] = len(alleles)
             for k, a in enumerate(alleles, start=1):
                 s = _ACGT[a].tobytes().decode()
@@ -127,6 +138,28 @@ def make_full_db(path: str, n_species: int = 150, alleles_per_locus: int = 300, 
     for s in range(n_species):
         sl["sp%03d" % s] = [("g%d" % g, int(rng.integers(400, 601))) for g in range(7)]
     return make_db(path, sl, alleles_per_locus, n_profiles, seed)
+
+
+def make_skewed_db(path: str, n_species: int = 6, seed: int = SEED, n_profiles: int = 50, lo: int = 10, hi: int = 10_000,
+                   n_duplicates: int = 3) -> SynthDB:
+    """A PubMLST-shaped database (the real one, metaMLST_functions.py:39-57 with the schema of
+    metamlst-index.py:62-65, has loci with tens to thousands of alleles): alleles per locus log-uniform in lo..hi, locus
+    lengths U[300, 700], and n_duplicates loci that are near copies (~1 % apart) of a locus of ANOTHER species, so that
+    most of their seeds have postings in two loci and MLST_MAX_POSTINGS / the vote bins meet real collisions."""
+    rng = np.random.default_rng(seed + 2)
+    sl, counts = {}, {}
+    for s in range(n_species):
+        sp = "sk%03d" % s
+        sl[sp] = [("g%d" % g, int(rng.integers(300, 701))) for g in range(7)]
+        for g, _ in sl[sp]:
+            counts[(sp, g)] = int(round(float(np.exp(rng.uniform(np.log(lo), np.log(hi))))))
+    roots = {}
+    for k in range(min(n_duplicates, n_species - 1)):
+        src, dst = "sk%03d" % k, "sk%03d" % (k + 1)
+        g = "g%d" % int(rng.integers(0, 7))
+        roots[(dst, g)] = (src, g)
+        sl[dst] = [(gg, (dict(sl[src])[g] if gg == g else ln)) for gg, ln in sl[dst]]
+    return make_db(path, sl, counts, n_profiles, seed, roots=roots)
 
 
 def allele_sequence(db_path: str, species: str, gene: str, allele: int) -> str:

@@ -144,3 +144,74 @@ def test_routed_sieve_overflowing_tiles_become_candidates():
     eng.load_reference(idx)
     eng.submit_reads(fb, fq, off); orc.submit_reads(fb, fq, off)
     fx.assert_stats_equal(eng.stats(), orc.stats())
+
+
+@pytest.mark.skipif(not os.environ.get("MLST_WHOLE_BATCH"), reason="opt-in (MLST_WHOLE_BATCH=1): the oracle over all 50 M reads of a bench batch "
+                                                                     "takes ~2 min of every host core of the GPU box, 20 min on a small CPU share")
+def test_whole_bench_batch_equals_the_oracle():
+    """profiles/check_batch.py as a test: engine = oracle over EVERY read of resident batch 0 of the bench's cfg3 workload
+    (statistics, first-seen order, chosen alleles, pile-up counts) and every planted ST called."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "profiles", "check_batch.py"), "--batches", os.environ.get("MLST_WHOLE_BATCH_LIST", "0")],
+                       capture_output=True, text=True, timeout=3400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert recs
+    for rec in recs:
+        assert all(rec[k] for k in ("sum_score_equal", "n_hits_equal", "locus_len_equal", "locus_first_equal", "chosen_equal", "pileup_equal")), rec
+        assert not rec["not_as_planted"], rec["not_as_planted"]
+
+
+def test_pubmlst_shaped_database_with_skewed_loci_and_near_duplicate_loci():
+    """alleles per locus log-uniform 10 .. 10,000 (the real metamlstDB has loci with tens to thousands of
+    alleles: metaMLST_functions.py:39-57, schema metamlst-index.py:62-65), lengths 300-700, three loci that are ~1 % copies
+    of a locus of another species (their seeds carry postings of two loci).  k_extend's workgroup shapes (one wave up to
+    512 alleles, 256 threads beyond), the seed table's posting lists and the vote bins all meet that skew here: engine =
+    oracle bit for bit on a three-species sample that includes both sides of a duplicated locus, through the sieve the
+    size selects and through the routed one, and the device-side allele choice + consensus equal the host's.  (Planted STs
+    are not asserted: with thousands of alleles 3 % apart many differ only in columns a local aligner clips, and
+    metamlst.py:244 then takes the lowest allele number -- on both sides.  hi = 3,000 keeps the oracle's index build,
+    which is quadratic in the alleles of a locus, at ~15 s.)"""
+    sdb = synth.make_skewed_db(os.path.join(_TMP, "skew.db"), n_species=6, hi=3000)
+    idx = load_index(sdb.path)
+    counts = sorted(sdb.n_alleles.values())
+    assert counts[0] < 20 and counts[-1] > 2000 and idx.n_alleles > 20_000
+    parts_b, parts_q, planted = [], [], {}
+    for k, sp in enumerate(sdb.species[:3]):                  # sk000 / sk001 / sk002 share duplicated loci pairwise
+        g, _ = synth.make_genome(sdb, sp, sdb.profiles[sp][k], size=250_000, seed=70 + k)
+        b, q = synth.sample_reads(g, 60_000, seed=80 + k)
+        parts_b.append(b); parts_q.append(q); planted[sp] = k + 1
+    bases, quals = np.concatenate(parts_b), np.concatenate(parts_q)
+    perm = np.random.default_rng(4).permutation(len(bases))
+    fb, fq, off = synth.flatten_reads(bases[perm], quals[perm])
+    orc = oracle_lib.Oracle(idx, threads=os.cpu_count() or 1)
+    orc.submit_reads(fb, fq, off)
+    so, items_o = orc.stats(want_items=1 << 20)
+    for kind in (None, "routed"):
+        if kind:
+            os.environ["MLST_SIEVE"] = kind
+        try:
+            eng = Engine(0)
+            eng.load_reference(idx)
+            eng.submit_reads(fb, fq, off)
+            s = eng.stats()
+            fx.assert_stats_equal(s, so)
+            assert np.array_equal(fx.sorted_items(eng.items(1 << 20)), fx.sorted_items(items_o))
+            ch = sorted(pick_alleles_fast(idx, s, 100).values())
+            pe, po = eng.pileup(ch), orc.pileup(ch)
+            for a in ch:
+                assert np.array_equal(pe[a], po[a])
+            eng.reset_sample()
+            eng.submit_reads(fb, fq, off)
+            eng.typing_enqueue(penalty=100)
+            st, chd, letd = eng.typing_fetch()
+            want = pick_alleles_fast(idx, st, 100)
+            assert chd == want and len(want) >= 21
+            cons = eng.consensus(sorted(want.values()))
+            assert {a: bytes(v) for a, v in letd.items()} == {a: bytes(v) for a, v in cons.items()}
+            eng.close()
+        finally:
+            os.environ.pop("MLST_SIEVE", None)
