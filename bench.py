@@ -348,7 +348,7 @@ def rooflines(w, res, eng):
     on the GPU), and the VALU view of k_extend."""
     iso = res["iso_launch_ms"]
     kind = eng.sieve_info()["kind"]
-    stream_kernels = {"sieve_route": "k_route", "sieve_probe": "k_route_probe"} if kind == "routed" else {"sieve": "k_sieve_q"}
+    stream_kernels = {"sieve_route": "k_route", "sieve_probe": "k_route_probe", "sieve_verify": "k_route_verify"} if kind == "routed" else {"sieve": "k_sieve_q"}
     cands = dict(stream_kernels)
     cands.update({"seed": "k_seed+k_retain", "extend": "k_extend", "banded_sw": "k_banded", "accumulate": "k_accumulate+k_locus", "pileup": "k_pileup"})
     dom = max(cands, key=lambda k: iso.get(k, 0.0))

@@ -133,8 +133,9 @@ int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes
  * code of csrc/inflate_dev.h; *produced = bytes written).  Not a data path. */
 int mlst_selftest_inflate(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced);
 
-/* Test hook of the DEVICE decoder (csrc/inflate_wave.h): whole BGZF blocks in, their inflated text out (host buffers). */
-int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, uint8_t* out, uint64_t cap, uint64_t* produced);
+/* Test hook of the DEVICE decoder (csrc/inflate_wave.h): whole BGZF blocks in, their inflated text out (host buffers);
+ * kernel_ms (optional) receives the duration of the inflate kernel alone (HIP events). */
+int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, uint8_t* out, uint64_t cap, uint64_t* produced, double* kernel_ms);
 
 /* Same, with the three arrays already in DEVICE memory (GPU-side FASTQ decode feeds this). */
 int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
@@ -274,8 +275,8 @@ typedef struct mlst_item {     /* one (read, locus, strand, diagonal) unit of ex
 int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint64_t* n);
 
 /* Per-kernel device time measured with HIP events on the engine's stream.
- * which: 0=sieve (all its kernels) 1=seed 2=extend 3=banded-SW 4=accumulate 5=pileup 6=pack; 9 = k_route and 10 =
- * k_route_probe, the two kernels of the routed sieve (inside 0) (events bracket the launch on the engine's
+ * which: 0=sieve (all its kernels) 1=seed 2=extend 3=banded-SW 4=accumulate 5=pileup 6=pack; 9 = k_route, 10 =
+ * k_route_probe and 11 = k_route_verify, the three kernels of the routed sieve (inside 0) (events bracket the launch on the engine's
  * stream, so with several engines on one GPU they include the time a kernel queues behind another stream's kernel);
  * 7 = the sieve's execution window measured inside the kernel (wall clock at the first workgroup's start and the last
  * one's end; one submission per sample), added up when the sample's statistics are fetched;

@@ -125,8 +125,12 @@ struct Counters {
     u64 err;             // bit0 retained overflow, bit1 item overflow, bit2 result overflow, bit3 dp overflow
     u64 sv_t0n, sv_t1;   // sieve execution window in wall-clock ticks: max over workgroups of ~start and of end (profiling)
     u64 sv_wgmax;        // longest residency of one sieve workgroup (end - start), wall-clock ticks
-    u64 rt_next;         // routed sieve: tiles handed out beyond every producer's first one (zero between submissions)
     u64 cnt[MLST_CNT_N];
+    // (new fields go behind this point: the arrays that follow the counters in the statistics block keep their offsets --
+    // with these two in front of cnt[], k_extend, whose code had not changed, ran 0.62 instead of 0.55 ms)
+    u64 rt_next;         // routed sieve: tiles handed out beyond every producer's first one (zero between submissions)
+    u64 rt_parked;       // routed sieve: entries that passed the filter and wait in R.parked for k_route_verify (zero between submissions)
+    u64 pad_[14];        // the block stays a multiple of 128 bytes longer than it was in round 2
 };
 // item_state bits
 #define IS_SINGLE 1   /* the read has exactly one work item */
@@ -584,37 +588,31 @@ __device__ inline bool bin_exact(u32 w0, u32 w1, const uint4* __restrict__ sieve
 #define RT_DUMMY 0x01FFFFFFu
 // 33 hash bits of a canonical key: 8 choose the owner, 25 travel in the entry (a real key that hashes to RT_DUMMY takes
 // the value below it -- in the filter build, in k_route and in the re-hash of k_route_probe alike).
-// One 32 x 32 -> 64-bit multiply of the key folded to 32 bits; the 33 bits are taken from the MIDDLE of the product
-// (bits 15..47: every one of them depends on the key bits below it and, through the carries, on most of those above
-// bit 15; the map key -> product is injective, so two folded keys collide in these 33 bits with probability 2^-33 like
-// with any other hash).  Round 2 ran table_hash here (two multiplies, two xor-shifts) plus a parity: ~22 VALU
-// instructions per seed, three of them quarter rate; this is 7 with one multiply, and k_route hashes 450 M seeds per batch.
+// One 32 x 32 -> 64-bit multiply of the key's low word; 32 bits from the MIDDLE of the product (bits 16..47: each of them
+// depends on the key bits below it and, through the carries, on those above), XORed with a multiple of the key's top byte,
+// plus product bit 15.  Simulated on 16 M random keys: 0.189 % of random seeds share all 33 bits with a key (ideal
+// 2^-33 per pair: 0.186 %).  A first version folded the 40 key bits to 32 BEFORE the multiply: 33 bits cut out of a
+// 32-bit quantity collide seven times as often (1.3 %, 7.7 M instead of 2.9 M entries to examine: the consumer ran 0.3 ms
+// longer).  Round 2 ran table_hash here (two multiplies, two xor-shifts) plus a parity: ~22 VALU instructions per seed,
+// three of them quarter rate; this is 9 with one multiply, and k_route hashes 450 M seeds per batch.
 __host__ __device__ inline void rt_hash(u32 lo, u32 hi, u32& owner, u32& h25) {
-    const u32 m = lo ^ (hi * 0x9E3779u);          // hi < 256: a 24-bit multiply (full rate)
-    const u64 P = (u64)m * 0x9E3779B1u;
-    owner = (u32)(P >> 40) & 0xFFu;
-    h25 = (u32)(P >> 15) & RT_HMASK;
+    const u64 P = (u64)lo * 0x9E3779B1u;
+    const u32 x = (u32)(P >> 16) ^ (hi * 0x9E3779u);     // hi < 256: a 24-bit multiply (full rate)
+    owner = x >> 24;
+    h25 = ((x & 0xFFFFFFu) << 1) | ((u32)(P >> 15) & 1u);
     h25 = h25 < RT_DUMMY - 1u ? h25 : RT_DUMMY - 1u;
 }
-// Filter slice = 2^15 words of 32 bits (128 KiB).  A key sets three bits in each of TWO words: a pair of bits 13 apart,
-// rotated by five hash bits, and one more bit chosen by five others (one v_alignbit + one v_bfe + one v_lshl_or per word;
-// six independent bit positions cost 22 instructions per entry, and the consumer is bound by instruction issue: 48
-// VALU instructions per entry in round 2).  ~6 of 32 bits per word are set (65 k keys per owner): a foreign seed
-// passes one word with p ~ 0.015, both with ~2 * 10^-4 -- an order of magnitude under the 0.19 % of seeds that share all 33 hash bits
-// with a database key, which is what sends an entry to the exact check for nothing.
-__host__ __device__ inline u32 rt_rotr(u32 x, u32 r) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_alignbit(x, x, r);     // uses r & 31
-#else
-    r &= 31u; return r ? (x >> r) | (x << (32u - r)) : x;
-#endif
-}
+// Filter slice = 2^15 words of 32 bits (128 KiB), 16 bits per key.  A key sets three independently chosen bits in each
+// of TWO words: 0.19 % of foreign seeds pass (measured and simulated), beside the 0.19 % that share all 33 hash bits with
+// a database key -- every pass costs the consumer ~0.7 KB of row and bucket traffic.  Cheaper masks were tried in round
+// 3 (a rotated pair of bits + one bit per word: two instructions fewer per entry, 0.44 % pass: the consumer ran 0.3 ms
+// LONGER; a rotated triple: 1.8 %); with v_lshl_or the three bit positions cost six instructions per word as they are.
 __host__ __device__ inline void rt_filter_addr(u32 h25, u32& word0, u32& mask0, u32& word1, u32& mask1) {
     const u32 m = h25 * 0x9E3779B1u;               // top bits of a product are the well mixed ones
     word0 = h25 >> 10;
-    mask0 = rt_rotr(0x2001u, m >> 27) | (1u << ((m >> 22) & 31u));
-    word1 = ((m >> 7) ^ h25) & 0x7FFFu;
-    mask1 = rt_rotr(0x2001u, m >> 17) | (1u << ((m >> 12) & 31u));
+    mask0 = (1u << (m >> 27)) | (1u << ((m >> 22) & 31u)) | (1u << ((m >> 17) & 31u));
+    word1 = ((m >> 9) ^ h25) & 0x7FFFu;
+    mask1 = (1u << ((m >> 12) & 31u)) | (1u << ((m >> 7) & 31u)) | (1u << ((m >> 2) & 31u));
 }
 struct RouteDev {
     GP<u32> arena;                   // [owner][producer][cap] entries
@@ -623,7 +621,9 @@ struct RouteDev {
     GP<const u32> filter;            // [owner][RT_FWORDS]
     GP<u32> flags;                   // candidate flag per read (zeroed per submission)
     GP<u64> trace;                   // diagnostics (mlst_get_route_trace), NULL when off: four words per workgroup
+    GP<u64> parked; u64 parked_cap;  // entries that passed the filter (rt_park), examined by k_route_verify
     u32 cap, n_prod, tiles_max, nw;  // nw = waves per producer workgroup = groups of 64 reads per tile
+    u32 dbg;                         // profiling builds of the launch: bit 0 = entries that pass the filter are not examined (timing only, results wrong)
 };
 // where and when a workgroup ran: XCC id | HW_ID << 32, wall clock at its start; the end is stored by rt_trace_end
 __device__ inline void rt_trace_begin(const RouteDev& R, u32 slot) {
@@ -877,45 +877,72 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
 // not fetched: rows hold zeros beyond the read, and a window of them that happened to reproduce the entry's 33 hash
 // bits AND sat in the fingerprint sieve would add a candidate, which k_seed looks up exactly like every other.
 // A parked entry: hash (25 bits) | lane << 25 | producer wave << 31 | position of the tile in the producer's list << 35 |
-// producer << 51.  The tile's number is looked up here, not where the entry passed the filter: a dependent global load
-// there stalled the streaming loop in three iterations out of four (0.90 -> 1.00 ms).
+// producer << 51.  The tile's number is looked up when the entry is examined, not where it passed the filter: a
+// dependent global load there stalled the streaming loop in three iterations out of four (0.90 -> 1.00 ms).
 __device__ inline u64 rt_park(u32 entry, u32 wv, u32 jt, u32 p) {
     return (u64)(entry & (RT_HMASK | (63u << 25))) | ((u64)wv << 31) | ((u64)jt << 35) | ((u64)p << 51);
 }
-template <int WPR>
-__device__ inline void rt_examine(const u64* q, u32 cnt, int lane, u32 owner, const u32* __restrict__ packed, u64 n_reads, const RouteDev& R, u32 NWP,
-                                  const uint4* __restrict__ sieve, u32 smask, u32 sshift, u32* flags) {
+// Examine one parked entry: the read's row is fetched, its seeds are re-hashed, the one whose 25 hash bits are the
+// entry's probes the fingerprint sieve; a hit sets the read's candidate flag.  Three dependent round trips (tile number,
+// row, bucket), each a batch of independent loads.  A read with several seeds of that hash becomes a candidate without
+// the exact check (k_seed looks every seed of every candidate up exactly; round 2 probed inside the loop over the seeds:
+// up to nine dependent bucket walks per round, ~17 us per 64 entries).  The read's length is not fetched: rows hold
+// zeros beyond the read, and a window of them that reproduced the hash AND sat in the sieve would add a candidate.
+template <int WPR, bool CHECK_FLAG>
+__device__ inline void rt_examine_one(u64 e, const u32* __restrict__ packed, u64 n_reads, const RouteDev& R, u32 NWP,
+                                      const uint4* __restrict__ sieve, u32 smask, u32 sshift) {
     constexpr int NT = WPR - 1;
-    if ((u32)lane >= cnt) return;
-    const u64 e = q[lane];
     const u32 want = (u32)e & RT_HMASK, ln = ((u32)e >> 25) & 63u, wv = (u32)(e >> 31) & 15u, jt = (u32)(e >> 35) & 0xFFFFu, p = (u32)(e >> 51);
     const u32 tile = R.emitted[(u64)p * (R.tiles_max + 1) + 1 + jt];
     const u64 rr = ((u64)tile * NWP + wv) * 64 + ln;
     if (rr >= n_reads) return;
+    // a read on a locus arrives here nine times, from nine owners: once its flag is up the other eight need no row (640
+    // bytes each).  A stale look (the flag words are written by atomics of other XCDs) only costs the fetch it would have saved.
+    if (CHECK_FLAG && ((__hip_atomic_load(&R.flags.p[rr >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (rr & 31)) & 1u)) return;
     const u32* row = packed + packed_index(rr, WPR, 0);      // word c of the row: row[(c >> 1) * 128 + (c & 1)]
     u32 w[WPR];
     #pragma unroll
     for (int c = 0; c < WPR; c++) w[c] = row[(c >> 1) * 128 + (c & 1)];
     tie_all<WPR>(w);
-    bool hit = false;
+    u32 k0 = 0, k1 = 0, nm = 0;
     #pragma unroll
     for (int t = 0; t < NT; t++) {
-        if (!hit) {
-            u32 fl; const u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl);
-            u32 ow, hh; rt_hash((u32)c, (u32)(c >> 32), ow, hh);
-            if (ow == owner && hh == want) hit = bin_exact(w[t], w[t + 1], sieve, smask, sshift);
-        }
+        u32 fl; const u64 c = canon40((u64)w[t] | ((u64)(w[t + 1] & 0xFFu) << 32), fl);
+        u32 ow, hh; rt_hash((u32)c, (u32)(c >> 32), ow, hh);
+        if (hh == want) { if (nm == 0) { k0 = w[t]; k1 = w[t + 1]; } nm++; }
     }
-    if (hit) atomicOr(&flags[rr >> 5], 1u << (rr & 31));
+    bool hit = nm > 1;
+    if (nm == 1) hit = bin_exact(k0, k1, sieve, smask, sshift);
+    if (hit) atomicOr(&R.flags.p[rr >> 5], 1u << (rr & 31));
 }
+// up to 64 parked entries of one wave leave for k_route_verify (one atomic, one coalesced store); when the list is full
+// they are examined here
 template <int WPR>
+__device__ inline void rt_flush(const u64* q, u32 cnt, int lane, const u32* __restrict__ packed, u64 n_reads, const RouteDev& R, u32 NWP,
+                                const uint4* __restrict__ sieve, u32 smask, u32 sshift, Counters* __restrict__ ctr) {
+    if (cnt == 0 || (R.dbg & 1u)) return;
+    u64 base = 0;
+    if (lane == 0) base = atomicAdd(&ctr->rt_parked, (u64)cnt);
+    base = uniform_u64(base);
+    if (base + cnt <= R.parked_cap) { if ((u32)lane < cnt) R.parked[base + (u32)lane] = q[lane]; }
+    else if ((u32)lane < cnt) rt_examine_one<WPR, false>(q[lane], packed, n_reads, R, NWP, sieve, smask, sshift);
+}
+// the entries that passed the LDS filter, examined at full occupancy (inside k_route_probe, whose 147 KB of LDS allow 16
+// waves per CU, the three round trips of an examination stalled the streaming waves: 0.5 of 1.2 ms at 7.7 M entries)
+template <int WPR>
+__global__ __launch_bounds__(256) void k_route_verify(const u32* __restrict__ packed, u64 n_reads, const uint4* __restrict__ sieve, u32 smask, const RouteDev R,
+                                                      Counters* __restrict__ ctr) {
+    const u32 sshift = (u32)__clz((int)smask);
+    u64 n = ctr->rt_parked; n = n < R.parked_cap ? n : R.parked_cap;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        rt_examine_one<WPR, true>(R.parked[i], packed, n_reads, R, R.nw, sieve, smask, sshift);
+}
+template <int WPR, int PF>
 __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ packed, u64 n_reads,
                                                       const uint4* __restrict__ sieve, u32 smask, const RouteDev R, Counters* __restrict__ ctr) {
     __shared__ __attribute__((aligned(16))) u32 s_f[RT_FWORDS];
     __shared__ u64 s_q[16][128];                  // per-wave queue of entries that passed the filter: read | hash << 32
-    constexpr int PF = 2;                         // 16-byte loads per lane in flight: 2 KiB per wave, 32 KiB per CU.  (Four were no faster --
-                                                  // 0.94-0.98 against 0.90-0.93 ms in alternating runs -- and cost 20 VGPRs: ~100 against ~80, the
-                                                  // difference between one and two waves of another kernel per SIMD next to this one)
+    // PF = 16-byte loads per lane in flight: 2 (2 KiB per wave, 32 KiB per CU) or 4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 owner = blockIdx.x, P = R.n_prod;
     const u32 sshift = (u32)__clz((int)smask);
@@ -990,7 +1017,7 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
                         qn += (u32)__popcll(pm);
                         if (qn >= 64) {
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            rt_examine<WPR>(q + (qn - 64), 64, lane, owner, packed, n_reads, R, NWP, sieve, smask, sshift, R.flags.p);
+                            rt_flush<WPR>(q + (qn - 64), 64, lane, packed, n_reads, R, NWP, sieve, smask, sshift, ctr);
                             qn -= 64; n_pass += 64;
                         }
                     }
@@ -1000,7 +1027,7 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    rt_examine<WPR>(q, qn, lane, owner, packed, n_reads, R, NWP, sieve, smask, sshift, R.flags.p);
+    rt_flush<WPR>(q, qn, lane, packed, n_reads, R, NWP, sieve, smask, sshift, ctr);
     n_pass += qn;
     if (lane == 0 && n_pass) atomicAdd(&ctr->cnt[MLST_CNT_SIEVE_PASS], (u64)n_pass);
     __syncthreads();
@@ -1012,7 +1039,7 @@ __global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ f
     __shared__ u32 s_cnt[16]; __shared__ u64 s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u64 n_words = (n_reads + 31) >> 5;
-    if (blockIdx.x == 0 && tid == 0) ctr->rt_next = 0;      // the producers' tile counter, for the next submission
+    if (blockIdx.x == 0 && tid == 0) { ctr->rt_next = 0; ctr->rt_parked = 0; }      // the producers' tile counter and the parked list, for the next submission
     for (u64 w0 = (u64)blockIdx.x * 1024; w0 < n_words; w0 += (u64)gridDim.x * 1024) {
         const u64 wi = w0 + tid;
         u32 f = wi < n_words ? flags[wi] : 0u;
@@ -1039,16 +1066,28 @@ __global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ f
 
 // ------------------------------------------------------------------ BGZF -> text (one wave per <= 64 KiB deflate block)
 struct BgzfBlk { u64 in_off, out_off; u32 in_len, out_len; };
+#if !defined(MLST_INFLATE_GROUP)
+#define MLST_INFLATE_GROUP 64
+#endif
+#define INFLATE_NG (64 / MLST_INFLATE_GROUP)      /* streams per wave (csrc/inflate_wave.h) */
 // one wave per block (csrc/inflate_wave.h); comp_bytes = size of the compressed buffer (the input windows stop there)
 __global__ __launch_bounds__(64) void k_inflate(const u8* __restrict__ comp, u64 comp_bytes, const BgzfBlk* __restrict__ blk, u32 n_blk, u8* __restrict__ out,
-                                                u32* __restrict__ err /* [0] = 1 + first bad block, [1] = its code */) {
+                                                u32* __restrict__ err /* [0] = 1 + first bad block, [1] = its code */, unsigned long long* __restrict__ stats /* optional: 12 sums */) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ inflate_wave::Tabs s_tb;           // Huffman tables of the stream
-    const int lane = (int)threadIdx.x;
-    for (u32 i = blockIdx.x; i < n_blk; i += gridDim.x) {     // wave-uniform
+    constexpr int GS = inflate_wave::GS, NG = 64 / GS;      // lanes per stream, streams per wave
+    __shared__ inflate_wave::Tabs s_tb[NG];        // Huffman tables, output ring and match queue of every stream
+    const int lane = (int)threadIdx.x % GS, grp = (int)threadIdx.x / GS, gbase = grp * GS;
+    for (u32 i = blockIdx.x * NG + (u32)grp; i < n_blk; i += gridDim.x * NG) {     // the same for the lanes of a group
         const BgzfBlk B = blk[i];
         u32 produced = 0;
-        int rc = inflate_wave::inflate_stream(comp + B.in_off, (u64)B.in_len, comp + comp_bytes, out + B.out_off, B.out_len, s_tb, lane, &produced);
+        inflate_wave::Stats st;
+        int rc = inflate_wave::inflate_stream(comp + B.in_off, (u64)B.in_len, comp + comp_bytes, out + B.out_off, B.out_len, s_tb[grp], lane, gbase, &produced, &st);
+#if defined(MLST_INFLATE_STATS)
+        if (stats && lane == 0) {
+            const unsigned long long v[10] = {st.lookups, st.lits, st.near_, st.far_def, st.far_sync, st.far_flush, st.fences, st.builds, st.t_build, st.t_codes};
+            for (int k = 0; k < 10; k++) atomicAdd(&stats[k], v[k]);
+        }
+#endif
         if (rc == mlst_inflate::OK && produced != B.out_len) rc = mlst_inflate::E_SHORT;
         if (rc != mlst_inflate::OK && lane == 0 && atomicCAS(&err[0], 0u, i + 1u) == 0u) err[1] = (u32)(-rc);
         inflate_wave::wave_sync();                // the tables are rebuilt for the next stream
@@ -2411,7 +2450,8 @@ struct mlst_handle {
     // CU-routed sieve (K1c): filter slices (reference) and the per-submission arena
     int sieve_kind = 0; u32 sieve_chain = 0; u64 n_keys = 0;
     u32* d_rfilter = nullptr; u32* d_rt_arena = nullptr; u64 cap_rt_arena = 0; u32* d_rt_counts = nullptr; u32* d_rt_emitted = nullptr; u64 cap_rt_emitted = 0;
-    u32 rt_prod = 0, rt_cap = 0, rt_tiles_max = 0, rt_nw = 16;
+    u32 rt_prod = 0, rt_cap = 0, rt_tiles_max = 0, rt_nw = 16, rt_pf = 2;
+    u64* d_rt_parked = nullptr; u64 cap_rt_parked = 0;      // entries that passed the LDS filter (k_route_probe -> k_route_verify)
     u64* d_rt_trace = nullptr; bool rt_trace_on = false; const void* rt_last_packed = nullptr;      // mlst_get_route_trace
     std::vector<void*> dbg_pads;                 // mlst_debug_route_realloc: allocations kept to move the arena elsewhere
     u32* d_bin_flags = nullptr; u64 cap_bin_flags = 0;      // candidate flag per read of the current submission
@@ -2567,6 +2607,7 @@ static void free_state(mlst_handle* h) {
     EngineDev& E = h->E;
     hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; h->cap_bin_flags = 0;
     hipFree(h->d_rt_arena); hipFree(h->d_rt_counts); hipFree(h->d_rt_emitted); hipFree(h->d_rt_trace); h->d_rt_trace = nullptr;
+    hipFree(h->d_rt_parked); h->d_rt_parked = nullptr; h->cap_rt_parked = 0;
     for (void* q : h->dbg_pads) hipFree(q);
     h->dbg_pads.clear();
     h->d_rt_arena = nullptr; h->d_rt_counts = nullptr; h->d_rt_emitted = nullptr; h->cap_rt_arena = 0; h->cap_rt_emitted = 0; h->rt_prod = 0;
@@ -3013,6 +3054,7 @@ extern "C" int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, co
 static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     u32 nw = 16;                                        // waves per producer workgroup (tile = nw groups of 64 reads)
     { const char* e = getenv("MLST_ROUTE_WAVES"); if (e && atoi(e) == 8) nw = 8; }
+    { const char* e = getenv("MLST_PROBE_PF"); h->rt_pf = (e && atoi(e) == 4) ? 4u : 2u; }
     const u64 tile = (u64)nw * 64, n_tiles = (n_reads + tile - 1) / tile;
     u32 prod = (wpr <= 10 ? 512u : 256u) * (16u / nw);  // as many workgroups as the LDS lets share the CUs
     { const char* e = getenv("MLST_ROUTE_BLOCKS"); if (e && atoi(e) > 0) prod = (u32)atoi(e); }
@@ -3035,6 +3077,10 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     if (h->cap_rt_emitted < need_e) { hipStreamSynchronize(h->stream); hipFree(h->d_rt_emitted); h->d_rt_emitted = nullptr; HIPCHK(h, dmalloc(&h->d_rt_emitted, need_e)); h->cap_rt_emitted = need_e; }
     h->rt_tiles_max = (u32)tiles_max; h->rt_nw = nw;
     if (h->rt_trace_on && !h->d_rt_trace) { hipStreamSynchronize(h->stream); HIPCHK(h, dmalloc(&h->d_rt_trace, (u64)(RT_MAXP + RT_OWNERS) * 4)); HIPCHK(h, hipMemset(h->d_rt_trace, 0, (u64)(RT_MAXP + RT_OWNERS) * 32)); }
+    // ~0.6 % of the entries pass the filter (1.5 x the reads' real hits + 0.4 % of chance): room for a quarter of the reads,
+    // beyond which the consumer examines in place
+    const u64 need_p = std::max<u64>(n_reads / 4, 1ull << 16);
+    if (h->cap_rt_parked < need_p) { hipStreamSynchronize(h->stream); hipFree(h->d_rt_parked); h->d_rt_parked = nullptr; HIPCHK(h, dmalloc(&h->d_rt_parked, need_p)); h->cap_rt_parked = need_p; }
     const u64 n_flag_words = (n_reads + 31) >> 5;
     if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words; }
     return MLST_OK;
@@ -3061,7 +3107,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
                                                (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand,
                                                (u64)(uintptr_t)h->d_bin_flags, (u64)(uintptr_t)h->d_rt_arena, (u64)(uintptr_t)h->d_rt_counts,
-                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw, (u64)paired, (u64)(uintptr_t)h->d_rt_trace});
+                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw, (u64)paired, (u64)(uintptr_t)h->d_rt_trace, (u64)(uintptr_t)h->d_rt_parked, (u64)h->cap_rt_parked, (u64)h->rt_pf});
     if (gs == 1) { h->reads_seen += n_reads; return MLST_OK; }
     { Prof pf(h, 0);
       if (h->sieve_kind == MLST_SIEVE_LDS) {      // LDS first level: one 1024-thread workgroup per CU
@@ -3073,9 +3119,10 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       } else if (h->sieve_kind == MLST_SIEVE_ROUTED) {      // seeds routed to the CU that owns their filter slice (K1c)
         const u64 n_flag_words = (n_reads + 31) >> 5;
         zero_words(h, h->d_bin_flags, n_flag_words);
-        RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags; R.trace = h->d_rt_trace;
+        RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags; R.trace = h->d_rt_trace; R.parked = h->d_rt_parked; R.parked_cap = h->cap_rt_parked;
         h->rt_last_packed = d_packed;
         R.cap = h->rt_cap; R.n_prod = h->rt_prod; R.tiles_max = h->rt_tiles_max; R.nw = h->rt_nw;
+        { const char* e = getenv("MLST_RT_DEBUG"); R.dbg = e ? (u32)atoi(e) : 0u; if (R.dbg & 2u) R.parked_cap = 0; }      // 2 = examine in place (no k_route_verify work)
         { Prof pa(h, 9);
 #define SIEVE_CASE(W) case W: if (h->rt_nw == 8) hipLaunchKernelGGL((k_route<W, 8>), dim3(h->rt_prod), dim3(512), 0, h->stream, d_packed, d_lens, (u64)n_reads, R, E.ctr); \
                               else hipLaunchKernelGGL((k_route<W, 16>), dim3(h->rt_prod), dim3(1024), 0, h->stream, d_packed, d_lens, (u64)n_reads, R, E.ctr); break;
@@ -3084,7 +3131,14 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
 #undef SIEVE_CASE
         }
         { Prof pb(h, 10);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_route_probe<W>, dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); break;
+#define SIEVE_CASE(W) case W: if (h->rt_pf == 4) hipLaunchKernelGGL((k_route_probe<W, 4>), dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); \
+                              else hipLaunchKernelGGL((k_route_probe<W, 2>), dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); break;
+        switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
+                       SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
+#undef SIEVE_CASE
+        }
+        { Prof pc(h, 11);
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_route_verify<W>, dim3(2048), dim3(256), 0, h->stream, d_packed, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
@@ -3370,7 +3424,7 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
         HIPCHK(h, hipMemcpyAsync(h->d_bgzf_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->stream));
         u32* d_err = reinterpret_cast<u32*>(h->d_fq_meta + 2);
         HIPCHK(h, hipMemsetAsync(d_err, 0, 8, h->stream));
-        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(blks.size(), 1u << 20)), dim3(64), 0, h->stream, h->d_bgzf, (u64)h->cap_bgzf + 16, (const BgzfBlk*)h->d_bgzf_blk, (u32)blks.size(), h->d_fq_text, d_err);
+        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>((blks.size() + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, h->stream, h->d_bgzf, (u64)h->cap_bgzf + 16, (const BgzfBlk*)h->d_bgzf_blk, (u32)blks.size(), h->d_fq_text, d_err, (unsigned long long*)nullptr);
         u32 err[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));      // also: blks / data may be released by the caller after this
@@ -3381,7 +3435,7 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
 
 // k_inflate itself on whole BGZF blocks, text back to the host: the test hook of the DEVICE decoder (tests/test_inflate.py
 // compares it with zlib block by block on the GPU box)
-extern "C" int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, uint8_t* out, uint64_t cap, uint64_t* produced) {
+extern "C" int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, uint8_t* out, uint64_t cap, uint64_t* produced, double* kernel_ms) {
     if (!h) return MLST_E_INVALID;
     if (produced) *produced = 0;
     if (!data || !out) return fail(h, MLST_E_INVALID, "NULL argument");
@@ -3397,19 +3451,38 @@ extern "C" int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data,
     if (text_bytes > cap) return fail(h, MLST_E_LIMIT, "output buffer too small (%llu bytes needed)", (unsigned long long)text_bytes);
     if (produced) *produced = text_bytes;
     if (blks.empty()) return MLST_OK;
-    u8* d_in = nullptr; u8* d_out = nullptr; BgzfBlk* d_blk = nullptr; u32* d_err = nullptr;
+    u8* d_in = nullptr; u8* d_out = nullptr; BgzfBlk* d_blk = nullptr; u32* d_err = nullptr; unsigned long long* d_st = nullptr;
     int rc = MLST_OK; u32 err[2] = {0, 0};
+#if defined(MLST_INFLATE_STATS)
+    const bool want_stats = getenv("MLST_INFLATE_STATS") != nullptr;      // (diagnostic builds: hipcc -DMLST_INFLATE_STATS)
+#else
+    const bool want_stats = false;
+#endif
+    if (want_stats && (dmalloc(&d_st, (u64)16) != hipSuccess || hipMemset(d_st, 0, 128) != hipSuccess)) d_st = nullptr;
     if (dmalloc(&d_in, n_bytes + 16) != hipSuccess || dmalloc(&d_out, text_bytes + 16) != hipSuccess || dmalloc(&d_blk, (u64)blks.size()) != hipSuccess || dmalloc(&d_err, (u64)2) != hipSuccess)
         rc = fail(h, MLST_E_HIP, "device allocation failed");
     if (!rc && (hipMemcpy(d_in, data, n_bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice) != hipSuccess
                 || hipMemset(d_err, 0, 8) != hipSuccess || hipMemset(d_out, 0xEE, text_bytes) != hipSuccess)) rc = fail(h, MLST_E_HIP, "copy to the device failed");
     if (!rc) {
-        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(blks.size(), 1u << 20)), dim3(64), 0, h->stream, d_in, (u64)n_bytes + 16, (const BgzfBlk*)d_blk, (u32)blks.size(), d_out, d_err);
-        if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(err, d_err, 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out, d_out, text_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        hipEvent_t e0 = ev_get(h), e1 = ev_get(h);
+        hipEventRecord(e0, h->stream);
+        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>((blks.size() + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, h->stream, d_in, (u64)n_bytes + 16, (const BgzfBlk*)d_blk, (u32)blks.size(), d_out, d_err, d_st);
+        hipEventRecord(e1, h->stream);
+        hipError_t se = hipStreamSynchronize(h->stream);
+        float ms = 0; if (se == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
+        if (kernel_ms) *kernel_ms = (double)ms;
+        h->ev_pool.push_back(e0); h->ev_pool.push_back(e1);
+        if (se != hipSuccess || hipMemcpy(err, d_err, 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out, d_out, text_bytes, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(h, MLST_E_HIP, "k_inflate failed: %s", hipGetErrorString(hipGetLastError()));
         else if (err[0]) rc = fail(h, MLST_E_INVALID, "corrupt deflate data in BGZF block %u (code %u)", err[0] - 1, err[1]);
     }
-    hipFree(d_in); hipFree(d_out); hipFree(d_blk); hipFree(d_err);
+    if (d_st && !rc) {
+        unsigned long long v[10] = {0};
+        if (hipMemcpy(v, d_st, sizeof v, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "k_inflate stats over %zu blocks: look-ups %llu, literal bytes %llu, near matches %llu, far matches deferred %llu / at once %llu, far flushes %llu, fences %llu, "
+                            "table builds %llu, cycles in builds %llu / in codes %llu (sums over waves)\n", blks.size(), v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
+    }
+    hipFree(d_in); hipFree(d_out); hipFree(d_blk); hipFree(d_err); hipFree(d_st);
     return rc;
 }
 

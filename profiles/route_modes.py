@@ -96,8 +96,10 @@ def main():
             launches(2)
         rt, pb = launches(args.launches)
         tr = eng.route_trace()
+        cnt = eng.stats().counters
         ph = {"realloc_pad": pad, "arena": hex(tr["arena"]), "arena_mod_2MiB": tr["arena"] % (2 << 20), "packed": hex(tr["packed"]),
               "filter": hex(tr["filter"]), "flags": hex(tr["flags"]), "P": tr["P"], "cap": tr["cap"],
+              "filter_passes": int(cnt[7]), "candidates": int(cnt[3]), "rt_debug": os.environ.get("MLST_RT_DEBUG"),
               "route_ms": {"min": round(min(rt), 4), "median": round(float(np.median(rt)), 4), "max": round(max(rt), 4), "all": [round(v, 4) for v in rt]},
               "probe_ms": {"min": round(min(pb), 4), "median": round(float(np.median(pb)), 4), "max": round(max(pb), 4)},
               "producer": wg_summary(tr, 0), "consumer": wg_summary(tr, 1)}
@@ -108,7 +110,8 @@ def main():
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "a") as f:
         f.write(json.dumps(rec) + "\n")
-    print(json.dumps({"tag": args.tag, "route_ms_median": [p["route_ms"]["median"] for p in rec["phases"]],
+    print(json.dumps({"tag": args.tag, "route_ms_median": [p["route_ms"]["median"] for p in rec["phases"]], "probe_ms_median": [p["probe_ms"]["median"] for p in rec["phases"]],
+                      "filter_passes": [p["filter_passes"] for p in rec["phases"]],
                       "arena": [p["arena"] for p in rec["phases"]], "xcc0": [p["producer"]["xcc_of_wg0"] for p in rec["phases"]]}))
 
 
