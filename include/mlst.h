@@ -308,7 +308,8 @@ int mlst_get_sieve_info(mlst_handle* h, uint64_t out[4]);
  * workgroup (P producers, then the 256 consumers): XCC_ID | HW_ID << 32, wall clock at start, at end, 0.
  * *n_words = words needed (0 while nothing has been traced).
  * mlst_debug_route_realloc: free the routing arena (the next submission allocates it again), keeping pad_bytes of
- * device memory allocated in between so that the new arena lands elsewhere. */
+ * device memory allocated in between so that the new arena lands elsewhere; pad_bytes = UINT64_MAX keeps the old arena itself
+ * allocated (until mlst_destroy), so that the new one is different memory for certain. */
 int mlst_get_route_trace(mlst_handle* h, uint64_t* out, uint64_t cap_words, uint64_t* n_words);
 int mlst_debug_route_realloc(mlst_handle* h, uint64_t pad_bytes);
 /* Block until all work queued on the engine's stream is done. */

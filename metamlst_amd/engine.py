@@ -495,7 +495,8 @@ class Engine:
         return d
 
     def debug_route_realloc(self, pad_bytes: int = 0):
-        self._check(self.lib.mlst_debug_route_realloc(self._h, int(pad_bytes)), "mlst_debug_route_realloc")
+        """pad_bytes = -1: keep the old arena allocated (the new one is other memory for certain)."""
+        self._check(self.lib.mlst_debug_route_realloc(self._h, int(pad_bytes) & 0xFFFFFFFFFFFFFFFF), "mlst_debug_route_realloc")
 
     def synchronize(self):
         self._check(self.lib.mlst_synchronize(self._h), "mlst_synchronize")
