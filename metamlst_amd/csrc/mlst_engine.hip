@@ -658,13 +658,16 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
     constexpr int NT = WPR - 1;
     constexpr int QN = NW / 4;                    // thread slices of 256: slice q holds the runs of waves 4q .. 4q+3
     constexpr u32 TILE = NW * 64u;
-    constexpr u32 SCAP = TILE * NT + (NW == 16 ? 2048u : 1536u);      // + dummy and padding entries (typically ~5 % + ~4..8 %)
+    constexpr u32 SCAP = TILE * NT + (NW == 16 ? 1024u : 768u);       // + dummy entries of empty runs (typically ~5 %)
+    constexpr u32 CW = 16;                        // entries per 64-byte chunk: what leaves for a region is whole, aligned chunks
     constexpr int OPW = RT_OWNERS / NW;           // owners whose segments a wave writes out
     __shared__ u32 s_cnt[NW][RT_OWNERS];          // per (wave, owner): count, later the start of the run in s_sorted
     __shared__ __attribute__((aligned(16))) u32 s_sorted[SCAP + 4];      // + a spare word for slots without a seed
     __shared__ u32 s_part[QN][RT_OWNERS];         // entries of an owner's runs per slice of the waves
     __shared__ u32 s_off[RT_OWNERS + 1];          // start of each owner's segment in s_sorted (multiples of four)
-    __shared__ u32 s_cur[RT_OWNERS];              // entries written so far to region (owner, this workgroup)
+    __shared__ u32 s_cur[RT_OWNERS];              // entries written so far to region (owner, this workgroup): a multiple of CW
+    __shared__ u32 s_carry[RT_OWNERS][CW];        // the entries of an owner that did not fill a chunk yet (fewer than CW), oldest first
+    __shared__ u32 s_cn[RT_OWNERS];               // how many
     __shared__ u32 s_wsum[4]; __shared__ u32 s_over;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // the wave number in a scalar register
     const u32 p = blockIdx.x, P = gridDim.x;
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
     if (tid == 0) { atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64()); rt_trace_begin(R, p); }
     #pragma unroll
     for (int v = 0; v < 4; v++) s_cnt[sq * 4 + v][so] = 0;
-    if (tid < RT_OWNERS) s_cur[tid] = 0;
+    if (tid < RT_OWNERS) { s_cur[tid] = 0; s_cn[tid] = 0; }
     if (tid == 0) s_over = 0;
     __syncthreads();
     const u64 n_groups = (n_reads + 63) >> 6, n_tiles = (n_reads + TILE - 1) / TILE;
@@ -769,8 +772,7 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
         }
         lds_barrier();
         // ---- run lengths and starts.  Thread (sq_, so_) owns the runs of waves 4 sq_ .. 4 sq_ + 3 for owner so_.  An empty run
-        // holds one dummy entry (the consumer counts runs); an owner's segment is padded to a multiple of four entries
-        // (16-byte stores, 16-byte aligned regions) with entries that are neither a seed nor a run start.
+        // holds one dummy entry (the consumer counts runs).
         u32 c4[4], s4 = 0;
         #pragma unroll
         for (int v = 0; v < 4; v++) { c4[v] = s_cnt[sq_ * 4 + v][so_]; s4 += c4[v] ? c4[v] : 1u; }
@@ -779,19 +781,17 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
         u32 pq[QN], tot = 0;
         #pragma unroll
         for (int v = 0; v < QN; v++) { pq[v] = s_part[v][so_]; tot += pq[v]; }
-        const u32 tot4 = (tot + 3u) & ~3u;
-        const u32 inc = wave_incl_scan_dpp(tot4);          // every wave scans the 64 owners of its chunk (so_ >> 6)
+        const u32 inc = wave_incl_scan_dpp(tot);           // every wave scans the 64 owners of its chunk (so_ >> 6)
         if (sq_ == 0 && ln == 63) s_wsum[so_ >> 6] = inc;
         lds_barrier();
         {
-            u32 off = inc - tot4;
+            u32 off = inc - tot;
             for (u32 v = 0; v < (so_ >> 6); v++) off += s_wsum[v];
             if (sq_ == 0) {
                 s_off[so_] = off;
-                if (so_ == RT_OWNERS - 1) s_off[RT_OWNERS] = off + tot4;
-                if (s_cur[so_] + tot4 > R.cap || off + tot4 > SCAP) s_over = 1;
+                if (so_ == RT_OWNERS - 1) s_off[RT_OWNERS] = off + tot;
+                if (s_cur[so_] + s_cn[so_] + tot + CW > R.cap || off + tot > SCAP) s_over = 1;      // (+ CW: the last chunk is padded at the end)
             }
-            if (sq_ == QN - 1) for (u32 x = off + tot; x < off + tot4 && x < SCAP; x++) s_sorted[x] = RT_DUMMY;      // padding
             #pragma unroll
             for (int v = 0; v < QN; v++) off += (u32)v < sq_ ? pq[v] : 0u;
             #pragma unroll
@@ -832,32 +832,45 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
         }
         lds_barrier();
         prefetch_rows(t_nxt);         // requested here, when the seeds' registers are free again; in flight during the write-out
-        // ---- append every owner's segment to its region; wave v serves owners OPW v .. OPW v + OPW - 1, four at a time:
-        // 16 lanes per owner, 16 bytes per ln (segments and regions are multiples of four entries)
+        // ---- append to the regions in whole 64-byte chunks.  An owner's stream = what it carried over from the tiles before
+        // (fewer than CW entries, in LDS) followed by this tile's segment; the chunks that are full leave as aligned 16-byte
+        // stores, the rest is carried on.  (Round 2 appended every segment as it was, ~150 bytes at a 16-byte boundary: the
+        // lines were completed in L2 by the next tile's segment -- or left it half written; 2.41 GB reached HBM for 2.05 GB
+        // of entries.)  Wave v serves owners OPW v .. OPW v + OPW - 1, four at a time: 16 lanes per owner, four consecutive
+        // entries of the stream per lane and pass.
         {
             constexpr int NI = 2;                 // owners-of-four handled together (OPW / 4 = 4 or 8 in all)
             const u32 sub = (u32)ln & 15u, grp = (u32)ln >> 4;
-            // what two iterations need from LDS in two batches of independent reads (bounds and cursors, then the entries):
-            // one read after the other, this phase was a chain of ~20 LDS latencies
             #pragma unroll
             for (int i0 = 0; i0 < OPW / 4; i0 += NI) {
-                u32 oo[NI], sb[NI], se[NI], sc[NI];
+                u32 oo[NI], sb[NI], se[NI], sc[NI], cn[NI];
                 #pragma unroll
                 for (int i = 0; i < NI; i++) {
                     oo[i] = (u32)wave * OPW + (u32)(i0 + i) * 4 + grp;
                     asm volatile("" : "+v"(oo[i]));      // keeps the region addresses out of the loop-invariant (spilled) set
-                    sb[i] = s_off[oo[i]]; se[i] = s_off[oo[i] + 1]; sc[i] = s_cur[oo[i]];
+                    sb[i] = s_off[oo[i]]; se[i] = s_off[oo[i] + 1]; sc[i] = s_cur[oo[i]]; cn[i] = s_cn[oo[i]];
                 }
-                tie_all<NI>(sb); tie_all<NI>(se); tie_all<NI>(sc);
-                v4u dv[NI];
-                #pragma unroll
-                for (int i = 0; i < NI; i++) { const u32 j = sb[i] + sub * 4; dv[i] = *reinterpret_cast<const v4u*>(&s_sorted[j < se[i] ? j : 0u]); }
+                tie_all<NI>(sb); tie_all<NI>(se); tie_all<NI>(sc); tie_all<NI>(cn);
                 #pragma unroll
                 for (int i = 0; i < NI; i++) {
+                    const u32 T = cn[i] + (se[i] - sb[i]), out = T & ~(CW - 1u);
                     auto dst = reinterpret_cast<v4u GLOBAL_AS*>(R.arena.g() + (((u64)oo[i] * P + p) * R.cap + sc[i]));
-                    if (sb[i] + sub * 4 < se[i]) dst[sub] = dv[i];
-                    for (u32 j = sb[i] + sub * 4 + 64; j < se[i]; j += 64) dst[(j - sb[i]) >> 2] = *reinterpret_cast<const v4u*>(&s_sorted[j]);      // segments beyond 64 entries: rare
-                    if (sub == 0) s_cur[oo[i]] = sc[i] + (se[i] - sb[i]);
+                    for (u32 base = sub * 4; base < T; base += 64) {      // one pass for streams up to 64 entries, seldom two
+                        u32 v[4];
+                        #pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const u32 idx = base + (u32)e;
+                            const u32* src = idx < cn[i] ? &s_carry[oo[i]][idx] : &s_sorted[sb[i] + idx - cn[i]];
+                            v[e] = idx < T ? *src : RT_DUMMY;
+                        }
+                        tie_all<4>(v);
+                        if (base < out) { v4u q4 = {v[0], v[1], v[2], v[3]}; dst[base >> 2] = q4; }      // (base and out are multiples of 4 and 16: whole or not at all)
+                        else {
+                            #pragma unroll
+                            for (int e = 0; e < 4; e++) if (base + (u32)e < T) s_carry[oo[i]][base + (u32)e - out] = v[e];
+                        }
+                    }
+                    if (sub == 0) { s_cur[oo[i]] = sc[i] + out; s_cn[oo[i]] = T - out; }
                 }
             }
         }
@@ -867,7 +880,21 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
         lds_barrier();
         tile = t_nxt; t_nxt = s_tile;      // (s_tile is next written behind the first barrier of the following iteration)
     }
-    if (tid < RT_OWNERS) R.counts[(u64)tid * P + p] = s_cur[tid];
+    if (tid < RT_OWNERS) {      // the last, partly filled chunk of every region: padded with entries that are neither a seed nor a run start
+        u32 done = s_cur[tid]; const u32 cn = s_cn[tid];
+        if (cn) {
+            auto dst = reinterpret_cast<v4u GLOBAL_AS*>(R.arena.g() + (((u64)tid * P + p) * R.cap + done));
+            #pragma unroll
+            for (int k = 0; k < (int)CW / 4; k++) {
+                v4u q4;
+                q4.x = (u32)(4 * k) < cn ? s_carry[tid][4 * k] : RT_DUMMY; q4.y = (u32)(4 * k + 1) < cn ? s_carry[tid][4 * k + 1] : RT_DUMMY;
+                q4.z = (u32)(4 * k + 2) < cn ? s_carry[tid][4 * k + 2] : RT_DUMMY; q4.w = (u32)(4 * k + 3) < cn ? s_carry[tid][4 * k + 3] : RT_DUMMY;
+                dst[k] = q4;
+            }
+            done += CW;
+        }
+        R.counts[(u64)tid * P + p] = done;
+    }
     if (tid == 0) { R.emitted[(u64)p * (R.tiles_max + 1)] = n_emit; rt_trace_end(R, p); }
 }
 
@@ -3064,7 +3091,7 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     // is +-20 %); the capacities below (list of tiles, regions) are sized for that and a workgroup stops asking at the bound
     const u64 tiles_max = (n_tiles + prod - 1) / prod * 3 / 2 + 8;
     // expected entries per (owner, tile): tile * seeds / 256 + dummies (~10 % of nw) + ~2 of padding; 25 % and a constant on top
-    u64 cap = (u64)((double)tiles_max * ((double)tile / 256.0 * (wpr - 1) + 0.15 * nw + 2.0) * 1.25) + 256; cap = (cap + 3) & ~3ull;
+    u64 cap = (u64)((double)tiles_max * ((double)tile / 256.0 * (wpr - 1) + 0.15 * nw + 2.0) * 1.25) + 256; cap = (cap + 31) & ~31ull;      // regions start on 128-byte boundaries, whole 64-byte chunks are written
     if (cap >= (1ull << 31) || tiles_max > 0xFFFFull) return fail(h, MLST_E_LIMIT, "batch too large for the routed sieve (%llu tiles per producer workgroup)", (unsigned long long)tiles_max);
     const u64 need = (u64)RT_OWNERS * prod * cap;
     if (h->cap_rt_arena < need || h->rt_prod != prod || h->rt_cap != (u32)cap) {
