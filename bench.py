@@ -201,7 +201,8 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
 
             res = type_sample(idx, st, None, database, "sample", fast=True, cache=cache, consensus_fn=consensus_fn)
         else:
-            st, chosen_dev, letters_dev = e.typing_fetch()
+            # (the streamed form fetches through its shard: a counts exchange that did not fit its buffer is repeated there)
+            st, chosen_dev, letters_dev = shards[k % depth].fetch() if (world > 1 and mode["streamed"]) else e.typing_fetch()
             t_c = time.perf_counter()
             res = type_sample(idx, st, None, database, "sample", fast=True, cache=cache, typed=(chosen_dev, letters_dev))
         t_d = time.perf_counter()
@@ -333,7 +334,11 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
             "blocks": len(blocks), "block_ms": [round(b[0] * 1e3, 3) for b in blocks], "timed_s": round(total, 3),
             "host_ms_per_step": {k: round(v / args.steps, 4) for k, v in hm.items()}, "serial_ms_per_step": serial_ms,
             "iso_launch_ms": iso_launch, "iso_launch_spread": spread, "stats": stats, "st_call": st_call, "typed_ok": typed_ok, "batches_checked": len(calls),
-            "collectives": ("streamed on a torch stream" if mode["streamed"] else "host-driven") if world > 1 else None}
+            "collectives": ("streamed on a torch stream" if mode["streamed"] else "host-driven") if world > 1 else None,
+            "exchange": ({"statistics_bytes": int(shards[0].t_all.numel()) * 8, "counts_layout": "compact" if shards[0].compact else "fixed",
+                          "counts_bytes": int(shards[0].cap_cols) * 16, "counts_bytes_fixed_layout": int(shards[0].total_cols) * 16,
+                          "counts_columns_needed": (shards[0].needs[-1] if shards[0].needs else None),
+                          "steps_repeated_for_capacity": sum(sh.repeats for sh in shards)} if (world > 1 and mode["streamed"]) else None)}
 
 
 def load_profile_json(name):
@@ -535,7 +540,7 @@ def summarize(w, res, eng, world, depth):
     stats = res["stats"]
     return {"workload": w.label, "reads_per_gpu": w.n_reads, "n_alleles": int(w.idx.n_alleles), "n_loci": int(w.idx.n_loci),
             "sieve": eng.sieve_info(), "parallelism": "reads sharded x%d" % world, "pipeline_depth": depth, "distinct_resident_batches": len(w.batches),
-            "collectives": res["collectives"], "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (w.wpr * 4, w.qstride)}
+            "collectives": res["collectives"], "exchange_per_step": res.get("exchange"), "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (w.wpr * 4, w.qstride)}
 
 
 def main():

@@ -240,6 +240,19 @@ int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char n
  * consensus over d_counts + the copies to the host. */
 int mlst_typing_choose_pileup(mlst_handle* h, int32_t penalty, uint32_t* d_counts);
 int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_char, const uint32_t* d_counts);
+/* The same halves with the counts in a COMPACT layout, for the all-reduce in between: only the loci with a chosen
+ * allele get a slot (of the locus' longest allele), in locus order -- every rank holds the same statistics after the
+ * first exchange, chooses the same alleles and so derives the same layout.  d_counts: device, cap_cols * 4 uint32,
+ * zeroed by the call.  The capacity is fixed by the caller before the need is known (the size of a collective is a
+ * host decision): mlst_typing_compact_info, after mlst_typing_fetch, returns the columns needed and whether they
+ * fitted.  If they did not, nothing was piled up, no letter of that fetch is valid, and the caller repeats both halves
+ * with at least need_cols columns (mlst_typing_layout's total always suffices); statistics and choice are unaffected.
+ * mlst_typing_fetch returns the letters in the fixed layout of mlst_typing_layout either way.  (No reference
+ * counterpart: the reference is one process; what is exchanged are the counts behind cmseq's consensus,
+ * metaMLST_functions.py:255-259.) */
+int mlst_typing_choose_pileup_compact(mlst_handle* h, int32_t penalty, uint32_t* d_counts, uint64_t cap_cols);
+int mlst_typing_finish_compact(mlst_handle* h, uint32_t mincov, char none_char, const uint32_t* d_counts);
+int mlst_typing_compact_info(mlst_handle* h, uint64_t* need_cols, uint32_t* overflow);
 int mlst_typing_fetch(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_read_len_sum,
                       uint64_t* locus_first_read, uint64_t* counters, int32_t* chosen, uint8_t* letters);
 /* round(float(p) / float(q), 1) of Python as an exact integer number of tenths (host function, the same code

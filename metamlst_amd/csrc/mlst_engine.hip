@@ -2321,6 +2321,55 @@ __global__ __launch_bounds__(256) void k_consensus(const u32* __restrict__ count
     }
 }
 
+// ---- compact column layout for the multi-GPU exchange of the pileup counts (mlst_typing_choose_pileup_compact).
+// After the first exchange every rank holds the same statistics and chooses the same alleles, so every rank derives the
+// same layout: the loci WITH a chosen allele get their slots (of the locus' longest allele, as in the fixed layout) one
+// after the other; on cfg3 that is 140 of 1,050 loci, 1.1 MB of counts to all-reduce instead of 8.4 MB.  The caller fixes
+// the capacity before it knows the need (a collective's size is a host decision): when the slots do not fit, nothing is
+// piled up (chosen_pl = -1 everywhere), info says so and the caller repeats the phase with a larger buffer.
+// One block; info[0] = columns needed, info[1] = 1 when they exceed cap_cols.
+__global__ __launch_bounds__(1024) void k_layout_compact(const int* __restrict__ chosen, const u64* __restrict__ fixed_colbase, u32 n_loci, u64 cap_cols,
+                                                         u64* __restrict__ colbase_c, int* __restrict__ chosen_pl, u64* __restrict__ info) {
+    __shared__ u32 s_w[16]; __shared__ u64 s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (u32 l0 = 0; l0 < n_loci; l0 += 1024) {
+        const u32 l = l0 + (u32)tid;
+        const u32 w = (l < n_loci && chosen[l] >= 0) ? (u32)(fixed_colbase[l + 1] - fixed_colbase[l]) : 0u;
+        u32 inc = w;
+        for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        u32 before = 0, all = 0;
+        for (int v = 0; v < 16; v++) { const u32 t = s_w[v]; if (v < wv) before += t; all += t; }
+        const u64 run = s_run;
+        if (l < n_loci) colbase_c[l] = run + before + inc - w;
+        __syncthreads();
+        if (tid == 0) s_run = run + all;
+        __syncthreads();
+    }
+    const u64 need = s_run; const bool over = need > cap_cols;
+    for (u32 l = (u32)tid; l < n_loci; l += 1024) chosen_pl[l] = over ? -1 : chosen[l];
+    if (tid == 0) { info[0] = need; info[1] = over ? 1ull : 0ull; }
+}
+// majority letters of the compact counts, written in the FIXED layout mlst_typing_fetch hands out (one block per locus);
+// a locus without a slot gets what k_consensus makes of zero counts
+__global__ __launch_bounds__(256) void k_consensus_expand(const u32* __restrict__ counts, const int* __restrict__ chosen_pl, const u64* __restrict__ colbase_c,
+                                                          const u64* __restrict__ fixed_colbase, u32 mincov, u8 none_char, u8* __restrict__ out) {
+    const u32 l = blockIdx.x; const u64 fb = fixed_colbase[l], w = fixed_colbase[l + 1] - fb, cb = colbase_c[l];
+    const bool have = chosen_pl[l] >= 0;
+    for (u64 c = threadIdx.x; c < w; c += 256) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (have) v = reinterpret_cast<const uint4*>(counts)[cb + c];
+        u32 best = v.x; u8 ch = 'A';
+        if (v.y > best) { best = v.y; ch = 'C'; }
+        if (v.z > best) { best = v.z; ch = 'G'; }
+        if (v.w > best) { best = v.w; ch = 'T'; }
+        out[fb + c] = (v.x + v.y + v.z + v.w) >= mincov ? ch : none_char;
+    }
+}
+
 // ------------------------------------------------------------------ pileup of ready-made alignments (SAM / BAM input)
 // One thread per record: CIGAR walk over the chosen contig's columns.  A base counts when the record's true tags pass
 // AS >= minscore and XM <= max_xm (cmseq BAM_tagFilter), its Phred is >= minqual and it is A/C/G/T
@@ -2499,6 +2548,7 @@ struct mlst_handle {
     // device-side typing (mlst_typing_enqueue / mlst_typing_fetch): fixed column layout, one slot of loc_maxlen columns per locus
     int* d_allele_no = nullptr; int* d_auto_chosen = nullptr; u64* d_fixed_colbase = nullptr; std::vector<u64> fixed_colbase; u64 fixed_cols = 0;
     u32* d_auto_counts = nullptr; u8* d_auto_letters = nullptr; u8* h_auto = nullptr; bool auto_pending = false;
+    u64* d_compact_colbase = nullptr; int* d_compact_chosen = nullptr; u64* d_compact_info = nullptr; u64 off_compact_info = 0; bool compact_pending = false;      // mlst_typing_choose_pileup_compact
     // host-to-device copies of the FASTQ entries: a copy stream, two text buffers used in turn, the event that says a
     // buffer's last chunk has been packed (h2d_overlapped)
     hipStream_t copy_stream = nullptr; hipEvent_t stage_done = nullptr;
@@ -2624,6 +2674,7 @@ static void free_ref(mlst_handle* h) {
     hipFree(h->d_ascii); hipFree(h->d_aoff);
     hipFree(h->d_rfilter); h->d_rfilter = nullptr;
     hipFree(h->d_allele_no); hipFree(h->d_auto_chosen); hipFree(h->d_fixed_colbase); hipFree(h->d_auto_counts); hipFree(h->d_auto_letters);
+    hipFree(h->d_compact_colbase); hipFree(h->d_compact_chosen); hipFree(h->d_compact_info); h->d_compact_colbase = nullptr; h->d_compact_chosen = nullptr; h->d_compact_info = nullptr;
     if (h->h_auto) { hipHostFree(h->h_auto); h->h_auto = nullptr; }
     h->d_allele_no = h->d_auto_chosen = nullptr; h->d_fixed_colbase = nullptr; h->d_auto_counts = nullptr; h->d_auto_letters = nullptr; h->auto_pending = false;
     h->d_arena = h->d_planes = h->d_nmask = nullptr; h->d_allele_len = nullptr; h->d_allele_locus = nullptr; h->d_loci = nullptr; h->d_sieve = nullptr;
@@ -2987,7 +3038,9 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         HIPCHK(h, dmalloc(&h->d_fixed_colbase, (u64)n_loci + 1)); HIPCHK(h, hipMemcpy(h->d_fixed_colbase, h->fixed_colbase.data(), ((u64)n_loci + 1) * 8, hipMemcpyHostToDevice));
         HIPCHK(h, dmalloc(&h->d_auto_chosen, (u64)n_loci));
         HIPCHK(h, dmalloc(&h->d_auto_counts, h->fixed_cols * 4 + 4)); HIPCHK(h, dmalloc(&h->d_auto_letters, h->fixed_cols + 16));
-        HIPCHK(h, hipHostMalloc((void**)&h->h_auto, (u64)n_loci * 4 + h->fixed_cols + 64, hipHostMallocDefault));
+        h->off_compact_info = (((u64)n_loci * 4 + 15) & ~15ull) + ((h->fixed_cols + 15) & ~15ull);
+        HIPCHK(h, hipHostMalloc((void**)&h->h_auto, h->off_compact_info + 64, hipHostMallocDefault));
+        HIPCHK(h, dmalloc(&h->d_compact_colbase, (u64)n_loci + 1)); HIPCHK(h, dmalloc(&h->d_compact_chosen, (u64)n_loci + 1)); HIPCHK(h, dmalloc(&h->d_compact_info, 2));
     }
     // ---- sample state
     EngineDev& E = h->E;
@@ -3768,6 +3821,45 @@ extern "C" int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_cha
     hipSetDevice(h->device);
     int rc = typing_finish_kernels(h, mincov, none_char, d_counts);
     return rc ? rc : typing_finish_copies(h);
+}
+// The same two halves with the counts in the compact layout of k_layout_compact (what a multi-GPU caller all-reduces
+// between them): d_counts holds cap_cols * 4 uint32.  mlst_typing_compact_info, after mlst_typing_fetch, says how many
+// columns were needed and whether they fitted; if not, no letter of the fetch is valid and the caller runs both halves
+// again with a buffer of at least that many columns (statistics and choice are not touched by the repeat).
+extern "C" int mlst_typing_choose_pileup_compact(mlst_handle* h, int32_t penalty, uint32_t* d_counts, uint64_t cap_cols) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (!d_counts || cap_cols == 0) return fail(h, MLST_E_INVALID, "mlst_typing_choose_pileup_compact needs a counts buffer");
+    hipSetDevice(h->device);
+    const u64 nl = h->n_loci;
+    if (nl) hipLaunchKernelGGL(k_choose, dim3((unsigned)nl), dim3(256), 0, h->stream, h->d_E, h->d_allele_no, (int)penalty, h->d_auto_chosen);
+    hipLaunchKernelGGL(k_layout_compact, dim3(1), dim3(1024), 0, h->stream, h->d_auto_chosen, h->d_fixed_colbase, (u32)nl, (u64)cap_cols,
+                       h->d_compact_colbase, h->d_compact_chosen, h->d_compact_info);
+    zero_words(h, d_counts, cap_cols * 4);
+    zero_words(h, &h->E.ctr.p->n_pl_dp, 2);
+    { Prof pf(h, 5);
+      launch_pileup(h, h->d_compact_chosen, h->d_compact_colbase, d_counts);
+      hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_compact_chosen, h->d_compact_colbase, d_counts, h->d_pl_list, h->d_tb); }
+    HIPCHK(h, hipGetLastError());
+    return MLST_OK;
+}
+extern "C" int mlst_typing_finish_compact(mlst_handle* h, uint32_t mincov, char none_char, const uint32_t* d_counts) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (!d_counts) return fail(h, MLST_E_INVALID, "mlst_typing_finish_compact needs the counts buffer");
+    hipSetDevice(h->device);
+    if (h->n_loci) hipLaunchKernelGGL(k_consensus_expand, dim3((unsigned)h->n_loci), dim3(256), 0, h->stream, d_counts, h->d_compact_chosen, h->d_compact_colbase,
+                                      h->d_fixed_colbase, mincov, (u8)none_char, h->d_auto_letters);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->h_auto + h->off_compact_info, h->d_compact_info, 16, hipMemcpyDeviceToHost, h->stream));
+    h->compact_pending = true;
+    return typing_finish_copies(h);
+}
+extern "C" int mlst_typing_compact_info(mlst_handle* h, uint64_t* need_cols, uint32_t* overflow) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (!h->compact_pending || h->auto_pending) return fail(h, MLST_E_INVALID, "mlst_typing_compact_info follows mlst_typing_finish_compact and mlst_typing_fetch");
+    const u64* info = (const u64*)(h->h_auto + h->off_compact_info);
+    if (need_cols) *need_cols = info[0];
+    if (overflow) *overflow = (uint32_t)info[1];
+    return MLST_OK;
 }
 extern "C" int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");

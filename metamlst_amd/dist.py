@@ -5,6 +5,8 @@ two small all-reduces make the result independent of the GPU count:
   1. after pass 1:  SUM over ranks of {sum_score, n_hits, locus_read_len_sum, counters},
                     MIN over ranks of locus_first_read          -> every rank picks the same alleles
   2. after pass 2:  SUM of the pileup counts                    -> rank 0 runs the host tail
+                    (columns of the chosen alleles only: the host-driven form lays them out on the host, the
+                    streamed form on the device -- StreamedShard)
 
 torch.distributed does the plumbing: backend "nccl" (= RCCL over xGMI) on device tensors that
 the engine fills / reads through mlst_export_stats_device / mlst_import_stats_device, or
@@ -12,6 +14,8 @@ the engine fills / reads through mlst_export_stats_device / mlst_import_stats_de
 The reference has no counterpart (single process); the integer sums make 1 vs N GPUs bit identical.
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import torch
@@ -126,9 +130,19 @@ class StreamedShard:
     the two all-reduces (RCCL orders a collective against the current stream), import, allele choice + pileup, the
     all-reduce of the pileup counts, consensus and the copies to the host.  The host synchronises once per step, in
     fetch().  The engine library and torch share one HIP runtime in the process (the library binds to the
-    libamdhip64.so.7 torch has already loaded), so the engine can run on a torch stream (mlst_set_stream)."""
+    libamdhip64.so.7 torch has already loaded), so the engine can run on a torch stream (mlst_set_stream).
 
-    def __init__(self, engine, device: torch.device, group=None, force_collectives: bool = False):
+    The pileup counts travel in the COMPACT layout of mlst_typing_choose_pileup_compact: slots only for the loci with a
+    chosen allele (after the first exchange every rank chooses the same alleles, so every rank derives the same layout on
+    its device; cfg3: 140 of 1,050 loci, 1.1 MB instead of 8.4 MB per step).  The size of a collective is a host decision
+    taken before the device knows the need, so the capacity comes from the steps before (the first step takes the full
+    layout; then 1.5 x the largest need of the last eight steps, the same number on every rank because the need is a
+    function of the global choice).  A step that does not fit says so in fetch(): every rank then repeats the step's
+    second half with the full layout -- results are those of the fixed layout either way."""
+
+    HISTORY = 8
+
+    def __init__(self, engine, device: torch.device, group=None, force_collectives: bool = False, compact: bool | None = None):
         self.engine, self.device, self.group = engine, device, group
         self.force = force_collectives           # tests: issue the collectives even in a group of one
         self.stream = torch.cuda.Stream(device=device)
@@ -143,14 +157,37 @@ class StreamedShard:
         self.t_sum = self.t_all[:max(1, n_sum)]
         self.t_slots = self.t_all[max(1, n_sum):].view(self.world, self.n_min)
         self.t_min = torch.zeros(self.n_min, dtype=torch.int64, device=device)
-        self.t_counts = torch.zeros(max(1, engine.typing_total_cols()) * 4, dtype=torch.int32, device=device)
+        self.total_cols = max(1, engine.typing_total_cols())
+        self.t_counts = torch.zeros(self.total_cols * 4, dtype=torch.int32, device=device)
+        if compact is None:
+            compact = os.environ.get("MLST_COMPACT_EXCHANGE", "1") != "0"
+        self.compact = compact
+        self.cap_cols = self.total_cols          # columns of the next step's counts exchange
+        self.needs: list[int] = []               # columns the last steps needed
+        self.repeats = 0                         # steps whose second half ran twice (capacity too small)
+        self._last = None
         torch.cuda.synchronize(device)
         engine.set_stream(self.stream.cuda_stream)
+
+    def _multi(self) -> bool:
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
+
+    def _second_half(self, penalty: int, mincov: int, multi: bool):
+        e = self.engine
+        if multi and self.compact:
+            e.typing_choose_pileup_compact(penalty, self.t_counts.data_ptr(), self.cap_cols)
+            dist.all_reduce(self.t_counts[:self.cap_cols * 4], op=dist.ReduceOp.SUM, group=self.group)
+            e.typing_finish_compact(mincov, "N", self.t_counts.data_ptr())
+        else:
+            e.typing_choose_pileup(penalty, self.t_counts.data_ptr())
+            if multi:
+                dist.all_reduce(self.t_counts, op=dist.ReduceOp.SUM, group=self.group)
+            e.typing_finish(mincov, "N", self.t_counts.data_ptr())
 
     def enqueue(self, submit_fn, penalty: int = 100, mincov: int = 1):
         """submit_fn() queues pass 1 on the engine (reset_sample + submit_*); everything else follows here."""
         e = self.engine
-        multi = dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)
+        multi = self._multi()
         with torch.cuda.stream(self.stream):
             submit_fn()
             if multi:
@@ -158,14 +195,32 @@ class StreamedShard:
                 e.export_stats_device_async(self.t_sum.data_ptr(), self.t_slots[self.rank].data_ptr())
                 allreduce_sum_with_min_slots(self.t_all, max(1, self.n_sum), self.n_min, self.t_min, self.group)
                 e.import_stats_device_async(self.t_sum.data_ptr(), self.t_min.data_ptr())
-            e.typing_choose_pileup(penalty, self.t_counts.data_ptr())
-            if multi:
-                dist.all_reduce(self.t_counts, op=dist.ReduceOp.SUM, group=self.group)
-            e.typing_finish(mincov, "N", self.t_counts.data_ptr())
+            self._second_half(penalty, mincov, multi)
+        self._last = (penalty, mincov, multi)
+
+    def next_capacity(self, need: int) -> int:
+        """Capacity of the next counts exchange, from the needs seen: 1.5 x the largest of the last HISTORY steps, in
+        steps of 1,024 columns, at most the fixed layout."""
+        self.needs = (self.needs + [int(need)])[-self.HISTORY:]
+        want = (max(self.needs) * 3 // 2 + 2047) // 1024 * 1024
+        return max(1024, min(self.total_cols, want))
 
     def fetch(self):
         """-> (SampleStats, {locus: chosen allele idx}, {allele idx: consensus bytes}); whole-job values on every rank."""
-        return self.engine.typing_fetch()
+        res = self.engine.typing_fetch()
+        penalty, mincov, multi = self._last
+        if multi and self.compact:
+            need, over = self.engine.typing_compact_info()
+            if over:                             # every rank sees the same flag: all of them repeat, in the same order
+                self.repeats += 1
+                self.cap_cols = self.total_cols
+                with torch.cuda.stream(self.stream):
+                    self._second_half(penalty, mincov, multi)
+                res = self.engine.typing_fetch()
+                need, over = self.engine.typing_compact_info()
+                assert not over
+            self.cap_cols = self.next_capacity(need)
+        return res
 
     def close(self):
         self.engine.set_stream(0)

@@ -107,6 +107,9 @@ def load_library(path: str | None = None):
         "mlst_typing_enqueue": (C.c_int, [H, C.c_int32, C.c_uint32, C.c_char]),
         "mlst_typing_choose_pileup": (C.c_int, [H, C.c_int32, u32p]),
         "mlst_typing_finish": (C.c_int, [H, C.c_uint32, C.c_char, u32p]),
+        "mlst_typing_choose_pileup_compact": (C.c_int, [H, C.c_int32, u32p, C.c_uint64]),
+        "mlst_typing_finish_compact": (C.c_int, [H, C.c_uint32, C.c_char, u32p]),
+        "mlst_typing_compact_info": (C.c_int, [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "mlst_set_stream": (C.c_int, [H, C.c_void_p]),
         "mlst_export_stats_device_async": (C.c_int, [H, i64p, i64p]),
         "mlst_import_stats_device_async": (C.c_int, [H, i64p, i64p]),
@@ -333,6 +336,19 @@ class Engine:
 
     def typing_finish(self, mincov: int = 1, none_char: str = "N", d_counts: int = 0):
         self._check(self.lib.mlst_typing_finish(self._h, int(mincov), none_char.encode(), d_counts or None), "mlst_typing_finish")
+
+    def typing_choose_pileup_compact(self, penalty: int, d_counts: int, cap_cols: int):
+        """Allele choice + pileup into the compact layout (loci with a chosen allele only) of a buffer of cap_cols columns."""
+        self._check(self.lib.mlst_typing_choose_pileup_compact(self._h, int(penalty), d_counts, int(cap_cols)), "mlst_typing_choose_pileup_compact")
+
+    def typing_finish_compact(self, mincov: int, none_char: str, d_counts: int):
+        self._check(self.lib.mlst_typing_finish_compact(self._h, int(mincov), none_char.encode(), d_counts), "mlst_typing_finish_compact")
+
+    def typing_compact_info(self) -> tuple[int, bool]:
+        """After typing_fetch: (columns the compact layout needed, True when they did not fit the buffer)."""
+        need, over = C.c_uint64(), C.c_uint32()
+        self._check(self.lib.mlst_typing_compact_info(self._h, C.byref(need), C.byref(over)), "mlst_typing_compact_info")
+        return int(need.value), bool(over.value)
 
     def typing_total_cols(self) -> int:
         tot = C.c_uint64()

@@ -207,3 +207,7 @@ def test_bench_five_ranks_on_one_gpu_reports_the_world():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 5 and line["world_size_reported_by_backend"] == 5
     assert line["concordance"]["st_match"] and line["value"] > 0 and line["scaling"] == "weak"
+    # the streamed exchange: pileup counts of the loci with a chosen allele only (4 of 12 species have a genome in the sample)
+    ex = line["config"]["exchange_per_step"]
+    assert line["config"]["collectives"].startswith("streamed") and ex["counts_layout"] == "compact"
+    assert ex["counts_columns_needed"] * 16 <= ex["counts_bytes"] < ex["counts_bytes_fixed_layout"] and ex["steps_repeated_for_capacity"] == 0

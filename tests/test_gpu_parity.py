@@ -512,12 +512,27 @@ def test_streamed_shard_step_on_a_torch_stream():
         eng = Engine(0)
         eng.load_reference(idx)
         sh = StreamedShard(eng, torch.device("cuda", 0), force_collectives=True)
-        for _ in range(3):                       # reuse across samples, as the bench loop does
+        assert sh.compact and sh.cap_cols == sh.total_cols      # the first step exchanges the fixed layout's size
+        need = sum(int(idx.locus_maxlen[l]) for l in want)       # slots of the loci with a chosen allele
+        caps = []
+        for k in range(4):                       # reuse across samples, as the bench loop does
+            if k == 3:
+                sh.cap_cols = 1024               # too small for the seven loci: the second half runs again with the full layout
+            caps.append(sh.cap_cols)
             sh.enqueue(lambda: (eng.reset_sample(), eng.submit_reads(fb, fq, off)))
             st, chosen, letters = sh.fetch()
             fx.assert_stats_equal(st, s0)
             assert chosen == want
             assert {a: bytes(v) for a, v in letters.items()} == {a: bytes(v) for a, v in cons.items()}
+            assert sh.needs[-1] == need
+        assert caps[1] == caps[2] == max(1024, min(sh.total_cols, (need * 3 // 2 + 2047) // 1024 * 1024)) and sh.repeats == 1
+        sh.close()
+        # the fixed-layout exchange stays available (MLST_COMPACT_EXCHANGE=0)
+        sh = StreamedShard(eng, torch.device("cuda", 0), force_collectives=True, compact=False)
+        sh.enqueue(lambda: (eng.reset_sample(), eng.submit_reads(fb, fq, off)))
+        st, chosen, letters = sh.fetch()
+        fx.assert_stats_equal(st, s0)
+        assert chosen == want and {a: bytes(v) for a, v in letters.items()} == {a: bytes(v) for a, v in cons.items()}
         sh.close()
     finally:
         if created:
