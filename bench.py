@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--host-profile", default=None, help="diagnostics: cProfile of the host loop over 200 extra (untimed) steps, written to this file")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="timed blocks of --steps steps are repeated until this much has been timed")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"], help="workload of the headline line")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU and batch (default: 50 M for cfg3, 10 M for cfg2)")
@@ -316,6 +317,20 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
         total += dt
         if len(blocks) >= 200:
             break
+    if args.host_profile and rank == 0 and world == 1:      # where the host thread spends a step (untimed, after the timed blocks)
+        import cProfile
+        import io
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        run(200)
+        pr.disable()
+        fence()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("cumulative").print_stats(60)
+        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(40)
+        with open(args.host_profile, "w") as fh:
+            fh.write(buf.getvalue())
     if shards:
         for s_ in shards:
             s_.close()
