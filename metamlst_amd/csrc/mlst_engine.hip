@@ -1062,20 +1062,31 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
 }
 
 // candidate flags -> candidate list (one atomic per 1024-thread workgroup that holds candidates)
-__global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ flags, u64 n_reads, u32* __restrict__ cand, Counters* __restrict__ ctr, int paired) {
+#define FLAG_U 8      /* flag words per thread and turn of k_flag_compact */
+__global__ __launch_bounds__(1024) void k_flag_compact(u32* __restrict__ flags, u64 n_reads, u32* __restrict__ cand, Counters* __restrict__ ctr, int paired) {
     __shared__ u32 s_cnt[16]; __shared__ u64 s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u64 n_words = (n_reads + 31) >> 5;
     if (blockIdx.x == 0 && tid == 0) { ctr->rt_next = 0; ctr->rt_parked = 0; }      // the producers' tile counter and the parked list, for the next submission
-    for (u64 w0 = (u64)blockIdx.x * 1024; w0 < n_words; w0 += (u64)gridDim.x * 1024) {
-        const u64 wi = w0 + tid;
-        u32 f = wi < n_words ? flags[wi] : 0u;
-        if (paired) {      // mates become candidates together (see sv_emit); the last word is clipped to the reads that exist
-            f |= ((f & 0xAAAAAAAAu) >> 1) | ((f & 0x55555555u) << 1);
-            const u64 first = wi * 32;
-            if (first + 32 > n_reads) f &= first < n_reads ? ((1u << (n_reads - first)) - 1u) : 0u;
+    // FLAG_U words per thread, loaded together: one scan and one returning atomic per 8,192 words (a word per thread and turn
+    // was six turns per workgroup on cfg3, each a load, two barriers and an atomic one after the other: 22 us)
+    for (u64 w0 = (u64)blockIdx.x * (1024 * FLAG_U); w0 < n_words; w0 += (u64)gridDim.x * (1024 * FLAG_U)) {
+        u32 f[FLAG_U]; u32 c = 0;
+        #pragma unroll
+        for (int k = 0; k < FLAG_U; k++) {      // (a word that held flags is left zero for the next submission: no fill of the 6 MB in between)
+            const u64 wi = w0 + (u64)k * 1024 + tid; f[k] = wi < n_words ? flags[wi] : 0u;
+            if (f[k]) flags[wi] = 0u;
         }
-        u32 c = (u32)__popc(f), tot;
+        #pragma unroll
+        for (int k = 0; k < FLAG_U; k++) {
+            if (paired) {      // mates become candidates together (see sv_emit); the last word is clipped to the reads that exist
+                const u64 first = (w0 + (u64)k * 1024 + tid) * 32;
+                f[k] |= ((f[k] & 0xAAAAAAAAu) >> 1) | ((f[k] & 0x55555555u) << 1);
+                if (first + 32 > n_reads) f[k] &= first < n_reads ? ((1u << (n_reads - first)) - 1u) : 0u;
+            }
+            c += (u32)__popc(f[k]);
+        }
+        u32 tot;
         const u32 pre = wave_excl_scan_u32(c, tot);
         if (lane == 0) s_cnt[wv] = tot;
         __syncthreads();
@@ -1084,8 +1095,12 @@ __global__ __launch_bounds__(1024) void k_flag_compact(const u32* __restrict__ f
         if (all) {
             if (tid == 0) s_base = atomicAdd(&ctr->n_cand, (u64)all);
             __syncthreads();
-            u64 at = s_base + before + pre; u32 m = f;
-            while (m) { int b = __ffs(m) - 1; m &= m - 1; cand[at++] = (u32)(wi * 32 + b); }
+            u64 at = s_base + before + pre;
+            #pragma unroll
+            for (int k = 0; k < FLAG_U; k++) {
+                u32 m = f[k]; const u64 r0 = (w0 + (u64)k * 1024 + tid) * 32;
+                while (m) { int b = __ffs(m) - 1; m &= m - 1; cand[at++] = (u32)(r0 + b); }
+            }
         }
         __syncthreads();
     }
@@ -1232,6 +1247,7 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
     // on every access of the vote loops); one word of padding per lane makes the stride odd
     // (the per-(locus, strand) items are compacted in place over the bins: slot ni <= k is free by the time bin k is read)
     __shared__ u32 s_bins[256][MLST_MAX_CAND * 3 + 1];
+    __shared__ u32 s_tot[4][3]; __shared__ u64 s_base[3];
     const int tid = threadIdx.x, lane = tid & 63;
     u64 n_cand = E.ctr->n_cand;
     for (u64 c0 = (u64)blockIdx.x * 256; c0 < n_cand; c0 += (u64)gridDim.x * 256) {
@@ -1317,20 +1333,42 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             }
             for (int u = 0; u < ni; u++) if (items[u].votes >= MLST_MIN_VOTES) items[no++] = items[u];
         }
-        // retain the read.  Counters are bumped once per wave (ballot / prefix sums), not once per lane:
-        // a contended word serves only ~88 returning atomics per microsecond.
+        // retain the read.  The three counters (retained reads, items, result rows) are bumped once per WORKGROUP and
+        // turn: a contended word serves only ~88 returning atomics per microsecond, and once per wave they were 3 x 4,096
+        // of them -- most of the ~55 us this part of the kernel took on cfg3.  Two rounds: a read that finds no room
+        // in the retained arena must not reserve item slots (nothing would fill them).
         u64 keep = __ballot(no > 0);
-        u64 slot = ~0ull;
-        if (keep) {
-            int leader = __ffsll((long long)keep) - 1;
-            u64 base = 0;
-            if (lane == leader) base = atomicAdd(&E.ctr->n_ret, (u64)__popcll(keep));
-            base = __shfl(base, leader);
-            if (no > 0) {
-                slot = base + __popcll(keep & ((1ull << lane) - 1));
-                if (slot >= E.cap_ret) { atomicOr(&E.ctr->err, 1ull); slot = ~0ull; no = 0; }
-            }
+        if (lane == 0) s_tot[tid >> 6][0] = (u32)__popcll(keep);
+        __syncthreads();
+        if (tid == 0) {
+            const u32 t0 = s_tot[0][0] + s_tot[1][0] + s_tot[2][0] + s_tot[3][0];
+            s_base[0] = t0 ? atomicAdd(&E.ctr->n_ret, (u64)t0) : 0ull;
         }
+        __syncthreads();
+        u64 slot = ~0ull;
+        if (no > 0) {
+            u64 ret0 = s_base[0];
+            for (int w = 0; w < (tid >> 6); w++) ret0 += s_tot[w][0];
+            slot = ret0 + __popcll(keep & ((1ull << lane) - 1));
+            if (slot >= E.cap_ret) { atomicOr(&E.ctr->err, 1ull); slot = ~0ull; no = 0; }
+        }
+        u32 my_res = 0;
+        for (int u = 0; u < no; u++) my_res += E.loci[items[u].locus].n_pad;
+        u32 tot_items, tot_res;
+        const u32 pre_items = wave_excl_scan_u32((u32)no, tot_items);
+        const u32 pre_res = wave_excl_scan_u32(my_res, tot_res);
+        if (lane == 0) { s_tot[tid >> 6][1] = tot_items; s_tot[tid >> 6][2] = tot_res; }
+        __syncthreads();
+        if (tid == 0) {
+            u32 t1 = 0, t2 = 0;
+            for (int w = 0; w < 4; w++) { t1 += s_tot[w][1]; t2 += s_tot[w][2]; }
+            u64 b1 = 0, b2 = 0;
+            if (t1) { b1 = atomicAdd(&E.ctr->n_items, (u64)t1); b2 = atomicAdd(&E.ctr->n_res, (u64)t2); }
+            s_base[1] = b1; s_base[2] = b2;
+        }
+        __syncthreads();
+        u64 ib0 = s_base[1], ro0 = s_base[2];
+        for (int w = 0; w < (tid >> 6); w++) { ib0 += s_tot[w][1]; ro0 += s_tot[w][2]; }
         // the 400-byte copy of each kept read is left to k_retain (one half-block per read, all reads in parallel);
         // doing it here, read after read inside the wave, was the longest chain of this kernel
         if (no > 0) { E.ret_len[slot] = (u16)lw; E.ret_ridx[slot] = read_base + r; E.ret_nrec[slot] = 0; }
@@ -1340,17 +1378,7 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             const u32 other_r = (u32)__shfl_xor((int)r, 1); const u64 other_slot = (u64)__shfl_xor((long long)slot, 1); const bool other_in = __shfl_xor((int)(c < n_cand), 1) != 0;
             if (other_in && (other_r ^ 1u) == r && other_slot != ~0ull) mate_slot = (u32)other_slot;
         }
-        // item slots and result rows: wave prefix sums, one atomic per counter per wave
-        u32 my_res = 0;
-        for (int u = 0; u < no; u++) my_res += E.loci[items[u].locus].n_pad;
-        u32 tot_items, tot_res;
-        u32 pre_items = wave_excl_scan_u32((u32)no, tot_items);
-        u32 pre_res = wave_excl_scan_u32(my_res, tot_res);
-        u64 ib0 = 0, ro0 = 0;
-        if (tot_items) {
-            if (lane == 0) { ib0 = atomicAdd(&E.ctr->n_items, (u64)tot_items); ro0 = atomicAdd(&E.ctr->n_res, (u64)tot_res); }
-            ib0 = __shfl(ib0, 0); ro0 = __shfl(ro0, 0);
-        }
+        // item slots and result rows (reserved above)
         u64 ib = ib0 + pre_items, ro = ro0 + pre_res;
         if (no > 0) { E.ret_mate[slot] = mate_slot; E.ret_item0[slot] = (u32)ib; E.ret_nitems[slot] = (u8)no; }
         for (int u = 0; u < no; u++) {
@@ -2431,6 +2459,7 @@ __global__ __launch_bounds__(256) void k_choose(const EngineDev* __restrict__ Ep
     __shared__ u32 s_max[4]; __shared__ long long s_r[4]; __shared__ int s_no[4]; __shared__ int s_a[4];
     const u32 l = blockIdx.x; const LocusDev L = E.loci[l];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (l == 0 && threadIdx.x == 0) E.ctr->n_pl_dp = 0;      // the pile-up that follows starts its banded-SW list here (one launch less than a fill)
     u32 mx = 0;
     for (u32 k = threadIdx.x; k < L.n_alleles; k += 256) { u32 v = E.n_hits[L.a_begin + k]; mx = v > mx ? v : mx; }
     for (int o = 32; o > 0; o >>= 1) { u32 y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
@@ -3162,7 +3191,8 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     const u64 need_p = std::max<u64>(n_reads / 4, 1ull << 16);
     if (h->cap_rt_parked < need_p) { hipStreamSynchronize(h->stream); hipFree(h->d_rt_parked); h->d_rt_parked = nullptr; HIPCHK(h, dmalloc(&h->d_rt_parked, need_p)); h->cap_rt_parked = need_p; }
     const u64 n_flag_words = (n_reads + 31) >> 5;
-    if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words; }
+    if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words;
+                                            HIPCHK(h, hipMemset(h->d_bin_flags, 0, n_flag_words * 4)); }
     return MLST_OK;
 }
 
@@ -3197,8 +3227,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
       } else if (h->sieve_kind == MLST_SIEVE_ROUTED) {      // seeds routed to the CU that owns their filter slice (K1c)
-        const u64 n_flag_words = (n_reads + 31) >> 5;
-        zero_words(h, h->d_bin_flags, n_flag_words);
+        const u64 n_flag_words = (n_reads + 31) >> 5;      // (all zero: cleared at allocation and again by every k_flag_compact)
         RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags; R.trace = h->d_rt_trace; R.parked = h->d_rt_parked; R.parked_cap = h->cap_rt_parked;
         h->rt_last_packed = d_packed;
         R.cap = h->rt_cap; R.n_prod = h->rt_prod; R.tiles_max = h->rt_tiles_max; R.nw = h->rt_nw;
@@ -3223,7 +3252,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
         }
-        hipLaunchKernelGGL(k_flag_compact, dim3(grid_for(n_flag_words, 1024, 256)), dim3(1024), 0, h->stream, h->d_bin_flags, (u64)n_reads, h->d_cand, E.ctr, paired);
+        hipLaunchKernelGGL(k_flag_compact, dim3(grid_for((n_flag_words + FLAG_U - 1) / FLAG_U, 1024, 512)), dim3(1024), 0, h->stream, h->d_bin_flags, (u64)n_reads, h->d_cand, E.ctr, paired);
       } else {      // hashed first-level bitmap in global memory, 256-thread workgroups (MLST_SIEVE=global; databases without seeds)
         dim3 grid(grid_for((n_reads + 255) / 256, 1, h->sieve_g_blocks)), block(256);
 #define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, false>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.gbitmap.p, E.gbitmap_bits, h->d_cand, E.ctr, paired); break;
@@ -3793,7 +3822,6 @@ extern "C" int mlst_typing_choose_pileup(mlst_handle* h, int32_t penalty, uint32
     u32* cnt = d_counts ? d_counts : h->d_auto_counts;
     if (nl) hipLaunchKernelGGL(k_choose, dim3((unsigned)nl), dim3(256), 0, h->stream, h->d_E, h->d_allele_no, (int)penalty, h->d_auto_chosen);
     zero_words(h, cnt, (ncols ? ncols : 1) * 4);
-    zero_words(h, &h->E.ctr.p->n_pl_dp, 2);
     { Prof pf(h, 5);
       launch_pileup(h, h->d_auto_chosen, h->d_fixed_colbase, cnt);
       hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_auto_chosen, h->d_fixed_colbase, cnt, h->d_pl_list, h->d_tb); }
@@ -3835,7 +3863,6 @@ extern "C" int mlst_typing_choose_pileup_compact(mlst_handle* h, int32_t penalty
     hipLaunchKernelGGL(k_layout_compact, dim3(1), dim3(1024), 0, h->stream, h->d_auto_chosen, h->d_fixed_colbase, (u32)nl, (u64)cap_cols,
                        h->d_compact_colbase, h->d_compact_chosen, h->d_compact_info);
     zero_words(h, d_counts, cap_cols * 4);
-    zero_words(h, &h->E.ctr.p->n_pl_dp, 2);
     { Prof pf(h, 5);
       launch_pileup(h, h->d_compact_chosen, h->d_compact_colbase, d_counts);
       hipLaunchKernelGGL(k_pileup_dp, dim3(64), dim3(64), 0, h->stream, h->d_E, h->kp, h->d_compact_chosen, h->d_compact_colbase, d_counts, h->d_pl_list, h->d_tb); }
