@@ -951,8 +951,13 @@ __device__ inline void rt_flush(const u64* q, u32 cnt, int lane, const u32* __re
     u64 base = 0;
     if (lane == 0) base = atomicAdd(&ctr->rt_parked, (u64)cnt);
     base = uniform_u64(base);
-    if (base + cnt <= R.parked_cap) { if ((u32)lane < cnt) R.parked[base + (u32)lane] = q[lane]; }
-    else if ((u32)lane < cnt) rt_examine_one<WPR, false>(q[lane], packed, n_reads, R, NWP, sieve, smask, sshift);
+    u64 e = 0;
+    if ((u32)lane < cnt) {      // the queue holds entry | (run | region << 20) << 32: packed here, 64 at a time, not where an entry passed the filter
+        const u64 raw = q[lane]; const u32 hi = (u32)(raw >> 32), run = hi & 0xFFFFFu, p = hi >> 20;
+        e = rt_park((u32)raw, run & (NWP - 1u), NWP == 16 ? run >> 4 : run >> 3, p);
+    }
+    if (base + cnt <= R.parked_cap) { if ((u32)lane < cnt) R.parked[base + (u32)lane] = e; }
+    else if ((u32)lane < cnt) rt_examine_one<WPR, false>(e, packed, n_reads, R, NWP, sieve, smask, sshift);
 }
 // the entries that passed the LDS filter, examined at full occupancy (inside k_route_probe, whose 147 KB of LDS allow 16
 // waves per CU, the three round trips of an examination stalled the streaming waves: 0.5 of 1.2 ms at 7.7 M entries)
@@ -999,6 +1004,7 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
         n = (u32)__builtin_amdgcn_readfirstlane((int)n);
         const auto ent4 = reinterpret_cast<const v4u GLOBAL_AS*>(R.arena.g() + ((u64)owner * P + p) * R.cap);
         int seq = -1;                               // flags seen so far - 1 = sequence number of the current (tile, wave) run
+        const u32 pshift = p << 20;                 // a queued entry: entry | (run | region << 20) << 32 (runs per region < 2^20: tiles_max <= 0xFFFF, 16 runs each)
         v4u en[PF];
         #pragma unroll
         for (int u = 0; u < PF; u++) { const u32 i = (u32)u * 256 + (u32)lane * 4; en[u] = i < n ? __builtin_nontemporal_load(ent4 + (i >> 2)) : none4; }
@@ -1025,22 +1031,27 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
                     before = __builtin_amdgcn_mbcnt_hi((u32)(B[j] >> 32), __builtin_amdgcn_mbcnt_lo((u32)B[j], before));      // run starts in the lanes below
                 }
                 // the filter words of the four entries in one batch of independent LDS reads
-                u32 f0[4], f1[4], k0[4], k1[4]; bool sd[4];
+                u32 f0[4], f1[4], k0[4], k1[4];
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    sd[j] = (ev[u][j] & RT_HMASK) != RT_DUMMY;
                     u32 b0, b1; rt_filter_addr(ev[u][j] & RT_HMASK, b0, k0[j], b1, k1[j]);
-                    f0[j] = s_f[b0]; f1[j] = s_f[b1];      // (an entry without a seed reads the words of the value RT_DUMMY and fails on sd)
+                    f0[j] = s_f[b0]; f1[j] = s_f[b1];      // (an entry without a seed reads the words of the value RT_DUMMY and fails below)
                 }
                 tie_all<4>(f0); tie_all<4>(f1);
-                int run = seq + (int)before;
+                const u32 run0 = (u32)(seq + (int)before);      // the run of entry j: run0 + run starts among the lane's entries 0 .. j (worked out only where an entry passes)
                 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    run += fg[j] ? 1 : 0;
-                    const bool pass = sd[j] && (((f0[j] & k0[j]) ^ k0[j]) | ((f1[j] & k1[j]) ^ k1[j])) == 0u;
+                    // missing filter bits | "no seed" (RT_DUMMY is all ones: + 1 carries into bit 25), without a branch
+                    const u32 miss = ((f0[j] & k0[j]) ^ k0[j]) | ((f1[j] & k1[j]) ^ k1[j]) | (((ev[u][j] & RT_HMASK) + 1u) >> 25);
+                    const bool pass = miss == 0u;
                     const u64 pm = __ballot(pass);
                     if (pm) {
-                        if (pass) q[qn + (u32)__popcll(pm & lt)] = rt_park(ev[u][j], (u32)run & (NWP - 1u), NWP == 16 ? (u32)run >> 4 : (u32)run >> 3, p);
+                        if (pass) {
+                            u32 run = run0;
+                            #pragma unroll
+                            for (int jj = 0; jj <= j; jj++) run += ev[u][jj] >> 31;
+                            q[qn + (u32)__popcll(pm & lt)] = (u64)ev[u][j] | ((u64)(run | pshift) << 32);      // raw: rt_flush makes the parked form of it
+                        }
                         qn += (u32)__popcll(pm);
                         if (qn >= 64) {
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
