@@ -665,7 +665,7 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
     __shared__ __attribute__((aligned(16))) u32 s_sorted[SCAP + 4];      // + a spare word for slots without a seed
     __shared__ u32 s_part[QN][RT_OWNERS];         // entries of an owner's runs per slice of the waves
     __shared__ u32 s_off[RT_OWNERS + 1];          // start of each owner's segment in s_sorted (multiples of four)
-    __shared__ u32 s_cur[RT_OWNERS];              // entries written so far to region (owner, this workgroup): a multiple of CW
+    __shared__ u32 s_cur[RT_OWNERS];              // where region (owner, this workgroup) continues, as the number of the 64-byte chunk in the ARENA (one shift away from the address: the region's base was three 64-bit multiply-adds per owner and tile)
     __shared__ u32 s_carry[RT_OWNERS][CW];        // the entries of an owner that did not fill a chunk yet (fewer than CW), oldest first
     __shared__ u32 s_cn[RT_OWNERS];               // how many
     __shared__ u32 s_wsum[4]; __shared__ u32 s_over;
@@ -675,7 +675,8 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
     if (tid == 0) { atomicMax(&ctr->sv_t0n, ~(u64)wall_clock64()); rt_trace_begin(R, p); }
     #pragma unroll
     for (int v = 0; v < 4; v++) s_cnt[sq * 4 + v][so] = 0;
-    if (tid < RT_OWNERS) { s_cur[tid] = 0; s_cn[tid] = 0; }
+    const u32 cap_ch = R.cap / CW;                // chunks per region (the capacity is a multiple of 32 entries)
+    if (tid < RT_OWNERS) { s_cur[tid] = ((u32)tid * P + p) * cap_ch; s_cn[tid] = 0; }
     if (tid == 0) s_over = 0;
     __syncthreads();
     const u64 n_groups = (n_reads + 63) >> 6, n_tiles = (n_reads + TILE - 1) / TILE;
@@ -790,7 +791,8 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
             if (sq_ == 0) {
                 s_off[so_] = off;
                 if (so_ == RT_OWNERS - 1) s_off[RT_OWNERS] = off + tot;
-                if (s_cur[so_] + s_cn[so_] + tot + CW > R.cap || off + tot > SCAP) s_over = 1;      // (+ CW: the last chunk is padded at the end)
+                const u32 written = (s_cur[so_] - (so_ * P + p) * cap_ch) * CW;
+                if (written + s_cn[so_] + tot + CW > R.cap || off + tot > SCAP) s_over = 1;      // (+ CW: the last chunk is padded at the end)
             }
             #pragma unroll
             for (int v = 0; v < QN; v++) off += (u32)v < sq_ ? pq[v] : 0u;
@@ -854,7 +856,7 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
                 #pragma unroll
                 for (int i = 0; i < NI; i++) {
                     const u32 T = cn[i] + (se[i] - sb[i]), out = T & ~(CW - 1u);
-                    auto dst = reinterpret_cast<v4u GLOBAL_AS*>(R.arena.g() + (((u64)oo[i] * P + p) * R.cap + sc[i]));
+                    auto dst = reinterpret_cast<v4u GLOBAL_AS*>(R.arena.g()) + (u64)sc[i] * (CW / 4);
                     for (u32 base = sub * 4; base < T; base += 64) {      // one pass for streams up to 64 entries, seldom two
                         u32 v[4];
                         #pragma unroll
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
                             for (int e = 0; e < 4; e++) if (base + (u32)e < T) s_carry[oo[i]][base + (u32)e - out] = v[e];
                         }
                     }
-                    if (sub == 0) { s_cur[oo[i]] = sc[i] + out; s_cn[oo[i]] = T - out; }
+                    if (sub == 0) { s_cur[oo[i]] = sc[i] + out / CW; s_cn[oo[i]] = T - out; }
                 }
             }
         }
@@ -881,9 +883,10 @@ __global__ __launch_bounds__(NW * 64) void k_route(const u32* __restrict__ packe
         tile = t_nxt; t_nxt = s_tile;      // (s_tile is next written behind the first barrier of the following iteration)
     }
     if (tid < RT_OWNERS) {      // the last, partly filled chunk of every region: padded with entries that are neither a seed nor a run start
-        u32 done = s_cur[tid]; const u32 cn = s_cn[tid];
+        const u32 ch = s_cur[tid], cn = s_cn[tid];
+        u32 done = (ch - ((u32)tid * P + p) * cap_ch) * CW;
         if (cn) {
-            auto dst = reinterpret_cast<v4u GLOBAL_AS*>(R.arena.g() + (((u64)tid * P + p) * R.cap + done));
+            auto dst = reinterpret_cast<v4u GLOBAL_AS*>(R.arena.g()) + (u64)ch * (CW / 4);
             #pragma unroll
             for (int k = 0; k < (int)CW / 4; k++) {
                 v4u q4;
@@ -3185,7 +3188,7 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     const u64 tiles_max = (n_tiles + prod - 1) / prod * 3 / 2 + 8;
     // expected entries per (owner, tile): tile * seeds / 256 + dummies (~10 % of nw) + ~2 of padding; 25 % and a constant on top
     u64 cap = (u64)((double)tiles_max * ((double)tile / 256.0 * (wpr - 1) + 0.15 * nw + 2.0) * 1.25) + 256; cap = (cap + 31) & ~31ull;      // regions start on 128-byte boundaries, whole 64-byte chunks are written
-    if (cap >= (1ull << 31) || tiles_max > 0xFFFFull) return fail(h, MLST_E_LIMIT, "batch too large for the routed sieve (%llu tiles per producer workgroup)", (unsigned long long)tiles_max);
+    if (cap >= (1ull << 31) || tiles_max > 0xFFFFull || (u64)RT_OWNERS * prod * (cap / 16) >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "batch too large for the routed sieve (%llu tiles per producer workgroup)", (unsigned long long)tiles_max);
     const u64 need = (u64)RT_OWNERS * prod * cap;
     if (h->cap_rt_arena < need || h->rt_prod != prod || h->rt_cap != (u32)cap) {
         hipStreamSynchronize(h->stream);
