@@ -29,6 +29,9 @@ typedef unsigned char u8;
 using mlst_inflate::OK; using mlst_inflate::E_INPUT; using mlst_inflate::E_BLOCKTYPE; using mlst_inflate::E_STORED; using mlst_inflate::E_LENGTHS;
 using mlst_inflate::E_OUTPUT; using mlst_inflate::E_DISTANCE; using mlst_inflate::E_SYMBOL;
 
+#if !defined(MLST_INFLATE_PB)
+#define MLST_INFLATE_PB 4         /* far matches copied per memory round trip (a multiple of four) */
+#endif
 enum { LB = 10, DBITS = 8, SYM_D = 288, RING = 1024 };
 struct Tabs {                       // per wave, in LDS (5.1 KB: LDS decides how many blocks a CU decodes at a time -- 31)
     u8 ring[RING];                  // the last RING bytes of output: near matches are copied from here (see Out::copy)
@@ -41,7 +44,7 @@ struct Tabs {                       // per wave, in LDS (5.1 KB: LDS decides how
     u16 sym[SYM_D + 32];            // symbols in canonical order: literal / length, then (from SYM_D) distance
     u16 cnt[2][16];                 // codes per length
     u8 len[320];                    // code lengths: literal / length symbols followed by distance symbols
-    u32 pq[3][4];                   // far matches waiting for their copy (Out::copy): source, destination, length
+    u32 pq[3][MLST_INFLATE_PB];     // far matches waiting for their copy (Out::copy): source, destination, length
 };
 
 // the order in which the code-length code's own lengths are sent (RFC 1951 3.2.7), five bits each, in two words
@@ -140,7 +143,7 @@ struct Stats { u32 lookups = 0, lits = 0, near_ = 0, far_def = 0, far_sync = 0, 
 #define ISTAT(...)
 #endif
 struct Out {
-    enum { PB = 4 };                // far matches that may wait for their copy
+    enum { PB = MLST_INFLATE_PB };  // far matches that may wait for their copy
     ISTAT(Stats st;)
     u8* out; u8* ring; u32* pq; u32 op, cap; // op = bytes produced (pending literals and waiting matches included)
     u32 lit, nlit;                  // lane k holds pending byte k; nlit of them (uniform)

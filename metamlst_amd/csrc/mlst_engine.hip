@@ -2628,12 +2628,19 @@ template <typename T> static hipError_t dmalloc(GP<T>* p, u64 n) { return hipMal
 
 static hipEvent_t ev_get(mlst_handle* h) {
     if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
+    // timing events only: without the system-scope release a record carries by default (the write-back of what the kernel
+    // before it left in the L2s would otherwise be counted into that kernel's interval)
+    hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) hipEventCreate(&e); return e;
 }
+// Event profiling (mlst_set_profiling): the start event of a group is recorded behind an empty kernel.  Recorded on a
+// stream that has been idle (the first group of a submission), the interval also held the wake-up of the queue: 40-55 us
+// on k_route once no buffer fill ran in front of it any more, against 12 us before -- rocprofv3's kernel durations do
+// not include it, and bench.py's rooflines are meant to be the same numbers (profiles/round3/README.md).
+__global__ void k_nop() {}
 struct Prof {
     mlst_handle* h; int which; hipEvent_t a = nullptr, b = nullptr;
     Prof(mlst_handle* h_, int w) : h(h_), which(w) {
-        if (h->profiling) { a = ev_get(h); b = ev_get(h); hipEventRecord(a, h->stream); }
+        if (h->profiling) { a = ev_get(h); b = ev_get(h); hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, h->stream); hipEventRecord(a, h->stream); }
     }
     ~Prof() { if (h->profiling) { hipEventRecord(b, h->stream); h->events.push_back({a, b, which}); } }
 };
