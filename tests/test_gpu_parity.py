@@ -566,6 +566,31 @@ def test_dense_on_locus_reads_overflow_the_sieve_queue():
         finally:
             os.environ.pop("MLST_SIEVE", None)
 
+def test_routed_sieve_reused_across_submissions_of_different_sizes(monkeypatch):
+    """The routed sieve keeps its candidate flags between submissions (k_flag_compact clears the words it read instead of
+    a fill per submission) and hands out tiles from a counter it resets itself: a large batch, then a smaller one of other
+    reads, then the large one again on ONE engine -- every pass equals the oracle, and the number of candidates equals
+    that of a fresh engine (a stale flag would not change a result: k_seed looks every candidate up exactly; it would
+    show as an extra candidate)."""
+    monkeypatch.setenv("MLST_SIEVE", "routed")
+    from metamlst_amd.engine import CNT_CANDIDATES
+    db, idx = fx.ecoli_small(80)
+    big = fx.isolate_reads(db, "ecoli", 5, n_reads=30000)[:3]
+    small = fx.isolate_reads(db, "ecoli", 3, n_reads=7001, seed=synth.SEED + 5)[:3]
+    eng, orc = both(idx)
+    assert eng.sieve_info()["kind"] == "routed"
+    seen = []
+    for fb, fq, off in (big, small, big, small):
+        orc2 = oracle_lib.Oracle(idx, None)
+        s, _ = run_both(eng, orc2, fb, fq, off)
+        seen.append(int(s.counters[CNT_CANDIDATES]))
+    assert seen[0] == seen[2] and seen[1] == seen[3]
+    fresh = Engine(0)
+    fresh.load_reference(idx)
+    fresh.submit_reads(*small)
+    assert int(fresh.stats().counters[CNT_CANDIDATES]) == seen[1]
+
+
 @pytest.mark.parametrize("kind", ["lds", "routed", "global"])
 def test_read_lengths_from_36_to_300_through_every_sieve(monkeypatch, kind):
     """The sieve kernels are instantiated per row width (2 .. 20 words): batches of 36, 75, 100, 250 and 300 bp reads (whole
