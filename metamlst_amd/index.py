@@ -38,17 +38,29 @@ class AlleleIndex:
         return len(self.loci)
 
     def sequence(self, a: int) -> str:
-        return self.ascii_concat[int(self.off[a]):int(self.off[a + 1])].tobytes().decode()
+        s = self._seq_cache.get(a)
+        if s is None:
+            s = self.ascii_concat[int(self.off[a]):int(self.off[a + 1])].tobytes().decode()
+            if len(self._seq_cache) < 65536:     # the alleles a run keeps choosing (a typing step asks for ~140 of them, again and again)
+                self._seq_cache[a] = s
+        return s
 
     def label(self, a: int) -> str:
-        sp, gene = self.loci[int(self.locus_id[a])]
-        return "%s_%s_%d" % (sp, gene, int(self.allele_no[a]))
+        s = self._label_cache.get(a)
+        if s is None:
+            sp, gene = self.loci[int(self.locus_id[a])]
+            s = "%s_%s_%d" % (sp, gene, int(self.allele_no[a]))
+            if len(self._label_cache) < 65536:
+                self._label_cache[a] = s
+        return s
 
     def locus_index(self, species: str, gene: str) -> int:
         return self._locus_map[(species, gene)]
 
     def __post_init__(self):
         self._locus_map = {k: i for i, k in enumerate(self.loci)}
+        self._seq_cache: dict = {}
+        self._label_cache: dict = {}
         self.locus_id_ip = self.locus_id.astype(np.intp)       # fancy-index form (uint32 indices are converted on every use)
         self.locus_begin_ip = self.locus_begin.astype(np.intp)
 
