@@ -1883,6 +1883,11 @@ __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep
     // per pair (8 pairs per block) and oriented read position: mismatch penalty | N flag << 8 | base << 9, so that a DP
     // row costs one LDS read (fetched a row ahead) and no global-memory round trip
     __shared__ u16 s_info[8][RQ];
+    // the allele words the band can touch (32 words of 16 bases from the word of band cell 0 in row 0: 512 bases, the longest
+    // read + the band + the slack of the three-word window), fetched once per pair, one word per lane.  Fetched inside the
+    // row loop (a word every 16 rows, requested three words ahead) each of them was waited for at the top of the NEXT row --
+    // the compiler cannot count loads across the loop's branches and writes vmcnt(0): ten exposed round trips per pair.
+    __shared__ u32 s_aw[8][32];
     if (threadIdx.x < 128) s_pentab[threadIdx.x] = E.pen_tab[threadIdx.x];
     __syncthreads();
     const int b = threadIdx.x & 31, gl = threadIdx.x >> 5;
@@ -1913,14 +1918,14 @@ __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep
                 u32 pen = isn ? (u32)P.n_penalty : (u32)s_pentab[qb & 0x7F];
                 s_info[gl][i] = (u16)(pen | (isn << 8) | (rbase << 9));
             }
+            s_aw[gl][b] = arena_word(E, L, ((d - W) >> 4) + b, a_local);
         }
         __syncthreads();
         int Hp = P0, Fp = NEGP, best = P0;
         int jb = d - W, q = jb >> 4;
-        // allele bases of the band: words q..q+2 are in use, q+3 is the prefetch for the next word crossing (its
-        // load is not waited for until then)
-        u32 w0 = arena_word(E, L, q, a_local), w1 = arena_word(E, L, q + 1, a_local), w2 = arena_word(E, L, q + 2, a_local),
-            w3 = arena_word(E, L, q + 3, a_local);
+        const int q0 = q;
+        // allele bases of the band: words q..q+2 are in use, q+3 is taken from the staged words at the next word crossing
+        u32 w0 = s_aw[gl][0], w1 = s_aw[gl][1], w2 = s_aw[gl][2], w3 = s_aw[gl][3];
         u32 info_next = n > 0 ? (u32)s_info[gl][0] : 0u;
         for (int i = 0; i < nmax; i++, jb++) {
             bool row = i < n;
@@ -1930,7 +1935,7 @@ __global__ __launch_bounds__(256) void k_banded(const EngineDev* __restrict__ Ep
             u32 rbase = (info >> 9) & 3u;
             int pen = (int)(info & 0xFFu);
             bool gap_ok = row && (i >= G && i < n - G);
-            if (row && (jb >> 4) != q) { q++; w0 = w1; w1 = w2; w2 = w3; w3 = arena_word(E, L, q + 3, a_local); }
+            if (row && (jb >> 4) != q) { q++; w0 = w1; w1 = w2; w2 = w3; w3 = s_aw[gl][(q + 3 - q0) & 31]; }
             int sh = 2 * (jb - 16 * q);
             u64 lo64 = (u64)w0 | ((u64)w1 << 32);
             u64 rowbits = sh ? ((lo64 >> sh) | ((u64)w2 << (64 - sh))) : lo64;
