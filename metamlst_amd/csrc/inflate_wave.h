@@ -104,8 +104,10 @@ struct In {
     __device__ __attribute__((always_inline)) u32 next32() {
         const u32 d = nd & (2u * GS - 1u), l = d >> 1;
         u32 v;
-        if (MLST_INFLATE_VALU) v = (u32)__shfl((int)((d & 1u) ? whi : wlo), gbase + (int)l);
-        else v = (d & 1u) ? (u32)__builtin_amdgcn_readlane((int)whi, (int)l) : (u32)__builtin_amdgcn_readlane((int)wlo, (int)l);
+        // (one stream per wave: the lane number is the same in every lane whichever unit carries the state -- a v_readlane
+        // behind a v_readfirstlane instead of a trip through the LDS crossbar, on the chain once per 32 bits of input)
+        if (MLST_INFLATE_VALU && GS != 64) v = (u32)__shfl((int)((d & 1u) ? whi : wlo), gbase + (int)l);
+        else { const int ls = __builtin_amdgcn_readfirstlane((int)l); const u32 sel = (d & 1u) ? whi : wlo; v = (u32)__builtin_amdgcn_readlane((int)sel, ls); }
         nd++;
         if ((nd & (2u * GS - 1u)) == 0) { wlo = nlo; whi = nhi; load((nd >> (GLOG + 1)) + 1, nlo, nhi); }
         return v;
@@ -384,8 +386,7 @@ __device__ __attribute__((always_inline)) inline int codes(In& in, Tabs& T, Out&
         const u32 dist = db + in.take((int)de);             // up to 13 extra bits (>= 17 are left behind a table code)
         if (dist > o.op) return E_DISTANCE;
         if (o.op + len > o.cap) return E_OUTPUT;
-        if (in.overrun()) return E_INPUT;
-        o.copy(dist, len);
+        o.copy(dist, len);      // (a stream that runs past its end is caught at its end-of-block symbol or by the output bound: every symbol writes at least a byte)
     }
 }
 
