@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--pipeline", type=int, default=4,
                     help="engines per GPU, each with its own resident batch: the GPU already works on the next steps while the host "
                          "types step k (every step is still a complete pass); 1 = strictly serial steps")
+    ap.add_argument("--cu-partitions", type=int, default=0,
+                    help="shares of the CUs the engines are spread over (engine k on share k mod n; mlst_set_cu_partition): "
+                         "0 = one share per engine, 1 = every engine on the whole device (rounds 1-3)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg2 block and the end-to-end rates")
     ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end (host FASTQ text -> ST) measurement")
     ap.add_argument("--calibrate", action="store_true",
@@ -157,6 +160,16 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
     idx, database, engines = w.idx, w.database, w.engines
     depth = len(engines)
     eng = engines[0]
+    n_parts = max(1, min(args.cu_partitions or depth, depth))      # engine k runs on share k mod n_parts of the CUs
+
+    def place(on: bool):
+        """Engines on their own shares of the CUs (the timed blocks) or all on the whole device (isolated launches, serial
+        steps: the figures behind `roofline` are those of a kernel that has the GPU to itself)."""
+        for k, e in enumerate(engines):
+            e.synchronize()
+            e.set_cu_partition(k % n_parts if on else 0, n_parts if on else 1)
+
+    place(world > 1)      # N > 1: the shards run on the engines' own streams from the start (and the isolated launches on a share)
     shards = [StreamedShard(e, device) for e in engines] if world > 1 else None
     ports = [DeviceStatsPort(e, device) for e in engines] if world > 1 else None
     mode = {"streamed": world > 1}
@@ -237,10 +250,12 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
 
     def run(n_steps):
         """K steps through the `depth` engines.  An engine is free again as soon as its step's results are on the host, so
-        the next step for it is queued BEFORE the host tail of the one just fetched (.nfo lines, ST calls: 1.7 ms of
+        the next step for it is queued BEFORE the host tail of the one just fetched (.nfo lines, ST calls: 0.9 ms of
         Python): the GPU always has `depth` steps to work on.  (Queued after the tail, as until round 3, the four steps
         that start a block together also finish together, the host works off four tails in a row while the GPU runs dry,
-        and a block of 20 steps never leaves that pattern: 3.16 ms per step against 2.7 in blocks of 200.)"""
+        and a block of 20 steps never leaves that pattern.)  Steps are fetched in the order they were queued (taking
+        whichever engine has finished first, or putting tails off while an engine waits for its next step, measured no
+        better: profiles/round3/ab.md); with N > 1 the ranks must issue their collectives in one order anyway."""
         last = None
         calls.clear()
         host_driven = world > 1 and not mode["streamed"]
@@ -333,6 +348,15 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
         finish(0)
     fence()
     serial_ms = (time.perf_counter() - t0) / n_serial * 1e3
+    if world == 1 and n_parts > 1:      # from here on every engine has its own share of the CUs; graphs are rebuilt, warm-up again
+        place(True)
+        for e_i in range(depth):
+            for _ in range(3):
+                submit(e_i)
+                finish(e_i)
+        fence()
+        run(args.warmup)
+        fence()
     # ---- timed region: blocks of exactly K steps, repeated until min-seconds have been timed (at least 3 blocks)
     blocks, total = [], 0.0
     last = None
@@ -385,6 +409,7 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
             "host_ms_per_step": {k: round(v / args.steps, 4) for k, v in hm.items()}, "serial_ms_per_step": serial_ms,
             "iso_launch_ms": iso_launch, "iso_launch_spread": spread, "stats": stats, "st_call": st_call, "typed_ok": typed_ok, "batches_checked": len(calls),
             "collectives": ("streamed on a torch stream" if mode["streamed"] else "host-driven") if world > 1 else None,
+            "cu_partitions": n_parts,
             "exchange": ({"statistics_bytes": int(shards[0].t_all.numel()) * 8, "counts_layout": "compact" if shards[0].compact else "fixed",
                           "counts_bytes": int(shards[0].cap_cols) * 16, "counts_bytes_fixed_layout": int(shards[0].total_cols) * 16,
                           "counts_columns_needed": (shards[0].needs[-1] if shards[0].needs else None),
@@ -589,7 +614,7 @@ def cpu_baseline(w, args, res):
 def summarize(w, res, eng, world, depth):
     stats = res["stats"]
     return {"workload": w.label, "reads_per_gpu": w.n_reads, "n_alleles": int(w.idx.n_alleles), "n_loci": int(w.idx.n_loci),
-            "sieve": eng.sieve_info(), "parallelism": "reads sharded x%d" % world, "pipeline_depth": depth, "distinct_resident_batches": len(w.batches),
+            "sieve": eng.sieve_info(), "parallelism": "reads sharded x%d" % world, "pipeline_depth": depth, "cu_partitions": res.get("cu_partitions"), "distinct_resident_batches": len(w.batches),
             "collectives": res["collectives"], "exchange_per_step": res.get("exchange"), "resident_format": "2-bit bases %d B/read + Phred rows %d B/read" % (w.wpr * 4, w.qstride)}
 
 

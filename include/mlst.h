@@ -300,6 +300,13 @@ int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint64_t* n);
  * far is waited for.  With the engine on the stream a torch.distributed collective is ordered against, a multi-GPU
  * step needs no host synchronisation between its kernels and its collectives (metamlst_amd/dist.py). */
 int mlst_set_stream(mlst_handle* h, void* stream);
+/* The engine's own stream restricted to share `part` of `n_parts` equal shares of the device's CUs (hipExtStreamCreateWithCUMask;
+ * n_parts = 1: the whole device).  Engines of one process on disjoint shares run side by side instead of taking turns;
+ * mlst_get_stream hands the stream out (e.g. for torch.cuda.ExternalStream), mlst_busy asks without waiting whether work
+ * queued on the engine's current stream is still running (1) or not (0).  No reference counterpart (one process, one CPU). */
+int mlst_set_cu_partition(mlst_handle* h, uint32_t part, uint32_t n_parts);
+int mlst_get_stream(mlst_handle* h, void** stream);
+int mlst_busy(mlst_handle* h);
 /* mlst_export_stats_device / mlst_import_stats_device without the host synchronisation. */
 int mlst_export_stats_device_async(mlst_handle* h, int64_t* d_sum, int64_t* d_min);
 int mlst_import_stats_device_async(mlst_handle* h, const int64_t* d_sum, const int64_t* d_min);

@@ -145,7 +145,9 @@ class StreamedShard:
     def __init__(self, engine, device: torch.device, group=None, force_collectives: bool = False, compact: bool | None = None):
         self.engine, self.device, self.group = engine, device, group
         self.force = force_collectives           # tests: issue the collectives even in a group of one
-        self.stream = torch.cuda.Stream(device=device)
+        # the engine's own stream, known to torch: collectives are ordered against it, the engine keeps its CU partition
+        # (mlst_set_cu_partition) and its hipGraphs
+        self.stream = torch.cuda.ExternalStream(engine.own_stream(), device=device)
         n_sum, n_min = engine.flat_sizes()
         self.n_sum, self.n_min = n_sum, max(1, n_min)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -167,7 +169,7 @@ class StreamedShard:
         self.repeats = 0                         # steps whose second half ran twice (capacity too small)
         self._last = None
         torch.cuda.synchronize(device)
-        engine.set_stream(self.stream.cuda_stream)
+        engine.set_stream(0)                     # (back on its own stream, should a caller have moved it)
 
     def _multi(self) -> bool:
         return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force)

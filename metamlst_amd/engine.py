@@ -111,6 +111,9 @@ def load_library(path: str | None = None):
         "mlst_typing_finish_compact": (C.c_int, [H, C.c_uint32, C.c_char, u32p]),
         "mlst_typing_compact_info": (C.c_int, [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "mlst_set_stream": (C.c_int, [H, C.c_void_p]),
+        "mlst_set_cu_partition": (C.c_int, [H, C.c_uint32, C.c_uint32]),
+        "mlst_get_stream": (C.c_int, [H, C.POINTER(C.c_void_p)]),
+        "mlst_busy": (C.c_int, [H]),
         "mlst_export_stats_device_async": (C.c_int, [H, i64p, i64p]),
         "mlst_import_stats_device_async": (C.c_int, [H, i64p, i64p]),
         "mlst_typing_fetch": (C.c_int, [H, i64p, u32p, u64p, u64p, u64p, i32p, u8p]),
@@ -358,6 +361,21 @@ class Engine:
     def set_stream(self, stream: int = 0):
         """Run the engine on a caller's HIP stream (e.g. torch.cuda.Stream.cuda_stream); 0 = its own stream again."""
         self._check(self.lib.mlst_set_stream(self._h, stream or None), "mlst_set_stream")
+
+    def set_cu_partition(self, part: int, n_parts: int):
+        """The engine's own stream on share `part` of `n_parts` equal shares of the CUs (n_parts = 1: the whole device)."""
+        self._check(self.lib.mlst_set_cu_partition(self._h, int(part), int(n_parts)), "mlst_set_cu_partition")
+
+    def own_stream(self) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.mlst_get_stream(self._h, C.byref(p)), "mlst_get_stream")
+        return int(p.value or 0)
+
+    def busy(self) -> bool:
+        rc = self.lib.mlst_busy(self._h)
+        if rc < 0:
+            self._check(rc, "mlst_busy")
+        return rc == 1
 
     def export_stats_device_async(self, d_sum: int, d_min: int):
         self._check(self.lib.mlst_export_stats_device_async(self._h, d_sum, d_min), "mlst_export_stats_device_async")

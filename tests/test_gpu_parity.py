@@ -566,6 +566,33 @@ def test_dense_on_locus_reads_overflow_the_sieve_queue():
         finally:
             os.environ.pop("MLST_SIEVE", None)
 
+@pytest.mark.parametrize("kind", ["lds", "routed"])
+def test_engine_on_a_share_of_the_cus(monkeypatch, kind):
+    """mlst_set_cu_partition: the engine's stream masked to a quarter, then to a seventh of the CUs, then the whole device
+    again -- same statistics, items and pile-up as the oracle every time (the routed sieve sizes its producer grid by the
+    share; graphs are rebuilt); mlst_busy / mlst_get_stream answer."""
+    monkeypatch.setenv("MLST_SIEVE", kind)
+    db, idx = fx.ecoli_small(80)
+    fb, fq, off = fx.isolate_reads(db, "ecoli", 5, n_reads=30000)[:3]
+    eng, _ = both(idx)
+    assert eng.own_stream() != 0 and not eng.busy()
+    for part, n in ((1, 4), (6, 7), (0, 1)):
+        eng.set_cu_partition(part, n)
+        for _ in range(3):                   # the third identical submission replays the rebuilt graph
+            s, _ = run_both(eng, oracle_lib.Oracle(idx, None), fb, fq, off)
+        check_pileup(eng, _fresh_oracle(idx, fb, fq, off), idx, s)
+        assert not eng.busy()
+    assert eng.own_stream() != 0
+    with pytest.raises(MlstError):
+        eng.set_cu_partition(4, 4)
+
+
+def _fresh_oracle(idx, fb, fq, off):
+    o = oracle_lib.Oracle(idx, None)
+    o.submit_reads(fb, fq, off)
+    return o
+
+
 def test_routed_sieve_reused_across_submissions_of_different_sizes(monkeypatch):
     """The routed sieve keeps its candidate flags between submissions (k_flag_compact clears the words it read instead of
     a fill per submission) and hands out tiles from a counter it resets itself: a large batch, then a smaller one of other
