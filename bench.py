@@ -160,7 +160,9 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
     idx, database, engines = w.idx, w.database, w.engines
     depth = len(engines)
     eng = engines[0]
-    n_parts = max(1, min(args.cu_partitions or depth, depth))      # engine k runs on share k mod n_parts of the CUs
+    # engine k runs on share k mod n_parts of the CUs; by default the largest of 1, 2, 4, 8 shares (whole XCDs) that leaves every
+    # share at least one engine
+    n_parts = max(1, min(args.cu_partitions, depth)) if args.cu_partitions else max(p2 for p2 in (1, 2, 4, 8) if p2 <= depth)
 
     def place(on: bool):
         """Engines on their own shares of the CUs (the timed blocks) or all on the whole device (isolated launches, serial

@@ -3948,6 +3948,9 @@ extern "C" int mlst_set_cu_partition(mlst_handle* h, uint32_t part, uint32_t n_p
     if (n_parts == 1) HIPCHK(h, hipStreamCreate(&ns));
     else {
         std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+        // (shares of whole XCDs -- 2, 4 or 8 parts of the 8 x 32 CUs -- are the ones that pay: the dispatcher deals workgroups
+        // to the XCDs in turn, and a share with 32 CUs on one XCD and 19 on the next runs at the pace of the 19: thirds of
+        // the device were 15 % slower than no partition at all, fifths 85 %; shares that overlap their neighbours 5-8 %)
         const u32 lo = (u32)((u64)n_cu * part / n_parts), hi = (u32)((u64)n_cu * (part + 1) / n_parts);
         for (u32 c = lo; c < hi; c++) mask[c >> 5] |= 1u << (c & 31);
         HIPCHK(h, hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
