@@ -350,6 +350,8 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
         finish(0)
     fence()
     serial_ms = (time.perf_counter() - t0) / n_serial * 1e3
+    if world == 1 and n_parts > 1 and not args.cu_partitions and sum(v[0] for k_, v in isolated.items() if k_ in ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup")) < 1.0:
+        n_parts = 1      # a step of well under a millisecond of kernels (cfg2: 0.35 ms) gains nothing from shares (0.342 -> 0.351 ms)
     if world == 1 and n_parts > 1:      # from here on every engine has its own share of the CUs; graphs are rebuilt, warm-up again
         place(True)
         for e_i in range(depth):
@@ -395,6 +397,7 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
     if shards:
         for s_ in shards:
             s_.close()
+    place(False)      # what follows (end-to-end legs, the oracle check) has the whole device again
     if rank != 0:
         return None
     order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])

@@ -3938,6 +3938,7 @@ extern "C" int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t min
 extern "C" int mlst_set_cu_partition(mlst_handle* h, uint32_t part, uint32_t n_parts) {
     if (!h) return MLST_E_INVALID;
     if (n_parts == 0 || part >= n_parts) return fail(h, MLST_E_INVALID, "CU partition %u of %u", part, n_parts);
+    if (n_parts == 1 && h->cu_split == 1) return MLST_OK;      // the whole device already: keep the stream (a fresh one may share a hardware queue with another engine's)
     hipSetDevice(h->device);
     drain_events(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
