@@ -415,6 +415,7 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
             "iso_launch_ms": iso_launch, "iso_launch_spread": spread, "stats": stats, "st_call": st_call, "typed_ok": typed_ok, "batches_checked": len(calls),
             "collectives": ("streamed on a torch stream" if mode["streamed"] else "host-driven") if world > 1 else None,
             "cu_partitions": n_parts,
+            "iso_measured_on": ("whole device" if (world == 1 or n_parts == 1) else "share 1/%d of the CUs (N > 1: the engines keep their shares throughout)" % n_parts),
             "exchange": ({"statistics_bytes": int(shards[0].t_all.numel()) * 8, "counts_layout": "compact" if shards[0].compact else "fixed",
                           "counts_bytes": int(shards[0].cap_cols) * 16, "counts_bytes_fixed_layout": int(shards[0].total_cols) * 16,
                           "counts_columns_needed": (shards[0].needs[-1] if shards[0].needs else None),
@@ -452,7 +453,8 @@ def rooflines(w, res, eng):
                 "traffic_source": ("profiles/round3/pmc_%s.json: rocprofv3 --pmc passes of this command (profiles/pmc_round2.sh), committed -- not measured by this run" % w.name) if tr else None,
                 "alg_bytes_per_read": ALG_BYTES_BASES, "reads_per_launch": w.n_reads, "avg_launch_ms": round(ms, 4),
                 "launch_ms_spread": res.get("iso_launch_spread", {}).get(key),
-                "duration_source": "HIP events on the engine's stream around each of 20 serial launches, median (= rocprofv3 --kernel-trace average of --pipeline 1)"}
+                "duration_source": "HIP events on the engine's stream around each of 20 serial launches, median (= rocprofv3 --kernel-trace average of --pipeline 1)",
+                "measured_on": res.get("iso_measured_on", "whole device")}
 
     if dom in stream_kernels:
         roof = hbm_roof(dom, stream_kernels[dom])
