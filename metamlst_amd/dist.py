@@ -207,9 +207,9 @@ class StreamedShard:
         want = (max(self.needs) * 3 // 2 + 2047) // 1024 * 1024
         return max(1024, min(self.total_cols, want))
 
-    def fetch(self):
+    def fetch(self, per_allele: bool = True):
         """-> (SampleStats, {locus: chosen allele idx}, {allele idx: consensus bytes}); whole-job values on every rank."""
-        res = self.engine.typing_fetch()
+        res = self.engine.typing_fetch(per_allele)
         penalty, mincov, multi = self._last
         if multi and self.compact:
             need, over = self.engine.typing_compact_info()
@@ -218,7 +218,7 @@ class StreamedShard:
                 self.cap_cols = self.total_cols
                 with torch.cuda.stream(self.stream):
                     self._second_half(penalty, mincov, multi)
-                res = self.engine.typing_fetch()
+                res = self.engine.typing_fetch(per_allele)
                 need, over = self.engine.typing_compact_info()
                 assert not over
             self.cap_cols = self.next_capacity(need)

@@ -383,20 +383,23 @@ class Engine:
     def import_stats_device_async(self, d_sum: int, d_min: int):
         self._check(self.lib.mlst_import_stats_device_async(self._h, d_sum, d_min), "mlst_import_stats_device_async")
 
-    def typing_fetch(self):
-        """-> (SampleStats, {locus: chosen allele idx}, {allele idx: consensus bytes}) of the last typing_enqueue."""
+    def typing_fetch(self, per_allele: bool = True):
+        """-> (SampleStats, {locus: chosen allele idx}, {allele idx: consensus bytes}) of the last typing_enqueue.
+        per_allele=False leaves sum_score / n_hits out (empty arrays): a caller that takes choice and consensus from the
+        device needs the per-locus figures only, and 12 bytes per allele of a large database are 4 MB to copy per sample."""
         nA, nL = self.index.n_alleles, self.index.n_loci
         if getattr(self, "_colbase", None) is None or len(self._colbase) != nL + 1:
             self._colbase = np.zeros(nL + 1, np.uint64)
             tot = C.c_uint64()
             self._check(self.lib.mlst_typing_layout(self._h, _ptr(self._colbase), C.byref(tot)), "mlst_typing_layout")
             self._cb_list = [int(x) for x in self._colbase]
-        s = SampleStats(np.empty(nA, np.int64), np.empty(nA, np.uint32), np.empty(nL, np.uint64),
+        nA_out = nA if per_allele else 0
+        s = SampleStats(np.empty(nA_out, np.int64), np.empty(nA_out, np.uint32), np.empty(nL, np.uint64),
                         np.empty(nL, np.uint64), np.empty(MLST_CNT_N, np.uint64))
         chosen = np.empty(nL, np.int32)
         letters = np.empty(self._cb_list[-1], np.uint8)
-        self._check(self.lib.mlst_typing_fetch(self._h, _ptr(s.sum_score), _ptr(s.n_hits), _ptr(s.locus_len_sum), _ptr(s.locus_first),
-                                               _ptr(s.counters), _ptr(chosen), _ptr(letters)), "mlst_typing_fetch")
+        self._check(self.lib.mlst_typing_fetch(self._h, _ptr(s.sum_score) if per_allele else None, _ptr(s.n_hits) if per_allele else None,
+                                               _ptr(s.locus_len_sum), _ptr(s.locus_first), _ptr(s.counters), _ptr(chosen), _ptr(letters)), "mlst_typing_fetch")
         raw = letters.tobytes()
         ch, let = {}, {}
         off = self.index.off
