@@ -270,6 +270,17 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
                 if k + ahead < n_steps:
                     submit(k + ahead)
                 last = tail(k)
+            elif world == 1:
+                # wait, queue the engine's next step, THEN copy the results of the finished one out of their pinned slot
+                # (mlst_typing_wait / mlst_typing_fetch_waited): on its own share of the CUs an engine idles from the end of a
+                # step to the submission of the next
+                e = engines[k % depth]
+                t_b = time.perf_counter()
+                e.typing_wait()
+                host_ms["wait_device"] += (time.perf_counter() - t_b) * 1e3
+                if k + ahead < n_steps:
+                    submit(k + ahead)
+                last = tail(k, e.typing_fetch(bool(mode.get("full_fetch")), waited=True))
             else:
                 got = wait(k)
                 if k + ahead < n_steps:

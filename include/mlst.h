@@ -255,6 +255,12 @@ int mlst_typing_finish_compact(mlst_handle* h, uint32_t mincov, char none_char, 
 int mlst_typing_compact_info(mlst_handle* h, uint64_t* need_cols, uint32_t* overflow);
 int mlst_typing_fetch(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_read_len_sum,
                       uint64_t* locus_first_read, uint64_t* counters, int32_t* chosen, uint8_t* letters);
+/* mlst_typing_fetch in two halves: mlst_typing_wait waits for the queued typing step; its results stay in pinned memory (two
+ * slots, written in turn) while the caller queues the engine's next step; mlst_typing_fetch_waited copies them out without
+ * waiting.  (An engine on its own share of the CUs idles between the end of a step and the submission of the next.) */
+int mlst_typing_wait(mlst_handle* h);
+int mlst_typing_fetch_waited(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_read_len_sum,
+                             uint64_t* locus_first_read, uint64_t* counters, int32_t* chosen, uint8_t* letters);
 /* round(float(p) / float(q), 1) of Python as an exact integer number of tenths (host function, the same code
  * the device uses); 0 when q == 0. */
 long long mlst_round_tenths(long long p, uint32_t q);

@@ -2596,6 +2596,10 @@ struct mlst_handle {
     // device-side typing (mlst_typing_enqueue / mlst_typing_fetch): fixed column layout, one slot of loc_maxlen columns per locus
     int* d_allele_no = nullptr; int* d_auto_chosen = nullptr; u64* d_fixed_colbase = nullptr; std::vector<u64> fixed_colbase; u64 fixed_cols = 0;
     u32* d_auto_counts = nullptr; u8* d_auto_letters = nullptr; u8* h_auto = nullptr; bool auto_pending = false;
+    // results of the typing tail in pinned memory, two slots written in turn: the host can queue the engine's next step
+    // (mlst_typing_wait, then submit + mlst_typing_enqueue) before it copies the results of the step just finished out of
+    // theirs (mlst_typing_fetch_waited)
+    u8* h_tstats[2] = {nullptr, nullptr}; u8* h_tauto[2] = {nullptr, nullptr}; int t_slot = 0, t_last = 0, t_ready = -1;
     u64* d_compact_colbase = nullptr; int* d_compact_chosen = nullptr; u64* d_compact_info = nullptr; u64 off_compact_info = 0; bool compact_pending = false;      // mlst_typing_choose_pileup_compact
     // host-to-device copies of the FASTQ entries: a copy stream, two text buffers used in turn, the event that says a
     // buffer's last chunk has been packed (h2d_overlapped)
@@ -2733,6 +2737,7 @@ static void free_ref(mlst_handle* h) {
     hipFree(h->d_allele_no); hipFree(h->d_auto_chosen); hipFree(h->d_fixed_colbase); hipFree(h->d_auto_counts); hipFree(h->d_auto_letters);
     hipFree(h->d_compact_colbase); hipFree(h->d_compact_chosen); hipFree(h->d_compact_info); h->d_compact_colbase = nullptr; h->d_compact_chosen = nullptr; h->d_compact_info = nullptr;
     if (h->h_auto) { hipHostFree(h->h_auto); h->h_auto = nullptr; }
+    for (int k = 0; k < 2; k++) if (h->h_tauto[k]) { hipHostFree(h->h_tauto[k]); h->h_tauto[k] = nullptr; }
     h->d_allele_no = h->d_auto_chosen = nullptr; h->d_fixed_colbase = nullptr; h->d_auto_counts = nullptr; h->d_auto_letters = nullptr; h->auto_pending = false;
     h->d_arena = h->d_planes = h->d_nmask = nullptr; h->d_allele_len = nullptr; h->d_allele_locus = nullptr; h->d_loci = nullptr; h->d_sieve = nullptr;
     h->d_keys = nullptr; h->d_vals = h->d_posts = nullptr; h->d_floor = nullptr; h->d_pen = nullptr; h->d_ascii = nullptr; h->d_aoff = nullptr;
@@ -2748,6 +2753,7 @@ static void free_state(mlst_handle* h) {
     h->d_rt_arena = nullptr; h->d_rt_counts = nullptr; h->d_rt_emitted = nullptr; h->cap_rt_arena = 0; h->cap_rt_emitted = 0; h->rt_prod = 0;
     hipFree(h->d_E); h->d_E = nullptr;
     hipFree(h->d_stats); h->d_stats = nullptr; if (h->h_stats) { hipHostFree(h->h_stats); h->h_stats = nullptr; }
+    for (int k = 0; k < 2; k++) if (h->h_tstats[k]) { hipHostFree(h->h_tstats[k]); h->h_tstats[k] = nullptr; }
     hipFree(E.ret_bases); hipFree(E.ret_quals); hipFree(E.ret_len); hipFree(E.ret_ridx); hipFree(E.ret_nrec);
     hipFree(E.ret_mate); hipFree(E.ret_item0); hipFree(E.ret_nitems); E.ret_mate = nullptr; E.ret_item0 = nullptr; E.ret_nitems = nullptr;
     hipFree(E.items); hipFree(E.item_state); hipFree(E.res); hipFree(E.dp_list);
@@ -3097,6 +3103,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         HIPCHK(h, dmalloc(&h->d_auto_counts, h->fixed_cols * 4 + 4)); HIPCHK(h, dmalloc(&h->d_auto_letters, h->fixed_cols + 16));
         h->off_compact_info = (((u64)n_loci * 4 + 15) & ~15ull) + ((h->fixed_cols + 15) & ~15ull);
         HIPCHK(h, hipHostMalloc((void**)&h->h_auto, h->off_compact_info + 64, hipHostMallocDefault));
+        for (int k = 0; k < 2; k++) { if (h->h_tauto[k]) hipHostFree(h->h_tauto[k]); HIPCHK(h, hipHostMalloc((void**)&h->h_tauto[k], h->off_compact_info + 64, hipHostMallocDefault)); }
         HIPCHK(h, dmalloc(&h->d_compact_colbase, (u64)n_loci + 1)); HIPCHK(h, dmalloc(&h->d_compact_chosen, (u64)n_loci + 1)); HIPCHK(h, dmalloc(&h->d_compact_info, 2));
     }
     // ---- sample state
@@ -3117,6 +3124,8 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         h->stats_bytes = o ? o : 8;
         HIPCHK(h, dmalloc(&h->d_stats, h->stats_bytes));
         HIPCHK(h, hipHostMalloc((void**)&h->h_stats, h->stats_bytes, hipHostMallocDefault));
+        for (int k = 0; k < 2; k++) { if (h->h_tstats[k]) hipHostFree(h->h_tstats[k]); HIPCHK(h, hipHostMalloc((void**)&h->h_tstats[k], h->stats_bytes, hipHostMallocDefault)); }
+        h->t_slot = 0; h->t_ready = -1;
         E.sum_score = (long long*)(h->d_stats + h->off_sum); E.locus_len = (u64*)(h->d_stats + h->off_len);
         E.ctr = (Counters*)(h->d_stats + h->off_ctr); E.n_hits = (u32*)(h->d_stats + h->off_hits);
         E.locus_first = (u64*)(h->d_stats + h->off_first);
@@ -3866,10 +3875,11 @@ static int typing_finish_kernels(mlst_handle* h, uint32_t mincov, char none_char
 }
 static int typing_finish_copies(mlst_handle* h) {
     const u64 nl = h->n_loci, ncols = h->fixed_cols;
-    HIPCHK(h, hipMemcpyAsync(h->h_stats, h->d_stats, h->stats_bytes, hipMemcpyDeviceToHost, h->stream));
-    if (nl) HIPCHK(h, hipMemcpyAsync(h->h_auto, h->d_auto_chosen, nl * 4, hipMemcpyDeviceToHost, h->stream));
-    if (ncols) HIPCHK(h, hipMemcpyAsync(h->h_auto + ((nl * 4 + 15) & ~15ull), h->d_auto_letters, ncols, hipMemcpyDeviceToHost, h->stream));
-    h->auto_pending = true;
+    u8* hs = h->h_tstats[h->t_slot]; u8* ha = h->h_tauto[h->t_slot];
+    HIPCHK(h, hipMemcpyAsync(hs, h->d_stats, h->stats_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (nl) HIPCHK(h, hipMemcpyAsync(ha, h->d_auto_chosen, nl * 4, hipMemcpyDeviceToHost, h->stream));
+    if (ncols) HIPCHK(h, hipMemcpyAsync(ha + ((nl * 4 + 15) & ~15ull), h->d_auto_letters, ncols, hipMemcpyDeviceToHost, h->stream));
+    h->auto_pending = true; h->t_last = h->t_slot; h->t_slot ^= 1;
     return MLST_OK;
 }
 extern "C" int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_char, const uint32_t* d_counts) {
@@ -3904,14 +3914,14 @@ extern "C" int mlst_typing_finish_compact(mlst_handle* h, uint32_t mincov, char 
     if (h->n_loci) hipLaunchKernelGGL(k_consensus_expand, dim3((unsigned)h->n_loci), dim3(256), 0, h->stream, d_counts, h->d_compact_chosen, h->d_compact_colbase,
                                       h->d_fixed_colbase, mincov, (u8)none_char, h->d_auto_letters);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->h_auto + h->off_compact_info, h->d_compact_info, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_tauto[h->t_slot] + h->off_compact_info, h->d_compact_info, 16, hipMemcpyDeviceToHost, h->stream));      // (the slot typing_finish_copies is about to fill)
     h->compact_pending = true;
     return typing_finish_copies(h);
 }
 extern "C" int mlst_typing_compact_info(mlst_handle* h, uint64_t* need_cols, uint32_t* overflow) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
-    if (!h->compact_pending || h->auto_pending) return fail(h, MLST_E_INVALID, "mlst_typing_compact_info follows mlst_typing_finish_compact and mlst_typing_fetch");
-    const u64* info = (const u64*)(h->h_auto + h->off_compact_info);
+    if (!h->compact_pending || h->t_ready < 0) return fail(h, MLST_E_INVALID, "mlst_typing_compact_info follows mlst_typing_finish_compact and mlst_typing_fetch");
+    const u64* info = (const u64*)(h->h_tauto[h->t_ready] + h->off_compact_info);
     if (need_cols) *need_cols = info[0];
     if (overflow) *overflow = (uint32_t)info[1];
     return MLST_OK;
@@ -4009,25 +4019,49 @@ extern "C" int mlst_import_stats_device_async(mlst_handle* h, const int64_t* d_s
 
 // Waits for mlst_typing_enqueue and hands everything over: the statistics of mlst_get_allele_stats, chosen[n_loci]
 // (allele index or -1) and the consensus letters in the fixed layout of mlst_typing_layout.
+static int typing_hand_over(mlst_handle* h, int slot, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_len, uint64_t* locus_first,
+                            uint64_t* counters, int32_t* chosen, uint8_t* letters) {
+    const u8* hs = h->h_tstats[slot]; const u8* ha = h->h_tauto[slot];
+    Counters* c = (Counters*)(hs + h->off_ctr);
+    if (c->err) return fail(h, MLST_E_CAPACITY, "capacity exceeded (flags 0x%llx); raise mlst_params.max_*", (unsigned long long)c->err);
+    const u64 nl = h->n_loci;
+    if (sum_score) memcpy(sum_score, hs + h->off_sum, (u64)h->n_alleles * 8);
+    if (n_hits) memcpy(n_hits, hs + h->off_hits, (u64)h->n_alleles * 4);
+    if (locus_len) memcpy(locus_len, hs + h->off_len, nl * 8);
+    if (locus_first) memcpy(locus_first, hs + h->off_first, nl * 8);
+    note_sieve_window(h, c);
+    if (counters) { for (int i = 0; i < MLST_CNT_N; i++) counters[i] = c->cnt[i]; counters[MLST_CNT_RETAINED] = c->n_ret; counters[MLST_CNT_ITEMS] = c->n_items; }
+    if (chosen) memcpy(chosen, ha, nl * 4);
+    if (letters) memcpy(letters, ha + ((nl * 4 + 15) & ~15ull), h->fixed_cols);
+    return MLST_OK;
+}
 extern "C" int mlst_typing_fetch(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_len, uint64_t* locus_first,
                                  uint64_t* counters, int32_t* chosen, uint8_t* letters) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     if (!h->auto_pending) return fail(h, MLST_E_INVALID, "mlst_typing_fetch without mlst_typing_enqueue");
     hipSetDevice(h->device);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->auto_pending = false;
-    Counters* c = (Counters*)(h->h_stats + h->off_ctr);
-    if (c->err) return fail(h, MLST_E_CAPACITY, "capacity exceeded (flags 0x%llx); raise mlst_params.max_*", (unsigned long long)c->err);
-    const u64 nl = h->n_loci;
-    if (sum_score) memcpy(sum_score, h->h_stats + h->off_sum, (u64)h->n_alleles * 8);
-    if (n_hits) memcpy(n_hits, h->h_stats + h->off_hits, (u64)h->n_alleles * 4);
-    if (locus_len) memcpy(locus_len, h->h_stats + h->off_len, nl * 8);
-    if (locus_first) memcpy(locus_first, h->h_stats + h->off_first, nl * 8);
-    note_sieve_window(h, c);
-    if (counters) { for (int i = 0; i < MLST_CNT_N; i++) counters[i] = c->cnt[i]; counters[MLST_CNT_RETAINED] = c->n_ret; counters[MLST_CNT_ITEMS] = c->n_items; }
-    if (chosen) memcpy(chosen, h->h_auto, nl * 4);
-    if (letters) memcpy(letters, h->h_auto + ((nl * 4 + 15) & ~15ull), h->fixed_cols);
+    h->auto_pending = false; h->t_ready = h->t_last;
+    return typing_hand_over(h, h->t_ready, sum_score, n_hits, locus_len, locus_first, counters, chosen, letters);
+}
+// The two halves of mlst_typing_fetch.  mlst_typing_wait waits for the step queued by mlst_typing_enqueue (or the _finish
+// entries); its results stay where they are, in one of two pinned slots, while the caller queues the engine's NEXT step
+// (mlst_reset_sample, submit, mlst_typing_enqueue -- that one writes the other slot); mlst_typing_fetch_waited then copies
+// them out without waiting for anything.  An engine on its own share of the CUs (mlst_set_cu_partition) is idle from the
+// end of one step to the submission of the next: this keeps the copies (4 MB per step on cfg3) out of that gap.
+extern "C" int mlst_typing_wait(mlst_handle* h) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (!h->auto_pending) return fail(h, MLST_E_INVALID, "mlst_typing_wait without mlst_typing_enqueue");
+    hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->auto_pending = false; h->t_ready = h->t_last;
     return MLST_OK;
+}
+extern "C" int mlst_typing_fetch_waited(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_len, uint64_t* locus_first,
+                                        uint64_t* counters, int32_t* chosen, uint8_t* letters) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (h->t_ready < 0) return fail(h, MLST_E_INVALID, "mlst_typing_fetch_waited without mlst_typing_wait");
+    return typing_hand_over(h, h->t_ready, sum_score, n_hits, locus_len, locus_first, counters, chosen, letters);
 }
 
 extern "C" int mlst_hamming_all(mlst_handle* h, uint32_t locus, const uint8_t* query, uint32_t len, uint32_t* dist) {

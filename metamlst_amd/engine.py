@@ -117,6 +117,8 @@ def load_library(path: str | None = None):
         "mlst_export_stats_device_async": (C.c_int, [H, i64p, i64p]),
         "mlst_import_stats_device_async": (C.c_int, [H, i64p, i64p]),
         "mlst_typing_fetch": (C.c_int, [H, i64p, u32p, u64p, u64p, u64p, i32p, u8p]),
+        "mlst_typing_wait": (C.c_int, [H]),
+        "mlst_typing_fetch_waited": (C.c_int, [H, i64p, u32p, u64p, u64p, u64p, i32p, u8p]),
         "mlst_round_tenths": (C.c_longlong, [C.c_longlong, C.c_uint32]),
         "mlst_hamming_le": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]),
         "mlst_hamming_all": (C.c_int, [H, C.c_uint32, u8p, C.c_uint32, u32p]),
@@ -383,7 +385,11 @@ class Engine:
     def import_stats_device_async(self, d_sum: int, d_min: int):
         self._check(self.lib.mlst_import_stats_device_async(self._h, d_sum, d_min), "mlst_import_stats_device_async")
 
-    def typing_fetch(self, per_allele: bool = True):
+    def typing_wait(self):
+        """Wait for the queued typing step; its results stay in the engine (typing_fetch(waited=True)) while the next step is queued."""
+        self._check(self.lib.mlst_typing_wait(self._h), "mlst_typing_wait")
+
+    def typing_fetch(self, per_allele: bool = True, waited: bool = False):
         """-> (SampleStats, {locus: chosen allele idx}, {allele idx: consensus bytes}) of the last typing_enqueue.
         per_allele=False leaves sum_score / n_hits out (empty arrays): a caller that takes choice and consensus from the
         device needs the per-locus figures only, and 12 bytes per allele of a large database are 4 MB to copy per sample."""
@@ -398,8 +404,9 @@ class Engine:
                         np.empty(nL, np.uint64), np.empty(MLST_CNT_N, np.uint64))
         chosen = np.empty(nL, np.int32)
         letters = np.empty(self._cb_list[-1], np.uint8)
-        self._check(self.lib.mlst_typing_fetch(self._h, _ptr(s.sum_score) if per_allele else None, _ptr(s.n_hits) if per_allele else None,
-                                               _ptr(s.locus_len_sum), _ptr(s.locus_first), _ptr(s.counters), _ptr(chosen), _ptr(letters)), "mlst_typing_fetch")
+        fn = self.lib.mlst_typing_fetch_waited if waited else self.lib.mlst_typing_fetch
+        self._check(fn(self._h, _ptr(s.sum_score) if per_allele else None, _ptr(s.n_hits) if per_allele else None,
+                       _ptr(s.locus_len_sum), _ptr(s.locus_first), _ptr(s.counters), _ptr(chosen), _ptr(letters)), "mlst_typing_fetch")
         raw = letters.tobytes()
         ch, let = {}, {}
         off = self.index.off

@@ -566,6 +566,32 @@ def test_dense_on_locus_reads_overflow_the_sieve_queue():
         finally:
             os.environ.pop("MLST_SIEVE", None)
 
+def test_typing_results_survive_the_submission_of_the_next_step():
+    """mlst_typing_wait / mlst_typing_fetch_waited: the results of a finished typing step are copied out AFTER the engine's
+    next step (other reads) has been queued -- two pinned slots written in turn -- and equal those of mlst_typing_fetch."""
+    db, idx = fx.ecoli_small(80)
+    a = fx.isolate_reads(db, "ecoli", 5, n_reads=9000)[:3]
+    b = fx.isolate_reads(db, "ecoli", 3, n_reads=7000, seed=synth.SEED + 9)[:3]
+    eng = Engine(0)
+    eng.load_reference(idx)
+    want = []
+    for r in (a, b):
+        eng.reset_sample(); eng.submit_reads(*r); eng.typing_enqueue(penalty=100)
+        want.append(eng.typing_fetch())
+    eng.reset_sample(); eng.submit_reads(*a); eng.typing_enqueue(penalty=100)
+    for k, r in enumerate((b, a, b)):                  # step k waited for, step k + 1 queued, step k fetched
+        eng.typing_wait()
+        eng.reset_sample(); eng.submit_reads(*r); eng.typing_enqueue(penalty=100)
+        st, ch, let = eng.typing_fetch(waited=True)
+        ws, wc, wl = want[k % 2]
+        fx.assert_stats_equal(st, ws)
+        assert ch == wc and {x: bytes(v) for x, v in let.items()} == {x: bytes(v) for x, v in wl.items()}
+    st, ch, let = eng.typing_fetch()
+    fx.assert_stats_equal(st, want[1][0])
+    with pytest.raises(MlstError):
+        eng.typing_wait()                              # nothing queued
+
+
 @pytest.mark.parametrize("kind", ["lds", "routed"])
 def test_engine_on_a_share_of_the_cus(monkeypatch, kind):
     """mlst_set_cu_partition: the engine's stream masked to a quarter, then to a seventh of the CUs, then the whole device
