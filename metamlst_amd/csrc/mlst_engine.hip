@@ -2595,7 +2595,7 @@ struct mlst_handle {
     u32* d_counts = nullptr; u64 cap_counts = 0;
     // device-side typing (mlst_typing_enqueue / mlst_typing_fetch): fixed column layout, one slot of loc_maxlen columns per locus
     int* d_allele_no = nullptr; int* d_auto_chosen = nullptr; u64* d_fixed_colbase = nullptr; std::vector<u64> fixed_colbase; u64 fixed_cols = 0;
-    u32* d_auto_counts = nullptr; u8* d_auto_letters = nullptr; u8* h_auto = nullptr; bool auto_pending = false;
+    u32* d_auto_counts = nullptr; u8* d_auto_letters = nullptr; bool auto_pending = false;
     // results of the typing tail in pinned memory, two slots written in turn: the host can queue the engine's next step
     // (mlst_typing_wait, then submit + mlst_typing_enqueue) before it copies the results of the step just finished out of
     // theirs (mlst_typing_fetch_waited)
@@ -2736,7 +2736,6 @@ static void free_ref(mlst_handle* h) {
     hipFree(h->d_rfilter); h->d_rfilter = nullptr;
     hipFree(h->d_allele_no); hipFree(h->d_auto_chosen); hipFree(h->d_fixed_colbase); hipFree(h->d_auto_counts); hipFree(h->d_auto_letters);
     hipFree(h->d_compact_colbase); hipFree(h->d_compact_chosen); hipFree(h->d_compact_info); h->d_compact_colbase = nullptr; h->d_compact_chosen = nullptr; h->d_compact_info = nullptr;
-    if (h->h_auto) { hipHostFree(h->h_auto); h->h_auto = nullptr; }
     for (int k = 0; k < 2; k++) if (h->h_tauto[k]) { hipHostFree(h->h_tauto[k]); h->h_tauto[k] = nullptr; }
     h->d_allele_no = h->d_auto_chosen = nullptr; h->d_fixed_colbase = nullptr; h->d_auto_counts = nullptr; h->d_auto_letters = nullptr; h->auto_pending = false;
     h->d_arena = h->d_planes = h->d_nmask = nullptr; h->d_allele_len = nullptr; h->d_allele_locus = nullptr; h->d_loci = nullptr; h->d_sieve = nullptr;
@@ -3102,7 +3101,6 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         HIPCHK(h, dmalloc(&h->d_auto_chosen, (u64)n_loci));
         HIPCHK(h, dmalloc(&h->d_auto_counts, h->fixed_cols * 4 + 4)); HIPCHK(h, dmalloc(&h->d_auto_letters, h->fixed_cols + 16));
         h->off_compact_info = (((u64)n_loci * 4 + 15) & ~15ull) + ((h->fixed_cols + 15) & ~15ull);
-        HIPCHK(h, hipHostMalloc((void**)&h->h_auto, h->off_compact_info + 64, hipHostMallocDefault));
         for (int k = 0; k < 2; k++) { if (h->h_tauto[k]) hipHostFree(h->h_tauto[k]); HIPCHK(h, hipHostMalloc((void**)&h->h_tauto[k], h->off_compact_info + 64, hipHostMallocDefault)); }
         HIPCHK(h, dmalloc(&h->d_compact_colbase, (u64)n_loci + 1)); HIPCHK(h, dmalloc(&h->d_compact_chosen, (u64)n_loci + 1)); HIPCHK(h, dmalloc(&h->d_compact_info, 2));
     }
