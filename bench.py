@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--cu-partitions", type=int, default=0,
                     help="shares of the CUs the engines are spread over (engine k on share k mod n; mlst_set_cu_partition): "
                          "0 = one share per engine, 1 = every engine on the whole device (rounds 1-3)")
+    ap.add_argument("--stagger-ms", type=float, default=None,
+                    help="time between the first submissions of a block (default: 0.75 ms when the engines have their own CU shares, else 0)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg2 block and the end-to-end rates")
     ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end (host FASTQ text -> ST) measurement")
     ap.add_argument("--calibrate", action="store_true",
@@ -263,7 +265,14 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
         calls.clear()
         host_driven = world > 1 and not mode["streamed"]
         ahead = depth - 1 if host_driven else depth      # host-driven exchange: the engine is busy until its tail has run
+        # the first submissions of a block 0.75 ms apart when every engine has its own share of the CUs: started in the same
+        # instant the four launch sequences stay in step (all in k_route, then all in k_route_probe ...) for a round or two;
+        # 0.5-1 ms apart they mix from the start: 2.62-2.66 -> 2.56-2.57 ms per step in blocks of 20, the 2.3 ms of waiting
+        # included (1.5 ms apart: 2.62-2.64; 2.5 ms: 2.73)
+        stagger = (args.stagger_ms if args.stagger_ms is not None else (0.75 if n_parts > 1 else 0.0)) * 1e-3
         for k in range(min(ahead, n_steps)):
+            if k and stagger:
+                time.sleep(stagger)
             submit(k)
         for k in range(n_steps):
             if host_driven:
