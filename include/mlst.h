@@ -327,6 +327,13 @@ int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]);
  * memory, 3 = CU-routed filter slices in LDS; chosen by database size, MLST_SIEVE=lds / global / routed forces one), [1] = distinct canonical seeds, [2] = longest overflow walk of a key in the
  * fingerprint sieve (the kernels follow a chain for 64 buckets; the build keeps it <= 32), [3] = sieve buckets. */
 int mlst_get_sieve_info(mlst_handle* h, uint64_t out[4]);
+/* The block-haplotype tables k_extend scores against (SURVEY 8 f1 "locus backbone / variant-column table"; they replace
+ * aligning a read against every allele one by one, which is what a bowtie2 -a run over the FASTA of
+ * metaMLST_functions.py:149-161 does): [0] = distinct 32-base block haplotypes of all loci, [1] = bytes of the tables
+ * (also counted in mlst_get_index_bytes [0]), [2] = loci that have them, [3] / [4] = most haplotypes in any run of 6 / 11
+ * blocks (what a read of <= 160 / <= 320 bases covers), [5] / [6] = bytes of LDS a work item of k_extend_160 / _320 gets
+ * for the summaries (MLST_EXT_LDS_KB bounds it; loci that need more are aligned pair by pair), [7] = threads per work item. */
+int mlst_get_extend_info(mlst_handle* h, uint64_t out[8]);
 /* Diagnostics of the routed sieve (profiles/route_modes.py; no reference counterpart, not a data path).
  * mlst_get_route_trace: the first call switches the trace on; later calls wait for the stream and return, for the last
  * submission, out[0] = producer workgroups P, [1] = arena address, [2] = packed-row address, [3] = wall-clock kHz,

@@ -106,8 +106,17 @@ struct LocusDev {
     u32 has_n, species, max_len;
     u64 plane_off;      // word offset of this locus in the bit-plane arena
     u32 pblocks;        // 32-base blocks per allele in the bit-plane arena (ceil(max_len/32) + 1)
-    u32 pad_;
+    u32 hap_ok;         // block-haplotype tables present (every block of the locus has fewer than 65,536 haplotypes)
+    // block-haplotype tables (k_extend): the distinct (planes, N mask, length) tuples of every 32-base allele block
+    u64 hid_off;        // word offset of the locus in hap_id: hap_id[hid_off + (q >> 1) * n_pad + allele] = haplotypes of blocks q (even; low half) and q + 1
+    u32 hap_off;        // record offset of the locus in hap_rec
+    u32 hblk_off;       // offset in hap_blk of the locus' pblocks + 1 prefix counts: the records of block q are
+                        // hap_rec[hap_off + hap_blk[hblk_off + q] ... hap_off + hap_blk[hblk_off + q + 1])
+    u32 hap_win[2];     // most haplotype records in any run of 6 / of 11 consecutive blocks (what a read of <= 160 / <= 320 bases covers)
 };
+// One distinct 32-base block of the alleles of a locus: bit planes, N mask and how many of the 32 columns exist
+// (the last block of an allele is shorter; blocks behind an allele's end have len = 0 and act as the identity).
+struct HapRec { u32 lo, hi, nm, len; };
 struct ItemDev {         // one (read, locus, strand, diagonal) unit of extension work
     u64 res_off;         // offset of its result row in the pair-result arena
     u32 ret;             // retained-read slot
@@ -171,6 +180,7 @@ struct EngineDev {
     GP<const u64> keys; GP<const u32> vals; GP<const u32> posts; u32 table_mask;
     GP<const int> floor_tab; GP<const u8> pen_tab;
     u32 n_alleles, n_loci;
+    GP<const HapRec> hap_rec; GP<const u32> hap_blk; GP<const u32> hap_id;      // block-haplotype tables (see LocusDev)
     // sample state
     GP<long long> sum_score; GP<u32> n_hits; GP<u64> locus_len; GP<u64> locus_first;
     GP<Counters> ctr;
@@ -1671,99 +1681,429 @@ __device__ inline u64 ext_steal(const EngineDev& E, u32 q, u64 begin, u64 end) {
     return begin + q + (u64)EXT_Q * atomicAdd(&E.ctr->ext_q[q][0], 1ull);
 }
 
+// ---- item records (k_ext_prep -> k_extend).  Everything k_extend needs to know about a work item, gathered into one
+// contiguous record by a kernel whose lanes are items: read on its own, a workgroup of k_extend followed a chain of ~8
+// dependent round trips per item (ticket -> item -> locus, read length -> quality and base rows -> ballots -> block
+// table), ~25 with the six record loads and five id loads behind it, and at 7 waves per SIMD that chain, not the vector
+// units, set its pace (PMC, profiles/round4/README.md).  Words of a record (NBA = NB + 1 blocks):
+//   0 flags   1 n | pen_def << 16   2 diag   3 ret   4 locus   5,6 res_off   7 a_begin   8 n_alleles   9 n_pad
+//   10 hap_off   11,12 hid_off   13 floor_n   14 pblocks   15 hap_win (of this instantiation)
+//   16 .. 16+NBA      first record of block q0 + t in the locus' table (clamped: empty outside the allele), t = 0 .. NBA
+//   32 + 4 t          the read's planes funnel-shifted onto block t: low, high, N mask, non-default-penalty mask
+//   32 + 4 NBA + t    read columns that exist in block t
+#define XF_SINGLE 1u
+#define XF_RESOK 2u
+#define XF_HAPOK 4u
+#define XF_READN 8u
+#define XF_SPECIAL 16u      /* a column with a non-default penalty or an N in the read, or a locus with N columns: s_pen is needed */
+#define XF_STRAND 32u
+template <int NB> struct XRec {
+    static constexpr int NBA = NB + 1, HB = 16, PL = 32, VR = 32 + 4 * NBA, WORDS = (VR + NBA + 15) & ~15;
+};
+
 template <int NB>
-__device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, const KParams& P) {
+__global__ __launch_bounds__(256) void k_ext_prep(const EngineDev* __restrict__ Ep, KParams P, u32* __restrict__ xrec, u64 cap_xrec) {
+    typedef XRec<NB> X;
+    const EngineDev& E = *Ep;
+    __shared__ u32 s_rl[4][RW / 2 + 2]; __shared__ u32 s_rh[4][RW / 2 + 2]; __shared__ u32 s_rn[4][RW / 2 + 2]; __shared__ u32 s_odd[4][RW / 2 + 2];
+    __shared__ u8 s_pen[4][RQ]; __shared__ u8 s_pentab[128]; __shared__ u32 s_w[4][X::WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 128; i += 256) s_pentab[i] = E.pen_tab[i];
+    __syncthreads();
+    const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
+    for (u64 i0 = begin + (u64)blockIdx.x * 4; i0 < end; i0 += (u64)gridDim.x * 4) {      // block-uniform trip count (the barrier below)
+        const u64 ii = i0 + wv;                                   // wave = item
+        const bool live = ii < end && ii - begin < cap_xrec;
+        if (live) {
+            const ItemDev it = E.items[ii];
+            const LocusDev L = E.loci[it.locus];
+            const u32 lw = E.ret_len[it.ret]; const int n = (int)(lw & 0x7FFFu);
+            const u8 state = E.item_state[ii];
+            const int pen_def = stage_read_planes(E, P, it, n, s_rl[wv], s_rh[wv], s_rn[wv], s_odd[wv], s_pen[wv], s_pentab, lane, 64);
+            const int q0 = it.diag >> 5; const u32 rs = 32u - ((u32)it.diag & 31u);      // 1..32
+            u32* w = s_w[wv];
+            if (lane <= X::NBA) {
+                int q = q0 + lane; q = q < 0 ? 0 : (q > (int)L.pblocks ? (int)L.pblocks : q);
+                w[X::HB + lane] = L.hap_ok ? E.hap_blk[L.hblk_off + (u32)q] : 0u;
+            }
+            u32 any = 0;
+            if (lane <= NB) {
+                auto sh = [&](const u32* A) { const u64 v2 = ((u64)(lane < NB ? A[lane] : 0u) << 32) | (u64)(lane > 0 ? A[lane - 1] : 0u); return (u32)(v2 >> rs); };
+                auto vw = [&](int k) { const int c = n - 32 * k; return (k < 0 || k >= NB) ? 0u : (c >= 32 ? 0xFFFFFFFFu : (c > 0 ? ((1u << c) - 1u) : 0u)); };
+                const u32 rn_t = sh(s_rn[wv]), od_t = sh(s_odd[wv]);
+                w[X::PL + 4 * lane] = sh(s_rl[wv]); w[X::PL + 4 * lane + 1] = sh(s_rh[wv]); w[X::PL + 4 * lane + 2] = rn_t; w[X::PL + 4 * lane + 3] = od_t;
+                w[X::VR + lane] = (u32)((((u64)vw(lane) << 32) | (u64)vw(lane - 1)) >> rs);
+                any = rn_t | od_t;
+            }
+            const bool special = __any(any != 0) || L.has_n;
+            if (lane == 0) {
+                const bool res_ok = it.res_off + L.n_pad <= E.cap_res;
+                w[0] = ((state & IS_SINGLE) ? XF_SINGLE : 0u) | (res_ok ? XF_RESOK : 0u) | (L.hap_ok ? XF_HAPOK : 0u) | ((lw & 0x8000u) ? XF_READN : 0u)
+                     | (special ? XF_SPECIAL : 0u) | (it.strand ? XF_STRAND : 0u);
+                w[1] = (u32)n | ((u32)pen_def << 16); w[2] = (u32)it.diag; w[3] = it.ret; w[4] = it.locus; w[5] = (u32)it.res_off; w[6] = (u32)(it.res_off >> 32);
+                w[7] = L.a_begin; w[8] = L.n_alleles; w[9] = L.n_pad; w[10] = L.hap_off; w[11] = (u32)L.hid_off; w[12] = (u32)(L.hid_off >> 32);
+                w[13] = (u32)E.floor_tab[n]; w[14] = L.pblocks; w[15] = L.hap_win[NB > 5 ? 1 : 0];
+            }
+        }
+        __syncthreads();
+        if (live) {
+            u32* dst = xrec + (ii - begin) * X::WORDS;
+            for (int j = lane; j < X::WORDS; j += 64) dst[j] = s_w[wv][j];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- Block-haplotype form of the ungapped extension (round 4).  The consumer, metamlst.py:133-151, needs one score per
+// allele, and the alleles of a locus differ by a few SNPs (metaMLST_functions.py:149-161 dumps them one by one): a 32-base
+// block of a 300-allele locus has ~55 distinct contents, of a 1,430-allele locus ~180 (profiles/round4/hap_counts.md).
+// The Kadane recurrence on the packed value is max-plus linear: a block maps the running value v to max(v + T, R) and
+// the best value seen so far to max(best, v + Pm, B) -- four integers, exact (sums and maxima of the same terms the
+// column-by-column walk adds and compares).  So a work item (1) has the READ shifted onto the allele's block grid, once
+// (k_ext_prep); (2) scores every distinct haplotype of every covered block (lanes = haplotypes, summaries to LDS);
+// (3) composes each allele from its 5-6 (10-11) summaries: one 16-byte LDS read and five integer operations per block.
+// The mismatch count of the full overlap is minus the low 16 bits of the summed T (every mismatch subtracts
+// (penalty << 16) + 1).  Pairs whose gap-trigger test needs the aligned span go through ungapped_planes<TRACK> as before.
+__device__ inline int4 hap_summary(const KParams& P, const HapRec h, u32 rl, u32 rh, u32 rn, u32 od, u32 vr, const u8* s_pen, int pen_base,
+                                   int pen_def, bool special_any) {
+    const int MA = P.match_bonus << MLST_P_SHIFT, negMA = -MA;
+    const u32 lm = h.len >= 32u ? 0xFFFFFFFFu : ((1u << h.len) - 1u);
+    const u32 valid = vr & lm;                                  // columns that exist in the read and in the haplotype: one run of bits
+    u32 M = ((h.lo ^ rl) | (h.hi ^ rh) | rn | h.nm) & valid;
+    const int lo_c = __ffs((int)valid) - 1, hi_c = lo_c + __popc(valid);      // valid = 0: lo_c = hi_c = -1
+    // gu / gf: value on the path that never restarted (relative to v) / on the best path that did (absolute), both
+    // minus MA * (columns counted so far), so that the value just before column c is g + c * MA
+    int gu = mad24(lo_c, negMA, 0), gf = NEGP, Pm = NEGP, B = NEGP;
+    const int PDM = (pen_def << MLST_P_SHIFT) + 1 + MA, floorv = P0 - MA;
+    if (special_any) {
+        const u32 special = od | h.nm;
+        while (M) {
+            const int bit = __ffs((int)M) - 1; M &= M - 1;
+            const int tu = mad24(bit, MA, gu), tf = mad24(bit, MA, gf);
+            Pm = tu > Pm ? tu : Pm; B = tf > B ? tf : B;
+            int dm = PDM;
+            if ((special >> bit) & 1u) dm = ((((h.nm >> bit) & 1u) ? P.n_penalty : (int)s_pen[pen_base + bit]) << MLST_P_SHIFT) + 1 + MA;
+            gu -= dm;
+            int x = tf - dm; x = x > floorv ? x : floorv;          // max(value after the mismatch, P0) - MA
+            gf = mad24(bit, negMA, x);
+        }
+    } else {
+        while (M) {
+            const int bit = __ffs((int)M) - 1; M &= M - 1;
+            const int tu = mad24(bit, MA, gu), tf = mad24(bit, MA, gf);
+            Pm = tu > Pm ? tu : Pm; B = tf > B ? tf : B;
+            gu -= PDM;
+            int x = tf - PDM; x = x > floorv ? x : floorv;
+            gf = mad24(bit, negMA, x);
+        }
+    }
+    return make_int4(mad24(hi_c, MA, gu), mad24(hi_c, MA, gf), Pm, B);
+}
+
+// Profiling build only (-DMLST_EXT_TRACE, profiles/extend_phases.sh): shader-clock cycles a wave of k_extend spends in each
+// phase of an item, summed over all waves.  0 record, 1 requests + s_pen, 2 summaries, 3 composition, 4 counts + fused
+// accumulation, 5 hand-over to the next item, 6 items, 7 waves.
+#ifdef MLST_EXT_TRACE
+__device__ u64 g_ext_trace[8];
+#define XT_DECL u64 xt_[6] = {0, 0, 0, 0, 0, 0}; u64 xt_items = 0; u64 xt_t = __builtin_readcyclecounter()
+#define XT(k) do { const u64 now_ = __builtin_readcyclecounter(); xt_[k] += now_ - xt_t; xt_t = now_; } while (0)
+#define XT_ITEM xt_items++
+#define XT_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_ext_trace[k_], xt_[k_]); atomicAdd(&g_ext_trace[6], xt_items); atomicAdd(&g_ext_trace[7], 1ull); } } while (0)
+extern "C" int mlst_debug_ext_trace(uint64_t out[8], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ext_trace), 64) != hipSuccess) return -1;
+    if (reset) { u64 z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ext_trace), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define XT_DECL
+#define XT(k)
+#define XT_ITEM
+#define XT_FLUSH
+#endif
+#define R_TRACK 0x10000000u      /* k_extend, inside one item only: the pair's gap-trigger test needs the aligned span */
+
+template <int NB>
+__device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, const KParams& P, const u32 lds_recs, const u32 acc_cap, const u32* __restrict__ xrec, const u64 cap_xrec) {
+    typedef XRec<NB> X;
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
+    extern __shared__ int4 s_hap[];                // haplotype summaries of the current item (lds_recs of them + the identity)
     __shared__ u32 s_rl[RW / 2 + 2]; __shared__ u32 s_rh[RW / 2 + 2]; __shared__ u32 s_rn[RW / 2 + 2]; __shared__ u32 s_odd[RW / 2 + 2];
     __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
     __shared__ u32 s_cnt[16][3];
+    __shared__ __attribute__((aligned(16))) u32 s_x[2][X::WORDS];      // the records of the current and of the next item
+    __shared__ u64 s_ii[2];
     const int tid = threadIdx.x, nthr = blockDim.x, nwv = blockDim.x >> 6;      // 64..1024 threads per work item
     for (int i = tid; i < 128; i += nthr) s_pentab[i] = E.pen_tab[i];
     u64 c_tot = 0, c_ign = 0;                     // block-level counters, flushed once at the end (thread 0)
-    const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
-    // Work queue: items cost different amounts (mismatch density, allele count of the locus), so blocks take the
-    // next item from a counter instead of a fixed stride.  The ticket for item k+1 is drawn while item k is staged.
-    __shared__ u64 s_next;
+    const u64 begin = E.ctr->items_done;
+    u64 end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
+    if (end - begin > cap_xrec) end = begin + cap_xrec;      // (the host flags the overflow: see mlst_submit_packed_device)
+    // Work queue: items cost different amounts (mismatch density, allele count of the locus), so blocks take the next
+    // item from a counter instead of a fixed stride; 32 counters in separate lines, own one first, then the others'.
+    // Tickets are drawn two items ahead: the item after the current one is known when the current one starts, so its
+    // record is fetched while the current one is worked on.
     u32 myq = blockIdx.x % EXT_Q, tried = 0;      // thread 0 only: current queue, exhausted queues seen in a row
-    if (tid == 0) s_next = begin + myq + (u64)EXT_Q * atomicAdd(&E.ctr->ext_q[myq][0], 1ull);
-    __syncthreads();
-    u64 ii = uniform_u64(s_next);                 // readfirstlane: keeps the per-item descriptor loads and index math scalar
-    if (ii >= end) {                              // own queue already empty: steal (block-uniform branch)
-        if (tid == 0) {
-            u64 nx = ii;
-            while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal(E, myq, begin, end); }
-            s_next = nx; tried = 0;
-        }
-        __syncthreads();
-        ii = uniform_u64(s_next);
+    auto resolve = [&](u64 ticket) -> u64 {       // thread 0: item of a ticket of queue myq; moves on to other queues when it is past the end
+        u64 nx = begin + myq + (u64)EXT_Q * ticket;
+        while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal(E, myq, begin, end); }
+        if (nx >= end) nx = end; else tried = 0;
+        return nx;
+    };
+    if (tid == 0) {
+        s_ii[0] = resolve(atomicAdd(&E.ctr->ext_q[myq][0], 1ull));
+        s_ii[1] = tried < EXT_Q ? resolve(atomicAdd(&E.ctr->ext_q[myq][0], 1ull)) : end;
     }
+    __syncthreads();
+    u64 ii = uniform_u64(s_ii[0]);
+    if (ii < end) for (int j = tid; j < X::WORDS; j += nthr) s_x[0][j] = xrec[(ii - begin) * X::WORDS + j];
+    __syncthreads();
+    int cur = 0;
+    XT_DECL;
     while (ii < end) {                            // block-uniform
-        u64 ticket = 0;
-        if (tid == 0) ticket = atomicAdd(&E.ctr->ext_q[myq][0], 1ull);
-        ItemDev it = E.items[ii];
-        const LocusDev L = E.loci[it.locus];
-        u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu); bool read_has_n = (lw & 0x8000u) != 0;
-        u8 state = E.item_state[ii];
-        __syncthreads();
-        const int pen_def = __builtin_amdgcn_readfirstlane(stage_read_planes(E, P, it, n, s_rl, s_rh, s_rn, s_odd, s_pen, s_pentab, tid, nthr));
-        __syncthreads();
-        const bool res_ok = it.res_off + L.n_pad <= E.cap_res;      // else flagged by k_seed
-        const int floor_n = E.floor_tab[n];
-        u32 rl[NB], rh[NB], od[NB], rn[NB];       // block-uniform read planes, held in scalar registers
+        XT_ITEM;
+        const u64 ii_next = uniform_u64(s_ii[cur ^ 1]);
+        // the next item's record: requested now, parked in LDS at the end of this item
+        u32 pf[(X::WORDS + 63) / 64];
         #pragma unroll
-        for (int w = 0; w < NB; w++) {
-            rl[w] = __builtin_amdgcn_readfirstlane(s_rl[w]); rh[w] = __builtin_amdgcn_readfirstlane(s_rh[w]);
-            od[w] = __builtin_amdgcn_readfirstlane(s_odd[w]);
-            rn[w] = read_has_n ? __builtin_amdgcn_readfirstlane(s_rn[w]) : 0u;
-        }
-        u32 nrec = 0, ndp = 0;
-        for (u32 a = tid; res_ok && a < L.n_alleles; a += nthr) {
-            int m = (int)E.allele_len[L.a_begin + a];
-            int mm, bs, be;
-            int best = L.has_n ? ungapped_planes<NB, false, true>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be)
-                               : ungapped_planes<NB, false, false>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
-            int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
-            bool need_dp = P.trig < 0;
-            if (!need_dp && mm > P.trig && score >= floor_n) {       // rare: the policy needs the aligned span
-                if (L.has_n) ungapped_planes<NB, true, true>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
-                else ungapped_planes<NB, true, false>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
-                need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
-            }
+        for (int k = 0; k < (X::WORDS + 63) / 64; k++) { pf[k] = 0; if (ii_next < end && tid + 64 * k < X::WORDS && tid < 64) pf[k] = xrec[(ii_next - begin) * X::WORDS + tid + 64 * k]; }
+        u64 ticket = 0;
+        if (tid == 0 && tried < EXT_Q) ticket = atomicAdd(&E.ctr->ext_q[myq][0], 1ull);
+        asm volatile("" ::: "memory");
+        const u32* x = s_x[cur];
+        const uint4 h0 = *reinterpret_cast<const uint4*>(x), h1 = *reinterpret_cast<const uint4*>(x + 4), h2 = *reinterpret_cast<const uint4*>(x + 8), h3 = *reinterpret_cast<const uint4*>(x + 12);
+        const u32 flags = __builtin_amdgcn_readfirstlane(h0.x);
+        const int n = __builtin_amdgcn_readfirstlane(h0.y & 0xFFFFu), pen_def = __builtin_amdgcn_readfirstlane(h0.y >> 16);
+        const int diag = __builtin_amdgcn_readfirstlane((int)h0.z);
+        const u32 ret = __builtin_amdgcn_readfirstlane(h0.w);
+        const u64 res_off = ((u64)(u32)__builtin_amdgcn_readfirstlane(h1.z) << 32) | (u32)__builtin_amdgcn_readfirstlane(h1.y);
+        const u32 a_begin = __builtin_amdgcn_readfirstlane(h1.w), n_alleles = __builtin_amdgcn_readfirstlane(h2.x), n_pad = __builtin_amdgcn_readfirstlane(h2.y);
+        const int floor_n = __builtin_amdgcn_readfirstlane((int)h3.y);
+        const bool res_ok = flags & XF_RESOK, read_has_n = flags & XF_READN;
+        const bool use_hap = res_ok && (flags & XF_HAPOK) && (u32)__builtin_amdgcn_readfirstlane(h3.w) <= lds_recs;      // block-uniform
+        u32 nrec = 0, ndp = 0, ntrack = 0;        // per wave (counted with ballots: scalar registers)
+        // what follows an alignment, for both forms of it: the gap-trigger policy, the result word, the banded-SW worklist
+        // (called by every lane of a turn, `valid` or not: the counts are kept per wave, in every lane's copy)
+        auto emit_pair = [&](const u32 a, const int score, const int xm, const int xo, bool need_dp, const bool valid) {
             u32 r = pack_result(score, xm, xo);
-            if (need_dp) { r |= R_NEEDDP; ndp++; }
-            else if (score >= floor_n && score > 0) { r |= R_REC; nrec++; }
-            // banded-SW worklist: one returning atomic per wave, not per pair
-            u64 wm = __ballot(need_dp);
+            need_dp = need_dp && valid;
+            const bool is_rec = valid && !need_dp && score >= floor_n && score > 0;
+            if (need_dp) r |= R_NEEDDP; else if (is_rec) r |= R_REC;
+            nrec += (u32)__popcll(__ballot(is_rec));
+            const u64 wm = __ballot(need_dp);      // banded-SW worklist: one returning atomic per wave, not per pair
             if (wm) {
+                ndp += (u32)__popcll(wm);
                 int lane = tid & 63, leader = __ffsll((long long)wm) - 1; u64 base = 0;
                 if (lane == leader) base = atomicAdd(&E.ctr->n_dp, (u64)__popcll(wm));
                 base = __shfl(base, leader);
                 if (need_dp) { u64 slot = base + __popcll(wm & ((1ull << lane) - 1));
                                if (slot < E.cap_dp) E.dp_list[slot] = (ii << 20) | (u64)a; else atomicOr(&E.ctr->err, 8ull); }
             }
-            E.res[it.res_off + a] = r;
+            if (valid) E.res[res_off + a] = r;
+        };
+        // the read in its own coordinates (planes in LDS, s_pen): what rounds 1-3 staged for every item, now only for the
+        // items that take the pair-by-pair path or hold a pair whose policy test needs the aligned span
+        auto stage_old = [&]() {
+            ItemDev it; it.res_off = res_off; it.ret = ret; it.locus = __builtin_amdgcn_readfirstlane(h1.x); it.diag = diag; it.strand = (flags & XF_STRAND) ? 1 : 0; it.votes = 0;
+            __syncthreads();
+            stage_read_planes(E, P, it, n, s_rl, s_rh, s_rn, s_odd, s_pen, s_pentab, tid, nthr);
+            __syncthreads();
+        };
+        auto pairs_loop = [&](const bool only_marked) {
+            const LocusDev L = E.loci[__builtin_amdgcn_readfirstlane(h1.x)];
+            u32 rl[NB], rh[NB], od[NB], rn[NB];       // block-uniform read planes, held in scalar registers
+            #pragma unroll
+            for (int w = 0; w < NB; w++) {
+                rl[w] = __builtin_amdgcn_readfirstlane(s_rl[w]); rh[w] = __builtin_amdgcn_readfirstlane(s_rh[w]);
+                od[w] = __builtin_amdgcn_readfirstlane(s_odd[w]);
+                rn[w] = read_has_n ? __builtin_amdgcn_readfirstlane(s_rn[w]) : 0u;
+            }
+            for (u32 a = tid; a < n_alleles; a += nthr) {
+                const bool valid = !only_marked || (E.res[res_off + a] & R_TRACK);
+                int m = (int)E.allele_len[a_begin + a];
+                int mm = 0, bs = 0, be = 0, best = P0;
+                if (valid) best = L.has_n ? ungapped_planes<NB, false, true>(E, P, L, a, m, n, diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be)
+                                         : ungapped_planes<NB, false, false>(E, P, L, a, m, n, diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
+                const int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
+                bool need_dp = P.trig < 0;
+                if (valid && !need_dp && mm > P.trig && score >= floor_n) {       // rare: the policy needs the aligned span
+                    if (L.has_n) ungapped_planes<NB, true, true>(E, P, L, a, m, n, diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
+                    else ungapped_planes<NB, true, false>(E, P, L, a, m, n, diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
+                    need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, diag, bs, be);
+                }
+                emit_pair(a, score, xm, xo, need_dp, valid);
+            }
+        };
+        XT(0);
+        bool done_fast = false;                   // the item was accumulated in the composition pass itself (below)
+        if (use_hap) {
+            // ---- block-haplotype path: block t of the item is allele block (diag >> 5) + t
+            const int q0 = diag >> 5;
+            const u32 pblocks = __builtin_amdgcn_readfirstlane(h3.z);
+            const u64 hid_off = ((u64)(u32)__builtin_amdgcn_readfirstlane(h3.x) << 32) | (u32)__builtin_amdgcn_readfirstlane(h2.w);
+            // haplotype ids: rows of block PAIRS (low half = even block), lanes = alleles; the item's NB + 1 blocks lie in NR
+            // rows from row q0 >> 1 on.  Uniform row pointers + the lane's offset: no vector address arithmetic per load.
+            constexpr int NR = (NB + 3) / 2;
+            GP<const u32>::G* idrow[NR];
+            #pragma unroll
+            for (int j = 0; j < NR; j++) { int r = (q0 >> 1) + j; const int nrows = (int)((pblocks + 1) >> 1); r = r < 0 ? 0 : (r >= nrows ? nrows - 1 : r); idrow[j] = E.hap_id.g() + hid_off + (u64)(u32)r * n_pad; }
+            const u32 odd16 = ((u32)q0 & 1u) * 16u;
+            auto load_ids = [&](const u32 a, u32 (&w)[NR]) {      // unconditional (a clamped): the compiler can count the loads in flight
+                const u32 ac = a < n_alleles ? a : n_alleles - 1;
+                #pragma unroll
+                for (int j = 0; j < NR; j++) w[j] = ld_row(idrow[j], ac * 4u);
+            };
+            u32 hb[NB + 2];
+            #pragma unroll
+            for (int t = 0; t <= NB + 1; t++) hb[t] = __builtin_amdgcn_readfirstlane(x[X::HB + t]);
+            auto recs = E.hap_rec.g() + __builtin_amdgcn_readfirstlane(h2.z);
+            u32 maxcnt = 0;
+            #pragma unroll
+            for (int t = 0; t <= NB; t++) { const u32 c = hb[t + 1] - hb[t]; maxcnt = c > maxcnt ? c : maxcnt; }
+            const bool special_any = flags & XF_SPECIAL;
+            if (special_any) {                     // per-column penalties of the read (Phred of a column that is not the read's usual one, N)
+                auto rq = E.ret_quals.g() + (u64)ret * RQ;
+                for (int i = tid; i < n; i += nthr) { const u8 qb = rq[(flags & XF_STRAND) ? n - 1 - i : i]; s_pen[i] = (qb >> 7) ? (u8)P.n_penalty : s_pentab[qb & 0x7F]; }
+            }
+            u32 Wn[NR];                            // ids of this thread's first allele: they do not depend on the summaries
+            load_ids((u32)tid, Wn);
+            const u32 ident = hb[NB + 1] - hb[0];   // one slot behind the summaries: the identity, for blocks outside the allele
+            u32 sbase[NB + 1], wid[NB + 1];        // per block: first summary, width of an id (0 = block outside the allele: identity)
+            #pragma unroll
+            for (int t = 0; t <= NB; t++) { const bool present = hb[t + 1] != hb[t]; sbase[t] = present ? hb[t] - hb[0] : ident; wid[t] = present ? 16u : 0u; }
+            if (tid == 0) s_hap[ident] = make_int4(0, NEGP, NEGP, NEGP);
+            if (special_any) lds_barrier();
+            XT(1);
+            for (u32 hb0 = 0; hb0 < maxcnt; hb0 += nthr) {
+                const u32 hh = hb0 + tid;
+                uint4 rc[NB + 1];
+                #pragma unroll
+                for (int t = 0; t <= NB; t++) {
+                    rc[t] = make_uint4(0, 0, 0, 0);
+                    if (hh < hb[t + 1] - hb[t]) rc[t] = *reinterpret_cast<GP<const uint4>::G*>(recs + hb[t] + hh);
+                }
+                #pragma unroll
+                for (int t = 0; t <= NB; t++) { TIE4(rc[t].x, rc[t].y, rc[t].z, rc[t].w); }
+                #pragma unroll
+                for (int t = 0; t <= NB; t++) {
+                    if (hh < hb[t + 1] - hb[t]) {
+                        const uint4 sp = *reinterpret_cast<const uint4*>(x + X::PL + 4 * t); HapRec hr; hr.lo = rc[t].x; hr.hi = rc[t].y; hr.nm = rc[t].z; hr.len = rc[t].w;
+                        s_hap[(hb[t] - hb[0]) + hh] = hap_summary(P, hr, sp.x, sp.y, sp.z, sp.w, x[X::VR + t], s_pen, 32 * t - (int)((u32)diag & 31u), pen_def, special_any);
+                    }
+                }
+            }
+            lds_barrier();                         // (not __syncthreads(): that would also wait for the loads in flight)
+            XT(2);
+            // composition of one allele from the summaries of its blocks -> packed best value, mismatches of the full overlap
+            auto compose = [&](const u32 (&w)[NR], int& best, int& mm) {
+                u32 wp[NB / 2 + 1];
+                #pragma unroll
+                for (int k = 0; k <= NB / 2; k++) wp[k] = __builtin_amdgcn_alignbit(k + 1 < NR ? w[k + 1 < NR ? k + 1 : 0] : 0u, w[k], odd16);
+                int4 S[NB + 1];
+                #pragma unroll
+                for (int t = 0; t <= NB; t++) S[t] = s_hap[sbase[t] + __builtin_amdgcn_ubfe(wp[t >> 1], 16u * (t & 1), wid[t])];
+                int v = P0, ts = 0; best = P0;
+                #pragma unroll
+                for (int t = 0; t <= NB; t++) {
+                    const int c1 = v + S[t].z; best = c1 > best ? c1 : best; best = S[t].w > best ? S[t].w : best;
+                    const int c2 = v + S[t].x; v = c2 > S[t].y ? c2 : S[t].y; ts += S[t].x;
+                }
+                best = v > best ? v : best;
+                mm = (-ts) & 0xFFFF;
+            };
+            bool slow = !(flags & XF_SINGLE) || P.trig < 0 || n_alleles > acc_cap;
+            if (!slow) {
+                // A read with one work item (nearly all): what metamlst.py:101-130 would add for each record is noted beside the
+                // summaries (LDS) while the alleles are composed, and added once the item's counts say that no pair needs the
+                // aligned span or the banded SW and that the read has not exactly one record (Q1: column 15 would then be XO).
+                // No result word is stored, none is read back; the additions leave in one burst at the end of the item (inside
+                // the pass every turn waited for the additions of the turn before: vmcnt counts them with the loads, in order).
+                u16* s_acc = reinterpret_cast<u16*>(s_hap + lds_recs + 1);
+                const bool n_ok = n >= P.min_read_len;
+                u32 nacc = 0;
+                for (u32 a = tid; a < n_alleles; a += nthr) {
+                    u32 W[NR];
+                    #pragma unroll
+                    for (int j = 0; j < NR; j++) W[j] = Wn[j];
+                    load_ids(a + nthr, Wn);                 // next turn's ids
+                    asm volatile("" ::: "memory");
+                    int best, mm; compose(W, best, mm);
+                    const int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF);
+                    const bool cand = score >= floor_n && score > 0;
+                    const bool track = cand && P.trig >= 0 && mm > P.trig;
+                    const bool rec = cand && !track, ok = rec && n_ok && score >= P.minscore && xm <= P.max_xm;
+                    nrec += (u32)__popcll(__ballot(rec)); nacc += (u32)__popcll(__ballot(ok)); ntrack += (u32)__popcll(__ballot(track));
+                    s_acc[a] = ok ? (u16)score : (u16)0;
+                }
+                // (a lane's copy of a count holds the ballots of the turns in which the lane was active: lane 0 has them all)
+                u32 tot_rec = __builtin_amdgcn_readfirstlane(nrec), tot_acc = __builtin_amdgcn_readfirstlane(nacc), tot_track = __builtin_amdgcn_readfirstlane(ntrack);
+                if (nwv > 1) {
+                    if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = tot_rec; s_cnt[tid >> 6][1] = tot_acc; s_cnt[tid >> 6][2] = tot_track; }
+                    __syncthreads();
+                    tot_rec = tot_acc = tot_track = 0;
+                    for (int w = 0; w < nwv; w++) { tot_rec += s_cnt[w][0]; tot_acc += s_cnt[w][1]; tot_track += s_cnt[w][2]; }
+                    __syncthreads();
+                }
+                if (tot_track == 0 && !(P.quirk && tot_rec == 1)) {      // block-uniform
+                    if (tot_acc) for (u32 a = tid; a < n_alleles; a += nthr) {      // (each thread reads back what it wrote)
+                        const u32 sc = s_acc[a];
+                        if (sc) { atomicAdd((u64*)&E.sum_score[a_begin + a], (u64)sc); atomicAdd(&E.n_hits[a_begin + a], 1u); }
+                    }
+                    if (tid == 0) {
+                        if (tot_rec) atomicAdd(&E.ret_nrec[ret], tot_rec);      // per-read record count (Q1)
+                        c_tot += tot_rec; c_ign += tot_rec - tot_acc;
+                        E.item_state[ii] = (u8)(IS_SINGLE | IS_DONE | (tot_acc ? IS_ACC : 0));
+                    }
+                    done_fast = true;
+                } else { slow = true; nrec = 0; ntrack = 0; }
+            }
+            if (slow) {
+                if (flags & XF_SINGLE) load_ids((u32)tid, Wn);      // (a read with several items comes here with its first ids still waiting)
+                for (u32 a = tid; a < n_alleles; a += nthr) {
+                    u32 W[NR];
+                    #pragma unroll
+                    for (int j = 0; j < NR; j++) W[j] = Wn[j];
+                    load_ids(a + nthr, Wn);
+                    asm volatile("" ::: "memory");
+                    int best, mm; compose(W, best, mm);
+                    const int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
+                    const bool track = P.trig >= 0 && mm > P.trig && score >= floor_n;      // rare: the policy needs the aligned span
+                    const u64 tm = __ballot(track);
+                    if (tm) { ntrack += (u32)__popcll(tm); if (track) E.res[res_off + a] = R_TRACK; }
+                    emit_pair(a, score, xm, xo, P.trig < 0, !track);
+                }
+                ntrack = __builtin_amdgcn_readfirstlane(ntrack);      // (lane 0 took part in every turn: its copy is the wave's count)
+                if (nwv > 1) {
+                    if ((tid & 63) == 0) s_cnt[tid >> 6][2] = ntrack;
+                    __syncthreads();
+                    ntrack = 0; for (int w = 0; w < nwv; w++) ntrack += s_cnt[w][2];
+                }
+                if (ntrack) { stage_old(); pairs_loop(true); }      // block-uniform
+            }
+        } else if (res_ok) {
+            stage_old();
+            pairs_loop(false);
         }
-        nrec = wave_sum_u32(nrec); ndp = wave_sum_u32(ndp);
+        XT(3);
+        if (!done_fast) {                         // block-uniform
         if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = nrec; s_cnt[tid >> 6][1] = ndp; }
         __syncthreads();
         u32 tot_rec = 0, tot_dp = 0;
         for (int w = 0; w < nwv; w++) { tot_rec += s_cnt[w][0]; tot_dp += s_cnt[w][1]; }
-        if (tid == 0 && tot_rec) atomicAdd(&E.ret_nrec[it.ret], tot_rec);   // per-read record count (Q1)
+        if (tid == 0 && tot_rec) atomicAdd(&E.ret_nrec[ret], tot_rec);   // per-read record count (Q1)
         // Fused accumulation (metamlst.py:101-130) when everything about this read is known here:
         // it has a single work item and no pair is waiting for the banded SW.
-        if (res_ok && (state & IS_SINGLE) && tot_dp == 0) {
+        if (res_ok && (flags & XF_SINGLE) && tot_dp == 0) {
             bool use_xo = P.quirk && tot_rec == 1;
             u32 acc = 0, ign = 0;
-            for (u32 a = tid; a < L.n_alleles; a += nthr) {
-                u32 r = E.res[it.res_off + a];
-                if (!(r & R_REC)) continue;
-                if (accept_rec(P, r, n, use_xo)) {
-                    atomicAdd((u64*)&E.sum_score[L.a_begin + a], (u64)(r & 0x3FF));
-                    atomicAdd(&E.n_hits[L.a_begin + a], 1u);
-                    acc++;
-                } else ign++;
+            for (u32 a = tid; a < n_alleles; a += nthr) {
+                u32 r = E.res[res_off + a];
+                const bool rec = r & R_REC, ok = rec && accept_rec(P, r, n, use_xo);
+                if (ok) {
+                    atomicAdd((u64*)&E.sum_score[a_begin + a], (u64)(r & 0x3FF));
+                    atomicAdd(&E.n_hits[a_begin + a], 1u);
+                }
+                acc += (u32)__popcll(__ballot(ok)); ign += (u32)__popcll(__ballot(rec && !ok));
             }
-            acc = wave_sum_u32(acc); ign = wave_sum_u32(ign);
             __syncthreads();
             if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = acc; s_cnt[tid >> 6][1] = ign; }
             __syncthreads();
@@ -1771,28 +2111,30 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                 u32 A = 0, I = 0;
                 for (int w = 0; w < nwv; w++) { A += s_cnt[w][0]; I += s_cnt[w][1]; }
                 c_tot += tot_rec; c_ign += I;
+                const u8 state = (u8)((flags & XF_SINGLE) ? IS_SINGLE : 0);
                 E.item_state[ii] = (u8)(state | IS_DONE | (A ? IS_ACC : 0));
             }
         }
-        if (tid == 0) {
-            u64 nx = begin + myq + (u64)EXT_Q * ticket;
-            while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal(E, myq, begin, end); }
-            s_next = nx; tried = 0;
         }
-        __syncthreads();
-        ii = uniform_u64(s_next);
+        XT(4);
+        // hand over to the next item: its record goes to the free LDS slot, the ticket drawn at the top names the item after it
+        #pragma unroll
+        for (int k = 0; k < (X::WORDS + 63) / 64; k++) if (tid < 64 && tid + 64 * k < X::WORDS) s_x[cur ^ 1][tid + 64 * k] = pf[k];
+        if (tid == 0) s_ii[cur] = tried < EXT_Q ? resolve(ticket) : end;
+        lds_barrier();                            // (LDS only: the additions of this item are still on their way)
+        ii = ii_next; cur ^= 1;
+        XT(5);
     }
+    XT_FLUSH;
     if (tid == 0) {
         if (c_tot) atomicAdd(&E.ctr->cnt[MLST_CNT_TOTAL_RECORDS], c_tot);
         if (c_ign) atomicAdd(&E.ctr->cnt[MLST_CNT_IGNORED], c_ign);
     }
 }
 
-// Two instantiations: reads up to 160 bases (five 32-base blocks; held to 72 VGPRs = 7 waves per SIMD, which measured
-// 3 % faster than the 80 the allocator takes when left alone) and up to MLST_MAX_READ_LEN.
-__attribute__((amdgpu_waves_per_eu(7, 7)))
-__global__ __launch_bounds__(1024) void k_extend_160(const EngineDev* __restrict__ Ep, KParams P) { extend_body<5>(Ep, P); }
-__global__ __launch_bounds__(1024) void k_extend_320(const EngineDev* __restrict__ Ep, KParams P) { extend_body<RW / 2>(Ep, P); }
+// Two instantiations: reads up to 160 bases (five 32-base blocks) and up to MLST_MAX_READ_LEN.
+__global__ __launch_bounds__(1024) void k_extend_160(const EngineDev* __restrict__ Ep, KParams P, u32 lds_recs, u32 acc_cap, const u32* __restrict__ xrec, u64 cap_xrec) { extend_body<5>(Ep, P, lds_recs, acc_cap, xrec, cap_xrec); }
+__global__ __launch_bounds__(1024) void k_extend_320(const EngineDev* __restrict__ Ep, KParams P, u32 lds_recs, u32 acc_cap, const u32* __restrict__ xrec, u64 cap_xrec) { extend_body<RW / 2>(Ep, P, lds_recs, acc_cap, xrec, cap_xrec); }
 
 template <int CTRL, int ROW_MASK = 0xF> __device__ inline int dpp_i32(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
@@ -2566,6 +2908,10 @@ struct mlst_handle {
     u32* d_arena = nullptr; u32* d_planes = nullptr; u32* d_nmask = nullptr; u16* d_allele_len = nullptr; u32* d_allele_locus = nullptr;
     LocusDev* d_loci = nullptr; uint4* d_sieve = nullptr; u32* d_bitmap = nullptr; u32* d_gbitmap = nullptr; u64* d_keys = nullptr; u32* d_vals = nullptr; u32* d_posts = nullptr;
     int* d_floor = nullptr; u8* d_pen = nullptr; u8* d_ascii = nullptr; u64* d_aoff = nullptr;
+    HapRec* d_hap_rec = nullptr; u32* d_hap_blk = nullptr; u32* d_hap_id = nullptr; u64 bytes_hap = 0, n_hap_rec = 0; u32 hap_win_max[2] = {0, 0}, hap_loci = 0;
+    u32 ext_lds_recs[2] = {0, 0};                // k_extend_160 / _320: haplotype summaries (16 B each) the launch keeps in LDS
+    u32 ext_acc_cap = 0;                         // alleles per locus for which k_extend keeps the pending additions of an item in LDS (2 B each)
+    u32* d_xrec[2] = {nullptr, nullptr}; u64 cap_xrec[2] = {0, 0};      // item records of k_ext_prep (one per work item of a submission), per instantiation
     u64 bytes_arena = 0, bytes_sieve = 0, bytes_table = 0; double bitmap_fill = 0.0;
     EngineDev E; EngineDev* d_E = nullptr;      // host copy and its device-resident twin
     bool have_ref = false, have_state = false;
@@ -2620,7 +2966,7 @@ struct mlst_handle {
     GraphSlot g_submit, g_typing; bool use_graphs = true;
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool;
-    double k_ms[12] = {0}; u64 k_n[12] = {0};      // see mlst_get_kernel_time
+    double k_ms[16] = {0}; u64 k_n[16] = {0};      // see mlst_get_kernel_time
     double wall_khz = 100000.0;                  // wall_clock64 rate (hipDeviceAttributeWallClockRate)
 };
 
@@ -2733,6 +3079,7 @@ static void free_ref(mlst_handle* h) {
     hipFree(h->d_arena); hipFree(h->d_planes); hipFree(h->d_nmask); hipFree(h->d_allele_len); hipFree(h->d_allele_locus); hipFree(h->d_loci);
     hipFree(h->d_sieve); hipFree(h->d_bitmap); h->d_bitmap = nullptr; hipFree(h->d_gbitmap); h->d_gbitmap = nullptr; hipFree(h->d_keys); hipFree(h->d_vals); hipFree(h->d_posts); hipFree(h->d_floor); hipFree(h->d_pen);
     hipFree(h->d_ascii); hipFree(h->d_aoff);
+    hipFree(h->d_hap_rec); hipFree(h->d_hap_blk); hipFree(h->d_hap_id); h->d_hap_rec = nullptr; h->d_hap_blk = nullptr; h->d_hap_id = nullptr;
     hipFree(h->d_rfilter); h->d_rfilter = nullptr;
     hipFree(h->d_allele_no); hipFree(h->d_auto_chosen); hipFree(h->d_fixed_colbase); hipFree(h->d_auto_counts); hipFree(h->d_auto_letters);
     hipFree(h->d_compact_colbase); hipFree(h->d_compact_chosen); hipFree(h->d_compact_info); h->d_compact_colbase = nullptr; h->d_compact_chosen = nullptr; h->d_compact_info = nullptr;
@@ -2756,6 +3103,7 @@ static void free_state(mlst_handle* h) {
     hipFree(E.ret_bases); hipFree(E.ret_quals); hipFree(E.ret_len); hipFree(E.ret_ridx); hipFree(E.ret_nrec);
     hipFree(E.ret_mate); hipFree(E.ret_item0); hipFree(E.ret_nitems); E.ret_mate = nullptr; E.ret_item0 = nullptr; E.ret_nitems = nullptr;
     hipFree(E.items); hipFree(E.item_state); hipFree(E.res); hipFree(E.dp_list);
+    for (int k = 0; k < 2; k++) { hipFree(h->d_xrec[k]); h->d_xrec[k] = nullptr; h->cap_xrec[k] = 0; }
     hipFree(h->d_locus_chosen); hipFree(h->d_locus_colbase); hipFree(h->d_pl_list); hipFree(h->d_tb);
     E.sum_score = nullptr; E.n_hits = nullptr; E.locus_len = E.locus_first = nullptr; E.ctr = nullptr; E.ret_bases = nullptr; E.ret_quals = nullptr;
     E.ret_len = nullptr; E.ret_ridx = nullptr; E.ret_nrec = nullptr; E.items = nullptr; E.item_state = nullptr; E.res = nullptr; E.dp_list = nullptr;
@@ -2799,6 +3147,8 @@ static int reset_sample_state(mlst_handle* h) {
 struct HostIndex {
     std::vector<LocusDev> loci; std::vector<u16> alen;
     std::vector<u32> arena, nmask, planes;
+    std::vector<HapRec> hap_rec; std::vector<u32> hap_blk; std::vector<u32> hap_id;      // block-haplotype tables
+    u32 hap_win_max[2] = {0, 0}; u32 hap_loci = 0;
     std::vector<u64> tkeys; std::vector<u32> tvals, posts; u32 tmask = 0;
     std::vector<u16> sv; u64 nb = 0; u32 smask = 0, sieve_chain = 0;      // fingerprint sieve; longest overflow walk of any key
     std::vector<u32> bitmap; double bitmap_fill = 0.0;                   // LDS half-seed bitmaps (small databases)
@@ -2858,11 +3208,14 @@ static std::shared_ptr<HostIndex> build_host_index(const uint8_t* ascii, const u
     // ---- per locus, in parallel: arena rows, seed pairs (unique within the locus)
     std::vector<std::vector<KP>> lkp(n_loci);
     std::vector<std::vector<std::pair<u32, u32>>> lnpos(n_loci);      // (allele, position) of non-ACGT characters
+    std::vector<std::vector<HapRec>> lhrec(n_loci); std::vector<std::vector<u32>> lhblk(n_loci); std::vector<std::vector<u32>> lhid(n_loci);
     {
         unsigned nthr = std::thread::hardware_concurrency(); if (nthr < 1) nthr = 1; if (nthr > 64) nthr = 64; if (nthr > n_loci) nthr = n_loci ? n_loci : 1;
         std::atomic<u32> next(0);
         auto work = [&]() {
             std::vector<u8> code; std::vector<u64> prev;
+            struct HK { HapRec r; u32 al; };
+            std::vector<HK> hk; std::vector<std::pair<u64, u32>> nmv;      // N-mask words of the locus, keyed (allele << 8) | block
             for (;;) {
                 const u32 l = next.fetch_add(1); if (l >= n_loci) break;
                 const LocusDev& L = loci[l]; std::vector<KP>& out = lkp[l];
@@ -2905,12 +3258,72 @@ static std::shared_ptr<HostIndex> build_host_index(const uint8_t* ascii, const u
                 }
                 std::sort(out.begin(), out.end(), [](const KP& x, const KP& y) { return x.key != y.key ? x.key < y.key : x.post < y.post; });
                 out.erase(std::unique(out.begin(), out.end(), [](const KP& x, const KP& y) { return x.key == y.key && x.post == y.post; }), out.end());
+                // ---- block-haplotype tables: the alleles of a locus differ by a few SNPs, so a 32-base block has far
+                // fewer distinct contents than the locus has alleles (profiles/round4/hap_counts.md); k_extend scores a
+                // read against every distinct block once and composes the alleles from those summaries
+                {
+                    nmv.clear();
+                    for (auto& ap : lnpos[l]) {
+                        const u64 key = ((u64)ap.first << 8) | (ap.second >> 5);
+                        if (nmv.empty() || nmv.back().first != key) nmv.push_back({key, 0u});
+                        nmv.back().second |= 1u << (ap.second & 31);
+                    }
+                    std::vector<HapRec>& hr = lhrec[l]; std::vector<u32>& hb = lhblk[l]; std::vector<u32>& hi_ = lhid[l];
+                    hb.assign(L.pblocks + 1, 0); hi_.assign((u64)((L.pblocks + 1) / 2) * L.n_pad, 0);
+                    bool ok = true;
+                    for (u32 q = 0; q < L.pblocks && ok; q++) {
+                        hk.resize(L.n_alleles);
+                        for (u32 al = 0; al < L.n_alleles; al++) {
+                            const int left = (int)alen[L.a_begin + al] - 32 * (int)q;
+                            HK& k = hk[al]; k.al = al; k.r.len = (u32)(left < 0 ? 0 : (left > 32 ? 32 : left));
+                            k.r.lo = planes[L.plane_off + (u64)(2 * q) * L.n_pad + al]; k.r.hi = planes[L.plane_off + (u64)(2 * q + 1) * L.n_pad + al]; k.r.nm = 0;
+                            if (!nmv.empty()) {
+                                const u64 key = ((u64)al << 8) | q;
+                                auto itn = std::lower_bound(nmv.begin(), nmv.end(), std::make_pair(key, 0u), [](const std::pair<u64, u32>& x, const std::pair<u64, u32>& y) { return x.first < y.first; });
+                                if (itn != nmv.end() && itn->first == key) k.r.nm = itn->second;
+                            }
+                        }
+                        auto less = [](const HK& x, const HK& y) {
+                            if (x.r.lo != y.r.lo) return x.r.lo < y.r.lo; if (x.r.hi != y.r.hi) return x.r.hi < y.r.hi;
+                            if (x.r.nm != y.r.nm) return x.r.nm < y.r.nm; return x.r.len < y.r.len; };
+                        std::sort(hk.begin(), hk.end(), less);
+                        u32 nh = 0;
+                        for (u32 i = 0; i < L.n_alleles; i++) {
+                            if (i == 0 || less(hk[i - 1], hk[i])) { if (nh >= 65535u) { ok = false; break; } hr.push_back(hk[i].r); nh++; }
+                            hi_[(u64)(q >> 1) * L.n_pad + hk[i].al] |= (nh - 1) << (16 * (q & 1));
+                        }
+                        hb[q + 1] = hb[q] + nh;
+                    }
+                    if (!ok) { hr.clear(); hb.clear(); hi_.clear(); }
+                }
             }
         };
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < nthr; t++) pool.emplace_back(work);
         work();
         for (auto& t : pool) t.join();
+    }
+    {   // lay the block-haplotype tables of the loci out one behind the other
+        u64 nrec = 0, nblk = 0, nid = 0;
+        for (u32 l = 0; l < n_loci; l++) { nrec += lhrec[l].size(); nblk += lhblk[l].size(); nid += lhid[l].size(); }
+        if (nrec >= (1ull << 28)) return bad(MLST_E_LIMIT, "block-haplotype table exceeds 2^28 records");
+        H->hap_rec.reserve(nrec ? nrec : 1); H->hap_blk.reserve(nblk ? nblk : 1); H->hap_id.reserve(nid ? nid : 1);
+        for (u32 l = 0; l < n_loci; l++) {
+            LocusDev& L = loci[l];
+            L.hap_ok = lhblk[l].empty() ? 0u : 1u; L.hap_off = (u32)H->hap_rec.size(); L.hblk_off = (u32)H->hap_blk.size(); L.hid_off = H->hap_id.size();
+            L.hap_win[0] = L.hap_win[1] = 0;
+            if (!L.hap_ok) continue;
+            const std::vector<u32>& hb = lhblk[l];
+            for (u32 q = 0; q < L.pblocks; q++) for (int k = 0; k < 2; k++) {
+                const u32 qe = std::min(L.pblocks, q + (k ? 11u : 6u)); L.hap_win[k] = std::max(L.hap_win[k], hb[qe] - hb[q]);
+            }
+            for (int k = 0; k < 2; k++) H->hap_win_max[k] = std::max(H->hap_win_max[k], L.hap_win[k]);
+            H->hap_loci++;
+            H->hap_rec.insert(H->hap_rec.end(), lhrec[l].begin(), lhrec[l].end()); H->hap_blk.insert(H->hap_blk.end(), hb.begin(), hb.end());
+            H->hap_id.insert(H->hap_id.end(), lhid[l].begin(), lhid[l].end());
+            std::vector<HapRec>().swap(lhrec[l]); std::vector<u32>().swap(lhid[l]);
+        }
+        if (H->hap_rec.empty()) H->hap_rec.push_back(HapRec{0, 0, 0, 0}); if (H->hap_blk.empty()) H->hap_blk.push_back(0); if (H->hap_id.empty()) H->hap_id.push_back(0);
     }
     for (u32 l = 0; l < n_loci; l++) if (!lnpos[l].empty()) { loci[l].has_n = 1; loci[l].nmask_off = nmask_words; nmask_words += (u64)loci[l].nwords * loci[l].n_pad; }
     std::vector<u32>& nmask = H->nmask; nmask.assign(nmask_words ? nmask_words : 1, 0);
@@ -3027,6 +3440,8 @@ static int sieve_kind_from_env() {
     return -1;
 }
 
+// dynamic LDS of k_extend_160 (k = 0) / _320: the haplotype summaries + the identity, then the pending additions of the item
+static size_t ext_lds_bytes(const mlst_handle* h, int k) { return (size_t)(h->ext_lds_recs[k] + 1) * 16 + (size_t)h->ext_acc_cap * 2; }
 // Build the device-resident reference: transposed 2-bit allele arena, N masks, seed sieve and exact seed table.
 extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const uint64_t* off, const uint32_t* locus_id,
                                    const uint32_t* species_id, const int32_t* allele_no, uint32_t n_alleles) {
@@ -3090,6 +3505,11 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     u64 abytes = off[n_alleles];
     HIPCHK(h, dmalloc(&h->d_ascii, abytes)); if (abytes) HIPCHK(h, hipMemcpy(h->d_ascii, ascii, abytes, hipMemcpyHostToDevice));
     HIPCHK(h, dmalloc(&h->d_aoff, (u64)n_alleles + 1)); HIPCHK(h, hipMemcpy(h->d_aoff, off, ((u64)n_alleles + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(h, dmalloc(&h->d_hap_rec, (u64)HI->hap_rec.size())); HIPCHK(h, hipMemcpy(h->d_hap_rec, HI->hap_rec.data(), HI->hap_rec.size() * sizeof(HapRec), hipMemcpyHostToDevice));
+    HIPCHK(h, dmalloc(&h->d_hap_blk, (u64)HI->hap_blk.size())); HIPCHK(h, hipMemcpy(h->d_hap_blk, HI->hap_blk.data(), HI->hap_blk.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, dmalloc(&h->d_hap_id, (u64)HI->hap_id.size())); HIPCHK(h, hipMemcpy(h->d_hap_id, HI->hap_id.data(), HI->hap_id.size() * 4, hipMemcpyHostToDevice));
+    h->bytes_hap = HI->hap_rec.size() * sizeof(HapRec) + HI->hap_blk.size() * 4 + HI->hap_id.size() * 4; h->n_hap_rec = HI->hap_rec.size();
+    h->hap_win_max[0] = HI->hap_win_max[0]; h->hap_win_max[1] = HI->hap_win_max[1]; h->hap_loci = HI->hap_loci;
     h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4 + HI->rfilter.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
     h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
     {   // device-side typing: allele numbers, one slot of max_len columns per locus
@@ -3110,6 +3530,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     h->bitmap_fill = HI->bitmap_fill;
     E.sieve = h->d_sieve; E.sieve_mask = smask; E.bitmap = h->d_bitmap; E.gbitmap = h->d_gbitmap; E.gbitmap_bits = gbitmap.empty() ? 0 : gbits; E.keys = h->d_keys; E.vals = h->d_vals; E.posts = h->d_posts; E.table_mask = tmask;
     E.floor_tab = h->d_floor; E.pen_tab = h->d_pen; E.n_alleles = n_alleles; E.n_loci = n_loci;
+    E.hap_rec = h->d_hap_rec; E.hap_blk = h->d_hap_blk; E.hap_id = h->d_hap_id;
     E.cap_ret = h->prm.max_retained_reads; E.cap_items = h->prm.max_items; E.cap_res = h->prm.max_pair_results; E.cap_dp = h->prm.max_items * 4;
     {   // statistics live in ONE device block so that a sample needs one memset pair and one D2H copy
         u64 o = 0;
@@ -3148,6 +3569,16 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         int blocks = 1792 * 256 / thr;     // 7 waves per SIMD (k_extend_160 is held to 72 VGPRs); the work queue balances the rest
         const char* e2 = getenv("MLST_EXT_BLOCKS"); if (e2 && atoi(e2) > 0) blocks = atoi(e2);
         h->ext_threads = thr; h->ext_blocks = blocks;
+        // haplotype summaries kept in LDS per work item: what the widest window of any locus needs, up to a budget
+        // (MLST_EXT_LDS_KB, default 96 of the CU's 160 KB; 0 switches the block-haplotype path off).  Loci whose windows
+        // need more take the pair-by-pair path inside the same launch.
+        u32 budget_kb = 96; const char* e4 = getenv("MLST_EXT_LDS_KB"); if (e4 && atoi(e4) >= 0 && atoi(e4) <= 150) budget_kb = (u32)atoi(e4);
+        h->ext_acc_cap = std::min<u32>((mx + 63u) & ~63u, 16384u);
+        for (int k = 0; k < 2; k++) {
+            h->ext_lds_recs[k] = std::min<u32>(h->hap_win_max[k], budget_kb * 1024u / 16u);
+            if (ext_lds_bytes(h, k) > 48u * 1024u)
+                HIPCHK(h, hipFuncSetAttribute(k ? (const void*)k_extend_320 : (const void*)k_extend_160, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ext_lds_bytes(h, k)));
+        }
         const char* e3 = getenv("MLST_SIEVE_BLOCKS"); if (e3 && atoi(e3) > 0) h->sieve_g_blocks = atoi(e3);
     }
     h->have_ref = h->have_state = true;
@@ -3249,6 +3680,10 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     EngineDev& E = h->E;
     if (wpr > h->max_wpr) h->max_wpr = wpr;
     if (h->sieve_kind == MLST_SIEVE_ROUTED) { int rc = ensure_route_buffers(h, n_reads, wpr); if (rc) return rc; }
+    {   // item records of k_ext_prep: one per work item a sample may hold (allocated on first use of an instantiation)
+        const int k = wpr <= 10 ? 0 : 1; const u64 words = k ? (u64)XRec<RW / 2>::WORDS : (u64)XRec<5>::WORDS;
+        if (!h->d_xrec[k]) { hipStreamSynchronize(h->stream); HIPCHK(h, dmalloc(&h->d_xrec[k], h->E.cap_items * words)); h->cap_xrec[k] = h->E.cap_items; }
+    }
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
                                                (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand,
                                                (u64)(uintptr_t)h->d_bin_flags, (u64)(uintptr_t)h->d_rt_arena, (u64)(uintptr_t)h->d_rt_counts,
@@ -3301,10 +3736,13 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       // (one pair of reads per workgroup and sweep, every sweep a chain of dependent scattered loads: a large grid keeps the
       // sweeps few -- 1024 workgroups took 59 sweeps = 112 us for the 121 k retained reads of cfg3)
       hipLaunchKernelGGL(k_retain, dim3(2048), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
+    { Prof pf(h, 12);     // item records (the read on the allele's block grid, the locus' fields, the block table)
+      if (wpr <= 10) hipLaunchKernelGGL(k_ext_prep<5>, dim3(2048), dim3(256), 0, h->stream, h->d_E, h->kp, h->d_xrec[0], h->cap_xrec[0]);
+      else hipLaunchKernelGGL(k_ext_prep<RW / 2>, dim3(2048), dim3(256), 0, h->stream, h->d_E, h->kp, h->d_xrec[1], h->cap_xrec[1]); }
     { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
       const int thr = h->ext_threads, blocks = h->ext_blocks;
-      if (wpr <= 10) hipLaunchKernelGGL(k_extend_160, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
-      else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
+      if (wpr <= 10) hipLaunchKernelGGL(k_extend_160, dim3(blocks), dim3(thr), ext_lds_bytes(h, 0), h->stream, h->d_E, h->kp, h->ext_lds_recs[0], h->ext_acc_cap, h->d_xrec[0], h->cap_xrec[0]);
+      else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(thr), ext_lds_bytes(h, 1), h->stream, h->d_E, h->kp, h->ext_lds_recs[1], h->ext_acc_cap, h->d_xrec[1], h->cap_xrec[1]); }
     { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
       hipLaunchKernelGGL(k_locus, dim3(128), dim3(1024), 0, h->stream, h->d_E, paired); }
@@ -4112,20 +4550,25 @@ extern "C" int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint
 
 extern "C" int mlst_set_profiling(mlst_handle* h, int on) { if (!h) return MLST_E_INVALID; drain_events(h); h->profiling = on == 1; h->window = on != 0; return MLST_OK; }
 extern "C" int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms, uint64_t* launches) {
-    if (!h || which < 0 || which >= 12) return MLST_E_INVALID;
+    if (!h || which < 0 || which >= 16) return MLST_E_INVALID;
     hipSetDevice(h->device); drain_events(h);
     if (total_ms) *total_ms = h->k_ms[which];
     if (launches) *launches = h->k_n[which];
     return MLST_OK;
 }
-extern "C" int mlst_reset_kernel_time(mlst_handle* h) { if (!h) return MLST_E_INVALID; drain_events(h); for (int i = 0; i < 12; i++) { h->k_ms[i] = 0; h->k_n[i] = 0; } return MLST_OK; }
+extern "C" int mlst_reset_kernel_time(mlst_handle* h) { if (!h) return MLST_E_INVALID; drain_events(h); for (int i = 0; i < 16; i++) { h->k_ms[i] = 0; h->k_n[i] = 0; } return MLST_OK; }
 extern "C" int mlst_get_index_bytes(mlst_handle* h, uint64_t out[4]) {
     if (!h || !out) return MLST_E_INVALID;
-    out[0] = h->bytes_arena; out[1] = h->bytes_sieve; out[2] = h->bytes_table; out[3] = (u64)(h->bitmap_fill * 1e6); return MLST_OK;
+    out[0] = h->bytes_arena + h->bytes_hap; out[1] = h->bytes_sieve; out[2] = h->bytes_table; out[3] = (u64)(h->bitmap_fill * 1e6); return MLST_OK;
 }
 extern "C" int mlst_get_sieve_info(mlst_handle* h, uint64_t out[4]) {
     if (!h || !out || !h->have_ref) return fail(h, MLST_E_INVALID, "no reference loaded");
     out[0] = (u64)h->sieve_kind; out[1] = h->n_keys; out[2] = h->sieve_chain; out[3] = (u64)h->E.sieve_mask + 1; return MLST_OK;
+}
+extern "C" int mlst_get_extend_info(mlst_handle* h, uint64_t out[8]) {
+    if (!h || !out || !h->have_ref) return fail(h, MLST_E_INVALID, "no reference loaded");
+    out[0] = h->n_hap_rec; out[1] = h->bytes_hap; out[2] = h->hap_loci; out[3] = h->hap_win_max[0]; out[4] = h->hap_win_max[1];
+    out[5] = h->ext_lds_recs[0] ? (u64)ext_lds_bytes(h, 0) : 0; out[6] = h->ext_lds_recs[1] ? (u64)ext_lds_bytes(h, 1) : 0; out[7] = (u64)h->ext_threads; return MLST_OK;
 }
 extern "C" void mlst_release_index_cache(void) { std::lock_guard<std::mutex> lk(g_index_mu); g_index_last.reset(); memset(g_index_key, 0, sizeof g_index_key); }
 // ---- diagnostics of the routed sieve (profiles/route_modes.py; not a data path)

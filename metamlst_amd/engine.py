@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("MLST_LIB", os.path.join(_HERE, "libmlst_hip.so"))   #
 MLST_CNT_N = 8
 CNT_TOTAL_RECORDS, CNT_IGNORED, CNT_READS_SEEN, CNT_CANDIDATES, CNT_RETAINED, CNT_ITEMS, CNT_DP_PAIRS = range(7)
 KERNELS = ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup", "pack", "sieve_inkernel", "sieve_wg_longest",
-           "sieve_route", "sieve_probe", "sieve_verify")
+           "sieve_route", "sieve_probe", "sieve_verify", "extend_prep")
 SIEVE_KINDS = ("lds", "global", "binned (round 1, removed)", "routed")
 
 
@@ -130,6 +130,7 @@ def load_library(path: str | None = None):
         "mlst_reset_kernel_time": (C.c_int, [H]),
         "mlst_get_index_bytes": (C.c_int, [H, C.POINTER(C.c_uint64)]),
         "mlst_get_sieve_info": (C.c_int, [H, C.POINTER(C.c_uint64)]),
+        "mlst_get_extend_info": (C.c_int, [H, C.POINTER(C.c_uint64)]),
         "mlst_release_index_cache": (None, []),
         "mlst_submit_fastq_stream": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
         "mlst_submit_fastq_pair": (C.c_int, [H, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -523,6 +524,13 @@ class Engine:
         out = (C.c_uint64 * 4)()
         self._check(self.lib.mlst_get_sieve_info(self._h, out), "mlst_get_sieve_info")
         return {"kind": SIEVE_KINDS[int(out[0])], "n_seeds": int(out[1]), "longest_chain": int(out[2]), "buckets": int(out[3])}
+
+    def extend_info(self) -> dict:
+        """The block-haplotype tables of the loaded database (mlst_get_extend_info)."""
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.mlst_get_extend_info(self._h, out), "mlst_get_extend_info")
+        keys = ("haplotypes", "bytes", "loci", "window6", "window11", "lds_bytes_160", "lds_bytes_320", "threads")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def route_trace(self):
         """Diagnostics of the routed sieve's last submission (None until the trace, switched on by the first call, has
