@@ -140,6 +140,7 @@ struct Counters {
     u64 rt_next;         // routed sieve: tiles handed out beyond every producer's first one (zero between submissions)
     u64 rt_parked;       // routed sieve: entries that passed the filter and wait in R.parked for k_route_verify (zero between submissions)
     u64 pad_[14];        // the block stays a multiple of 128 bytes longer than it was in round 2
+    u64 ext_q2[EXT_Q][16];      // work queues of k_extend_pairs (as ext_q; 4 KB: the arrays behind keep their alignment)
 };
 // item_state bits
 #define IS_SINGLE 1   /* the read has exactly one work item */
@@ -181,6 +182,7 @@ struct EngineDev {
     GP<const int> floor_tab; GP<const u8> pen_tab;
     u32 n_alleles, n_loci;
     GP<const HapRec> hap_rec; GP<const u32> hap_blk; GP<const u32> hap_id;      // block-haplotype tables (see LocusDev)
+    GP<u64> acc64;            // additions of k_extend's fast pass: count << 40 | sum per allele, ONE device addition per accepted record; k_accumulate hands them on (zero between submissions)
     // sample state
     GP<long long> sum_score; GP<u32> n_hits; GP<u64> locus_len; GP<u64> locus_first;
     GP<Counters> ctr;
@@ -1681,6 +1683,148 @@ __device__ inline u64 ext_steal(const EngineDev& E, u32 q, u64 begin, u64 end) {
     return begin + q + (u64)EXT_Q * atomicAdd(&E.ctr->ext_q[q][0], 1ull);
 }
 
+// ---- The pair-by-pair form of the extension (rounds 1-3): every (item, allele) pair aligned on its own, lanes = alleles.
+// It keeps the loci the block-haplotype kernel does not take (more alleles than MLST_EXT_HAP_MAX, default 512: an item of such
+// a locus wants a workgroup of several waves, and with one the haplotype form gains nothing -- profiles/round4/README.md; or
+// no tables); both kernels walk the items of a submission and skip the other one's loci (LocusDev::hap_ok).
+__device__ inline u64 ext_steal2(const EngineDev& E, u32 q, u64 begin, u64 end) {
+    u64 seen = __hip_atomic_load((u64*)&E.ctr->ext_q2[q][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (begin + q + (u64)EXT_Q * seen >= end) return end;
+    return begin + q + (u64)EXT_Q * atomicAdd(&E.ctr->ext_q2[q][0], 1ull);
+}
+template <int NB>
+__device__ __forceinline__ void extend_pairs_body(const EngineDev* __restrict__ Ep, const KParams& P) {
+    const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
+    __shared__ u32 s_rl[RW / 2 + 2]; __shared__ u32 s_rh[RW / 2 + 2]; __shared__ u32 s_rn[RW / 2 + 2]; __shared__ u32 s_odd[RW / 2 + 2];
+    __shared__ u8 s_pen[RQ]; __shared__ u8 s_pentab[128];
+    __shared__ u32 s_cnt[16][3];
+    const int tid = threadIdx.x, nthr = blockDim.x, nwv = blockDim.x >> 6;      // 64..1024 threads per work item
+    for (int i = tid; i < 128; i += nthr) s_pentab[i] = E.pen_tab[i];
+    u64 c_tot = 0, c_ign = 0;                     // block-level counters, flushed once at the end (thread 0)
+    const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
+    // Work queue: items cost different amounts (mismatch density, allele count of the locus), so blocks take the
+    // next item from a counter instead of a fixed stride.  The ticket for item k+1 is drawn while item k is staged.
+    __shared__ u64 s_next;
+    u32 myq = blockIdx.x % EXT_Q, tried = 0;      // thread 0 only: current queue, exhausted queues seen in a row
+    if (tid == 0) s_next = begin + myq + (u64)EXT_Q * atomicAdd(&E.ctr->ext_q2[myq][0], 1ull);
+    __syncthreads();
+    u64 ii = uniform_u64(s_next);                 // readfirstlane: keeps the per-item descriptor loads and index math scalar
+    if (ii >= end) {                              // own queue already empty: steal (block-uniform branch)
+        if (tid == 0) {
+            u64 nx = ii;
+            while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal2(E, myq, begin, end); }
+            s_next = nx; tried = 0;
+        }
+        __syncthreads();
+        ii = uniform_u64(s_next);
+    }
+    while (ii < end) {                            // block-uniform
+        u64 ticket = 0;
+        if (tid == 0) ticket = atomicAdd(&E.ctr->ext_q2[myq][0], 1ull);
+        ItemDev it = E.items[ii];
+        const LocusDev L = E.loci[it.locus];
+        if (L.hap_ok) {                               // the locus belongs to k_extend_160 / _320 (block-uniform)
+            if (tid == 0) {
+                u64 nx = begin + myq + (u64)EXT_Q * ticket;
+                while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal2(E, myq, begin, end); }
+                s_next = nx; tried = 0;
+            }
+            __syncthreads();
+            ii = uniform_u64(s_next);
+            continue;
+        }
+        u32 lw = E.ret_len[it.ret]; int n = (int)(lw & 0x7FFFu); bool read_has_n = (lw & 0x8000u) != 0;
+        u8 state = E.item_state[ii];
+        __syncthreads();
+        const int pen_def = __builtin_amdgcn_readfirstlane(stage_read_planes(E, P, it, n, s_rl, s_rh, s_rn, s_odd, s_pen, s_pentab, tid, nthr));
+        __syncthreads();
+        const bool res_ok = it.res_off + L.n_pad <= E.cap_res;      // else flagged by k_seed
+        const int floor_n = E.floor_tab[n];
+        u32 rl[NB], rh[NB], od[NB], rn[NB];       // block-uniform read planes, held in scalar registers
+        #pragma unroll
+        for (int w = 0; w < NB; w++) {
+            rl[w] = __builtin_amdgcn_readfirstlane(s_rl[w]); rh[w] = __builtin_amdgcn_readfirstlane(s_rh[w]);
+            od[w] = __builtin_amdgcn_readfirstlane(s_odd[w]);
+            rn[w] = read_has_n ? __builtin_amdgcn_readfirstlane(s_rn[w]) : 0u;
+        }
+        u32 nrec = 0, ndp = 0;
+        for (u32 a = tid; res_ok && a < L.n_alleles; a += nthr) {
+            int m = (int)E.allele_len[L.a_begin + a];
+            int mm, bs, be;
+            int best = L.has_n ? ungapped_planes<NB, false, true>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be)
+                               : ungapped_planes<NB, false, false>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
+            int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF), xo = 127 - ((best >> 8) & 0x7F);
+            bool need_dp = P.trig < 0;
+            if (!need_dp && mm > P.trig && score >= floor_n) {       // rare: the policy needs the aligned span
+                if (L.has_n) ungapped_planes<NB, true, true>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
+                else ungapped_planes<NB, true, false>(E, P, L, a, m, n, it.diag, rl, rh, od, rn, s_pen, pen_def, read_has_n, mm, bs, be);
+                need_dp = gap_trigger(P, mm, xm, score, floor_n, m, n, it.diag, bs, be);
+            }
+            u32 r = pack_result(score, xm, xo);
+            if (need_dp) { r |= R_NEEDDP; ndp++; }
+            else if (score >= floor_n && score > 0) { r |= R_REC; nrec++; }
+            // banded-SW worklist: one returning atomic per wave, not per pair
+            u64 wm = __ballot(need_dp);
+            if (wm) {
+                int lane = tid & 63, leader = __ffsll((long long)wm) - 1; u64 base = 0;
+                if (lane == leader) base = atomicAdd(&E.ctr->n_dp, (u64)__popcll(wm));
+                base = __shfl(base, leader);
+                if (need_dp) { u64 slot = base + __popcll(wm & ((1ull << lane) - 1));
+                               if (slot < E.cap_dp) E.dp_list[slot] = (ii << 20) | (u64)a; else atomicOr(&E.ctr->err, 8ull); }
+            }
+            E.res[it.res_off + a] = r;
+        }
+        nrec = wave_sum_u32(nrec); ndp = wave_sum_u32(ndp);
+        if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = nrec; s_cnt[tid >> 6][1] = ndp; }
+        __syncthreads();
+        u32 tot_rec = 0, tot_dp = 0;
+        for (int w = 0; w < nwv; w++) { tot_rec += s_cnt[w][0]; tot_dp += s_cnt[w][1]; }
+        if (tid == 0 && tot_rec) atomicAdd(&E.ret_nrec[it.ret], tot_rec);   // per-read record count (Q1)
+        // Fused accumulation (metamlst.py:101-130) when everything about this read is known here:
+        // it has a single work item and no pair is waiting for the banded SW.
+        if (res_ok && (state & IS_SINGLE) && tot_dp == 0) {
+            bool use_xo = P.quirk && tot_rec == 1;
+            u32 acc = 0, ign = 0;
+            for (u32 a = tid; a < L.n_alleles; a += nthr) {
+                u32 r = E.res[it.res_off + a];
+                if (!(r & R_REC)) continue;
+                if (accept_rec(P, r, n, use_xo)) {
+                    atomicAdd((u64*)&E.sum_score[L.a_begin + a], (u64)(r & 0x3FF));
+                    atomicAdd(&E.n_hits[L.a_begin + a], 1u);
+                    acc++;
+                } else ign++;
+            }
+            acc = wave_sum_u32(acc); ign = wave_sum_u32(ign);
+            __syncthreads();
+            if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = acc; s_cnt[tid >> 6][1] = ign; }
+            __syncthreads();
+            if (tid == 0) {
+                u32 A = 0, I = 0;
+                for (int w = 0; w < nwv; w++) { A += s_cnt[w][0]; I += s_cnt[w][1]; }
+                c_tot += tot_rec; c_ign += I;
+                E.item_state[ii] = (u8)(state | IS_DONE | (A ? IS_ACC : 0));
+            }
+        }
+        if (tid == 0) {
+            u64 nx = begin + myq + (u64)EXT_Q * ticket;
+            while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal2(E, myq, begin, end); }
+            s_next = nx; tried = 0;
+        }
+        __syncthreads();
+        ii = uniform_u64(s_next);
+    }
+    if (tid == 0) {
+        if (c_tot) atomicAdd(&E.ctr->cnt[MLST_CNT_TOTAL_RECORDS], c_tot);
+        if (c_ign) atomicAdd(&E.ctr->cnt[MLST_CNT_IGNORED], c_ign);
+    }
+}
+
+// Two instantiations: reads up to 160 bases (five 32-base blocks; held to 72 VGPRs = 7 waves per SIMD, which measured
+// 3 % faster than the 80 the allocator takes when left alone) and up to MLST_MAX_READ_LEN.
+__attribute__((amdgpu_waves_per_eu(7, 7)))
+__global__ __launch_bounds__(1024) void k_extend_pairs_160(const EngineDev* __restrict__ Ep, KParams P) { extend_pairs_body<5>(Ep, P); }
+__global__ __launch_bounds__(1024) void k_extend_pairs_320(const EngineDev* __restrict__ Ep, KParams P) { extend_pairs_body<RW / 2>(Ep, P); }
+
 // ---- item records (k_ext_prep -> k_extend).  Everything k_extend needs to know about a work item, gathered into one
 // contiguous record by a kernel whose lanes are items: read on its own, a workgroup of k_extend followed a chain of ~8
 // dependent round trips per item (ticket -> item -> locus, read length -> quality and base rows -> ballots -> block
@@ -1689,6 +1833,7 @@ __device__ inline u64 ext_steal(const EngineDev& E, u32 q, u64 begin, u64 end) {
 //   0 flags   1 n | pen_def << 16   2 diag   3 ret   4 locus   5,6 res_off   7 a_begin   8 n_alleles   9 n_pad
 //   10 hap_off   11,12 hid_off   13 floor_n   14 pblocks   15 hap_win (of this instantiation)
 //   16 .. 16+NBA      first record of block q0 + t in the locus' table (clamped: empty outside the allele), t = 0 .. NBA
+//   31 work item
 //   32 + 4 t          the read's planes funnel-shifted onto block t: low, high, N mask, non-default-penalty mask
 //   32 + 4 NBA + t    read columns that exist in block t
 #define XF_SINGLE 1u
@@ -1719,6 +1864,8 @@ __global__ __launch_bounds__(256) void k_ext_prep(const EngineDev* __restrict__ 
             const LocusDev L = E.loci[it.locus];
             const u32 lw = E.ret_len[it.ret]; const int n = (int)(lw & 0x7FFFu);
             const u8 state = E.item_state[ii];
+            if (!L.hap_ok) { if (lane < 32) s_w[wv][lane] = 0; }      // the other kernel's item: a record without XF_HAPOK
+            else {
             const int pen_def = stage_read_planes(E, P, it, n, s_rl[wv], s_rh[wv], s_rn[wv], s_odd[wv], s_pen[wv], s_pentab, lane, 64);
             const int q0 = it.diag >> 5; const u32 rs = 32u - ((u32)it.diag & 31u);      // 1..32
             u32* w = s_w[wv];
@@ -1743,6 +1890,8 @@ __global__ __launch_bounds__(256) void k_ext_prep(const EngineDev* __restrict__ 
                 w[1] = (u32)n | ((u32)pen_def << 16); w[2] = (u32)it.diag; w[3] = it.ret; w[4] = it.locus; w[5] = (u32)it.res_off; w[6] = (u32)(it.res_off >> 32);
                 w[7] = L.a_begin; w[8] = L.n_alleles; w[9] = L.n_pad; w[10] = L.hap_off; w[11] = (u32)L.hid_off; w[12] = (u32)(L.hid_off >> 32);
                 w[13] = (u32)E.floor_tab[n]; w[14] = L.pblocks; w[15] = L.hap_win[NB > 5 ? 1 : 0];
+                w[31] = (u32)ii;                                  // (max_items < 2^32)
+            }
             }
         }
         __syncthreads();
@@ -1804,17 +1953,36 @@ __device__ inline int4 hap_summary(const KParams& P, const HapRec h, u32 rl, u32
 // phase of an item, summed over all waves.  0 record, 1 requests + s_pen, 2 summaries, 3 composition, 4 counts + fused
 // accumulation, 5 hand-over to the next item, 6 items, 7 waves.
 #ifdef MLST_EXT_TRACE
+__device__ u32 g_ext_skip;      // bit 0: no summaries, bit 1: no composition (wrong results: instruction counts by difference)
+#define XSKIP(b) (xskip_ & (b))
+extern "C" int mlst_debug_ext_skip(uint32_t v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ext_skip), &v, 4) == hipSuccess ? 0 : -1; }
 __device__ u64 g_ext_trace[8];
-#define XT_DECL u64 xt_[6] = {0, 0, 0, 0, 0, 0}; u64 xt_items = 0; u64 xt_t = __builtin_readcyclecounter()
+__device__ u64 g_ext_cnt[8];      // 0 items through the fast pass, 1 items that fell back, 2 pairs whose policy test needs the span, 3 turns with such a pair
+extern "C" int mlst_debug_ext_cnt(uint64_t out[8], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ext_cnt), 64) != hipSuccess) return -1;
+    if (reset) { u64 z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ext_cnt), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#define XC(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_ext_cnt[k], (u64)(v)); } while (0)
+#if MLST_EXT_TRACE > 1      /* cycle stamps: they serialise the wave (the kernel runs 2-3 x longer); the phases' shares only */
+#define XT_DECL u64 xt_[6] = {0, 0, 0, 0, 0, 0}; u64 xt_items = 0; u64 xt_t = __builtin_readcyclecounter(); const u32 xskip_ = __builtin_amdgcn_readfirstlane(g_ext_skip)
 #define XT(k) do { const u64 now_ = __builtin_readcyclecounter(); xt_[k] += now_ - xt_t; xt_t = now_; } while (0)
 #define XT_ITEM xt_items++
 #define XT_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_ext_trace[k_], xt_[k_]); atomicAdd(&g_ext_trace[6], xt_items); atomicAdd(&g_ext_trace[7], 1ull); } } while (0)
+#else
+#define XT_DECL const u32 xskip_ = __builtin_amdgcn_readfirstlane(g_ext_skip)
+#define XT(k)
+#define XT_ITEM
+#define XT_FLUSH
+#endif
 extern "C" int mlst_debug_ext_trace(uint64_t out[8], int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ext_trace), 64) != hipSuccess) return -1;
     if (reset) { u64 z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ext_trace), z, 64) != hipSuccess) return -1; }
     return 0;
 }
 #else
+#define XC(k, v)
+#define XSKIP(b) false
 #define XT_DECL
 #define XT(k)
 #define XT_ITEM
@@ -1835,43 +2003,52 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
     const int tid = threadIdx.x, nthr = blockDim.x, nwv = blockDim.x >> 6;      // 64..1024 threads per work item
     for (int i = tid; i < 128; i += nthr) s_pentab[i] = E.pen_tab[i];
     u64 c_tot = 0, c_ign = 0;                     // block-level counters, flushed once at the end (thread 0)
-    const u64 begin = E.ctr->items_done;
-    u64 end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
-    if (end - begin > cap_xrec) end = begin + cap_xrec;      // (the host flags the overflow: see mlst_submit_packed_device)
-    // Work queue: items cost different amounts (mismatch density, allele count of the locus), so blocks take the next
-    // item from a counter instead of a fixed stride; 32 counters in separate lines, own one first, then the others'.
-    // Tickets are drawn two items ahead: the item after the current one is known when the current one starts, so its
-    // record is fetched while the current one is worked on.
+    u64 N;                                        // records of this submission, sorted by locus (k_ext_prep)
+    { const u64 b0 = E.ctr->items_done, e0 = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items; N = e0 - b0; if (N > cap_xrec) N = cap_xrec; }
+    // Work queue: items cost different amounts (mismatch density, allele count of the locus), so workgroups take the next
+    // record from a counter instead of a fixed stride.  32 counters in separate lines; counter q hands out the records
+    // q B .. (q + 1) B - 1 in order (B = N / 32 rounded up): the records are sorted by locus, so the workgroups on one counter
+    // work through the same few loci and each meets runs of one locus.  Own counter first, then the others'.  Tickets are
+    // drawn two records ahead: the one after the current is known when the current one starts and is fetched meanwhile.
+    const u64 QB = (N + EXT_Q - 1) / EXT_Q;
     u32 myq = blockIdx.x % EXT_Q, tried = 0;      // thread 0 only: current queue, exhausted queues seen in a row
-    auto resolve = [&](u64 ticket) -> u64 {       // thread 0: item of a ticket of queue myq; moves on to other queues when it is past the end
-        u64 nx = begin + myq + (u64)EXT_Q * ticket;
-        while (nx >= end && ++tried < EXT_Q) { myq = (myq + 1) % EXT_Q; nx = ext_steal(E, myq, begin, end); }
-        if (nx >= end) nx = end; else tried = 0;
+    auto place = [&](u32 q, u64 ticket) -> u64 { const u64 pl = (u64)q * QB + ticket; return (ticket < QB && pl < N) ? pl : N; };
+    auto resolve = [&](u64 ticket) -> u64 {       // thread 0: record of a ticket of queue myq; moves on to other queues when that one is drained
+        u64 nx = place(myq, ticket);
+        while (nx >= N && ++tried < EXT_Q) {
+            myq = (myq + 1) % EXT_Q;
+            const u64 seen = __hip_atomic_load((u64*)&E.ctr->ext_q[myq][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // a stale look only costs one atomic
+            nx = place(myq, seen) < N ? place(myq, atomicAdd(&E.ctr->ext_q[myq][0], 1ull)) : N;
+        }
+        if (nx < N) tried = 0;
         return nx;
     };
     if (tid == 0) {
         s_ii[0] = resolve(atomicAdd(&E.ctr->ext_q[myq][0], 1ull));
-        s_ii[1] = tried < EXT_Q ? resolve(atomicAdd(&E.ctr->ext_q[myq][0], 1ull)) : end;
+        s_ii[1] = tried < EXT_Q ? resolve(atomicAdd(&E.ctr->ext_q[myq][0], 1ull)) : N;
     }
+    u16* const s_pend = reinterpret_cast<u16*>(s_hap + lds_recs + 1);      // what the current item would add per allele, until its counts are known
+    const bool packed_acc = E.cap_items < (1ull << 24);      // count << 40 | sum in one 64-bit addition (else two additions)
     __syncthreads();
-    u64 ii = uniform_u64(s_ii[0]);
-    if (ii < end) for (int j = tid; j < X::WORDS; j += nthr) s_x[0][j] = xrec[(ii - begin) * X::WORDS + j];
+    u64 pp = uniform_u64(s_ii[0]);
+    if (pp < N) for (int j = tid; j < X::WORDS; j += nthr) s_x[0][j] = xrec[pp * X::WORDS + j];
     __syncthreads();
     int cur = 0;
     XT_DECL;
-    while (ii < end) {                            // block-uniform
+    while (pp < N) {                              // block-uniform
         XT_ITEM;
-        const u64 ii_next = uniform_u64(s_ii[cur ^ 1]);
-        // the next item's record: requested now, parked in LDS at the end of this item
+        const u64 pp_next = uniform_u64(s_ii[cur ^ 1]);
+        // the next record: requested now, parked in LDS once a wait for loads has passed anyway
         u32 pf[(X::WORDS + 63) / 64];
         #pragma unroll
-        for (int k = 0; k < (X::WORDS + 63) / 64; k++) { pf[k] = 0; if (ii_next < end && tid + 64 * k < X::WORDS && tid < 64) pf[k] = xrec[(ii_next - begin) * X::WORDS + tid + 64 * k]; }
+        for (int k = 0; k < (X::WORDS + 63) / 64; k++) { pf[k] = 0; if (pp_next < N && tid + 64 * k < X::WORDS && tid < 64) pf[k] = xrec[pp_next * X::WORDS + tid + 64 * k]; }
         u64 ticket = 0;
         if (tid == 0 && tried < EXT_Q) ticket = atomicAdd(&E.ctr->ext_q[myq][0], 1ull);
         asm volatile("" ::: "memory");
         const u32* x = s_x[cur];
         const uint4 h0 = *reinterpret_cast<const uint4*>(x), h1 = *reinterpret_cast<const uint4*>(x + 4), h2 = *reinterpret_cast<const uint4*>(x + 8), h3 = *reinterpret_cast<const uint4*>(x + 12);
         const u32 flags = __builtin_amdgcn_readfirstlane(h0.x);
+        const u64 ii = (u64)(u32)__builtin_amdgcn_readfirstlane(x[31]);      // the work item of this record
         const int n = __builtin_amdgcn_readfirstlane(h0.y & 0xFFFFu), pen_def = __builtin_amdgcn_readfirstlane(h0.y >> 16);
         const int diag = __builtin_amdgcn_readfirstlane((int)h0.z);
         const u32 ret = __builtin_amdgcn_readfirstlane(h0.w);
@@ -1881,6 +2058,16 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
         const bool res_ok = flags & XF_RESOK, read_has_n = flags & XF_READN;
         const bool use_hap = res_ok && (flags & XF_HAPOK) && (u32)__builtin_amdgcn_readfirstlane(h3.w) <= lds_recs;      // block-uniform
         u32 nrec = 0, ndp = 0, ntrack = 0;        // per wave (counted with ballots: scalar registers)
+        // hand-over to the next item: its record goes to the free LDS slot, the ticket drawn above names the item after it.
+        // Done as soon as a wait for loads has passed anyway (behind the haplotype records): at the end of the item the
+        // additions of the item are in flight, and a wait for these two values would wait for all of them (vmcnt is in order).
+        bool parked = false;
+        auto park = [&]() {
+            #pragma unroll
+            for (int k = 0; k < (X::WORDS + 63) / 64; k++) if (tid < 64 && tid + 64 * k < X::WORDS) s_x[cur ^ 1][tid + 64 * k] = pf[k];
+            if (tid == 0) s_ii[cur] = tried < EXT_Q ? resolve(ticket) : N;
+            parked = true;
+        };
         // what follows an alignment, for both forms of it: the gap-trigger policy, the result word, the banded-SW worklist
         // (called by every lane of a turn, `valid` or not: the counts are kept per wave, in every lane's copy)
         auto emit_pair = [&](const u32 a, const int score, const int xm, const int xo, bool need_dp, const bool valid) {
@@ -1949,6 +2136,7 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
             const u32 odd16 = ((u32)q0 & 1u) * 16u;
             auto load_ids = [&](const u32 a, u32 (&w)[NR]) {      // unconditional (a clamped): the compiler can count the loads in flight
                 const u32 ac = a < n_alleles ? a : n_alleles - 1;
+                if (XSKIP(8u)) { for (int j = 0; j < NR; j++) w[j] = 0; return; }
                 #pragma unroll
                 for (int j = 0; j < NR; j++) w[j] = ld_row(idrow[j], ac * 4u);
             };
@@ -1964,8 +2152,8 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                 auto rq = E.ret_quals.g() + (u64)ret * RQ;
                 for (int i = tid; i < n; i += nthr) { const u8 qb = rq[(flags & XF_STRAND) ? n - 1 - i : i]; s_pen[i] = (qb >> 7) ? (u8)P.n_penalty : s_pentab[qb & 0x7F]; }
             }
-            u32 Wn[NR];                            // ids of this thread's first allele: they do not depend on the summaries
-            load_ids((u32)tid, Wn);
+            u32 Wn[NR], Wn2[NR], Wn3[NR], Wn4[NR];   // ids of this thread's first four alleles: they do not depend on the summaries
+            load_ids((u32)tid, Wn); load_ids((u32)tid + nthr, Wn2); load_ids((u32)tid + 2 * nthr, Wn3); load_ids((u32)tid + 3 * nthr, Wn4);
             const u32 ident = hb[NB + 1] - hb[0];   // one slot behind the summaries: the identity, for blocks outside the allele
             u32 sbase[NB + 1], wid[NB + 1];        // per block: first summary, width of an id (0 = block outside the allele: identity)
             #pragma unroll
@@ -1973,7 +2161,7 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
             if (tid == 0) s_hap[ident] = make_int4(0, NEGP, NEGP, NEGP);
             if (special_any) lds_barrier();
             XT(1);
-            for (u32 hb0 = 0; hb0 < maxcnt; hb0 += nthr) {
+            for (u32 hb0 = 0; hb0 < maxcnt && !XSKIP(1u); hb0 += nthr) {
                 const u32 hh = hb0 + tid;
                 uint4 rc[NB + 1];
                 #pragma unroll
@@ -1991,6 +2179,7 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                     }
                 }
             }
+            park();
             lds_barrier();                         // (not __syncthreads(): that would also wait for the loads in flight)
             XT(2);
             // composition of one allele from the summaries of its blocks -> packed best value, mismatches of the full overlap
@@ -2010,6 +2199,43 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                 best = v > best ? v : best;
                 mm = (-ts) & 0xFFFF;
             };
+            // The gap-trigger policy of a pair with many mismatches (rare per pair, but one item in six holds such a pair on a
+            // database 3 % apart): length of the ungapped local alignment by the column-by-column walk of ungapped_planes<TRACK>,
+            // on the allele's block grid -- haplotype records by id, the read's planes from the item record.
+            auto span_needs_dp = [&](const u32 (&w)[NR], const int mm, const int xm, const int score) -> bool {
+                const int MA = P.match_bonus << MLST_P_SHIFT, PD = (pen_def << MLST_P_SHIFT) + 1;
+                int cur = P0, best = P0, cs = 0, last = 0, blen = 0, overlap = 0, i1 = 0; bool first = true;
+                #pragma unroll
+                for (int t = 0; t <= NB; t++) {
+                    if (hb[t + 1] == hb[t]) continue;                      // uniform
+                    const u32 k = (u32)t + (odd16 >> 4);
+                    const u32 id = (w[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu;
+                    const uint4 rc = *reinterpret_cast<GP<const uint4>::G*>(recs + hb[t] + id);
+                    const uint4 sp = *reinterpret_cast<const uint4*>(x + X::PL + 4 * t);
+                    const u32 lm = rc.w >= 32u ? 0xFFFFFFFFu : ((1u << rc.w) - 1u), valid = x[X::VR + t] & lm;
+                    if (!valid) continue;
+                    u32 M = ((rc.x ^ sp.x) | (rc.y ^ sp.y) | sp.z | rc.z) & valid;
+                    const int lo_c = __ffs((int)valid) - 1, nv = __popc(valid);
+                    if (first) { cs = last = 32 * t + lo_c; first = false; }
+                    overlap += nv; i1 = 32 * t + lo_c + nv;
+                    const u32 special = sp.w | rc.z;
+                    while (M) {
+                        const int bit = __ffs((int)M) - 1; M &= M - 1;
+                        const int i = 32 * t + bit;
+                        cur += (i - last) * MA;
+                        if (cur > best) { best = cur; blen = i - cs; }
+                        int dec = PD;
+                        if ((special >> bit) & 1u) dec = ((((rc.z >> bit) & 1u) ? P.n_penalty : (int)s_pen[32 * t - (int)((u32)diag & 31u) + bit]) << MLST_P_SHIFT) + 1;
+                        cur -= dec;
+                        if (cur <= P0) { cur = P0; cs = i + 1; }
+                        last = i + 1;
+                    }
+                }
+                cur += (i1 - last) * MA;
+                if (cur > best) blen = i1 - cs;
+                const int clipped = overlap - blen;          // overlap columns the ungapped alignment left out (gap_trigger)
+                return mm > P.trig && score >= floor_n && clipped >= P.clip && 2 * (mm - xm) >= clipped;
+            };
             bool slow = !(flags & XF_SINGLE) || P.trig < 0 || n_alleles > acc_cap;
             if (!slow) {
                 // A read with one work item (nearly all): what metamlst.py:101-130 would add for each record is noted beside the
@@ -2017,19 +2243,20 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                 // aligned span or the banded SW and that the read has not exactly one record (Q1: column 15 would then be XO).
                 // No result word is stored, none is read back; the additions leave in one burst at the end of the item (inside
                 // the pass every turn waited for the additions of the turn before: vmcnt counts them with the loads, in order).
-                u16* s_acc = reinterpret_cast<u16*>(s_hap + lds_recs + 1);
+                u16* const s_acc = s_pend;
                 const bool n_ok = n >= P.min_read_len;
                 u32 nacc = 0;
-                for (u32 a = tid; a < n_alleles; a += nthr) {
+                for (u32 a = tid; a < n_alleles && !XSKIP(2u); a += nthr) {
                     u32 W[NR];
                     #pragma unroll
-                    for (int j = 0; j < NR; j++) W[j] = Wn[j];
-                    load_ids(a + nthr, Wn);                 // next turn's ids
+                    for (int j = 0; j < NR; j++) { W[j] = Wn[j]; Wn[j] = Wn2[j]; Wn2[j] = Wn3[j]; Wn3[j] = Wn4[j]; }
+                    load_ids(a + 4 * nthr, Wn4);            // the ids four turns ahead: a load under this kernel's traffic takes several turns of composition
                     asm volatile("" ::: "memory");
                     int best, mm; compose(W, best, mm);
                     const int score = best >> MLST_P_SHIFT, xm = 255 - (best & 0xFF);
                     const bool cand = score >= floor_n && score > 0;
-                    const bool track = cand && P.trig >= 0 && mm > P.trig;
+                    bool track = cand && mm > P.trig;
+                    if (track) track = span_needs_dp(W, mm, xm, score);      // now: the pair goes to the banded SW (rare)
                     const bool rec = cand && !track, ok = rec && n_ok && score >= P.minscore && xm <= P.max_xm;
                     nrec += (u32)__popcll(__ballot(rec)); nacc += (u32)__popcll(__ballot(ok)); ntrack += (u32)__popcll(__ballot(track));
                     s_acc[a] = ok ? (u16)score : (u16)0;
@@ -2044,9 +2271,15 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                     __syncthreads();
                 }
                 if (tot_track == 0 && !(P.quirk && tot_rec == 1)) {      // block-uniform
+                    // The device performs ~95 G additions a second (the rate that binds k_pileup too), and two per accepted record --
+                    // sum and count -- were 0.42 of this kernel's 0.46 ms however few instructions it issued: count and sum travel in
+                    // ONE 64-bit addition to acc64 (count << 40 | sum: a submission holds < 2^24 items, checked on the host).
                     if (tot_acc) for (u32 a = tid; a < n_alleles; a += nthr) {      // (each thread reads back what it wrote)
                         const u32 sc = s_acc[a];
-                        if (sc) { atomicAdd((u64*)&E.sum_score[a_begin + a], (u64)sc); atomicAdd(&E.n_hits[a_begin + a], 1u); }
+                        if (sc && !XSKIP(4u)) {
+                            if (packed_acc) atomicAdd(&E.acc64[a_begin + a], (1ull << 40) | (u64)sc);
+                            else { atomicAdd((u64*)&E.sum_score[a_begin + a], (u64)sc); atomicAdd(&E.n_hits[a_begin + a], 1u); }
+                        }
                     }
                     if (tid == 0) {
                         if (tot_rec) atomicAdd(&E.ret_nrec[ret], tot_rec);      // per-read record count (Q1)
@@ -2057,7 +2290,7 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                 } else { slow = true; nrec = 0; ntrack = 0; }
             }
             if (slow) {
-                if (flags & XF_SINGLE) load_ids((u32)tid, Wn);      // (a read with several items comes here with its first ids still waiting)
+                load_ids((u32)tid, Wn);
                 for (u32 a = tid; a < n_alleles; a += nthr) {
                     u32 W[NR];
                     #pragma unroll
@@ -2079,12 +2312,9 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                 }
                 if (ntrack) { stage_old(); pairs_loop(true); }      // block-uniform
             }
-        } else if (res_ok) {
-            stage_old();
-            pairs_loop(false);
-        }
+        }                                         // (items of other loci: k_extend_pairs)
         XT(3);
-        if (!done_fast) {                         // block-uniform
+        if (!done_fast && use_hap) {              // block-uniform
         if ((tid & 63) == 0) { s_cnt[tid >> 6][0] = nrec; s_cnt[tid >> 6][1] = ndp; }
         __syncthreads();
         u32 tot_rec = 0, tot_dp = 0;
@@ -2117,12 +2347,9 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
         }
         }
         XT(4);
-        // hand over to the next item: its record goes to the free LDS slot, the ticket drawn at the top names the item after it
-        #pragma unroll
-        for (int k = 0; k < (X::WORDS + 63) / 64; k++) if (tid < 64 && tid + 64 * k < X::WORDS) s_x[cur ^ 1][tid + 64 * k] = pf[k];
-        if (tid == 0) s_ii[cur] = tried < EXT_Q ? resolve(ticket) : end;
+        if (!parked) park();
         lds_barrier();                            // (LDS only: the additions of this item are still on their way)
-        ii = ii_next; cur ^= 1;
+        pp = pp_next; cur ^= 1;
         XT(5);
     }
     XT_FLUSH;
@@ -2323,6 +2550,11 @@ __global__ __launch_bounds__(256) void k_accumulate(const EngineDev* __restrict_
     // state load per item and block)
     __shared__ u32 s_red[4][4]; __shared__ u32 s_list[256]; __shared__ u32 s_nlist;
     const int tid = threadIdx.x;
+    // what k_extend added in packed form (count << 40 | sum per allele) goes on to the per-allele sums; zero again afterwards
+    for (u64 a = (u64)blockIdx.x * 256 + tid; a < E.n_alleles; a += (u64)gridDim.x * 256) {
+        const u64 v = E.acc64[a];
+        if (v) { atomicAdd((u64*)&E.sum_score[a], v & ((1ull << 40) - 1)); atomicAdd(&E.n_hits[a], (u32)(v >> 40)); E.acc64[a] = 0; }
+    }
     u64 c_tot = 0, c_ign = 0, c_dp = 0;
     const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
     for (u64 i0 = begin + (u64)blockIdx.x * 256; i0 < end; i0 += (u64)gridDim.x * 256) {
@@ -2428,7 +2660,7 @@ __global__ void k_advance(Counters* c, u64 n_reads) {
     c->cnt[MLST_CNT_READS_SEEN] += n_reads;
     c->items_done = ni; c->dp_done = nd; c->n_cand = 0;
     c->n_res = 0;        // the result rows of a submission have been consumed by k_accumulate: the arena is reused by the next one
-    for (int q = 0; q < EXT_Q; q++) c->ext_q[q][0] = 0;
+    for (int q = 0; q < EXT_Q; q++) { c->ext_q[q][0] = 0; c->ext_q2[q][0] = 0; }
 }
 
 // ------------------------------------------------------------------ K6: pileup against the chosen allele of each locus
@@ -2911,6 +3143,7 @@ struct mlst_handle {
     HapRec* d_hap_rec = nullptr; u32* d_hap_blk = nullptr; u32* d_hap_id = nullptr; u64 bytes_hap = 0, n_hap_rec = 0; u32 hap_win_max[2] = {0, 0}, hap_loci = 0;
     u32 ext_lds_recs[2] = {0, 0};                // k_extend_160 / _320: haplotype summaries (16 B each) the launch keeps in LDS
     u32 ext_acc_cap = 0;                         // alleles per locus for which k_extend keeps the pending additions of an item in LDS (2 B each)
+    u64* d_acc64 = nullptr;                      // k_extend's additions of a submission, count << 40 | sum of scores per allele (k_accumulate hands them on)
     u32* d_xrec[2] = {nullptr, nullptr}; u64 cap_xrec[2] = {0, 0};      // item records of k_ext_prep (one per work item of a submission), per instantiation
     u64 bytes_arena = 0, bytes_sieve = 0, bytes_table = 0; double bitmap_fill = 0.0;
     EngineDev E; EngineDev* d_E = nullptr;      // host copy and its device-resident twin
@@ -2929,7 +3162,8 @@ struct mlst_handle {
     u32* d_packed = nullptr; u8* d_qrows = nullptr; u16* d_lens = nullptr; u64 cap_packed_words = 0, cap_qrow_bytes = 0, cap_lens = 0;
     u64 reads_seen = 0;
     u32 max_wpr = 0;                             // widest read rows submitted since the last reset (picks the k_pileup instantiation)
-    int ext_threads = 256, ext_blocks = 1024;    // k_extend launch shape (set in mlst_load_reference)
+    int ext_threads = 64, ext_blocks = 5120;     // k_extend launch shape (set in mlst_load_reference)
+    int extp_threads = 256, extp_blocks = 1792; u32 pair_loci = 0;      // k_extend_pairs: launch shape, loci it takes
     int sieve_g_blocks = 256 * 5;                // k_sieve_q<.,false> grid (MLST_SIEVE_BLOCKS overrides it)
     u8* d_fq_text = nullptr;                    // the text buffer of the chunk being parsed: one of d_fq_slot[] (not owned)
     u32* d_fq_blk = nullptr; u64 cap_fq_blk = 0;
@@ -3104,6 +3338,7 @@ static void free_state(mlst_handle* h) {
     hipFree(E.ret_mate); hipFree(E.ret_item0); hipFree(E.ret_nitems); E.ret_mate = nullptr; E.ret_item0 = nullptr; E.ret_nitems = nullptr;
     hipFree(E.items); hipFree(E.item_state); hipFree(E.res); hipFree(E.dp_list);
     for (int k = 0; k < 2; k++) { hipFree(h->d_xrec[k]); h->d_xrec[k] = nullptr; h->cap_xrec[k] = 0; }
+    hipFree(h->d_acc64); h->d_acc64 = nullptr;
     hipFree(h->d_locus_chosen); hipFree(h->d_locus_colbase); hipFree(h->d_pl_list); hipFree(h->d_tb);
     E.sum_score = nullptr; E.n_hits = nullptr; E.locus_len = E.locus_first = nullptr; E.ctr = nullptr; E.ret_bases = nullptr; E.ret_quals = nullptr;
     E.ret_len = nullptr; E.ret_ridx = nullptr; E.ret_nrec = nullptr; E.items = nullptr; E.item_state = nullptr; E.res = nullptr; E.dp_list = nullptr;
@@ -3440,7 +3675,7 @@ static int sieve_kind_from_env() {
     return -1;
 }
 
-// dynamic LDS of k_extend_160 (k = 0) / _320: the haplotype summaries + the identity, then the pending additions of the item
+// dynamic LDS of k_extend_160 (k = 0) / _320: the haplotype summaries + the identity, the pending additions of the item (2 B per allele)
 static size_t ext_lds_bytes(const mlst_handle* h, int k) { return (size_t)(h->ext_lds_recs[k] + 1) * 16 + (size_t)h->ext_acc_cap * 2; }
 // Build the device-resident reference: transposed 2-bit allele arena, N masks, seed sieve and exact seed table.
 extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const uint64_t* off, const uint32_t* locus_id,
@@ -3511,7 +3746,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     h->bytes_hap = HI->hap_rec.size() * sizeof(HapRec) + HI->hap_blk.size() * 4 + HI->hap_id.size() * 4; h->n_hap_rec = HI->hap_rec.size();
     h->hap_win_max[0] = HI->hap_win_max[0]; h->hap_win_max[1] = HI->hap_win_max[1]; h->hap_loci = HI->hap_loci;
     h->bytes_arena = arena.size() * 4 + planes.size() * 4 + nmask.size() * 4; h->bytes_sieve = nb * 16 + bitmap.size() * 4 + gbitmap.size() * 4 + HI->rfilter.size() * 4; h->bytes_table = tcap * 12 + posts.size() * 4;
-    h->loci = loci; h->aoff.assign(off, off + n_alleles + 1);
+    h->aoff.assign(off, off + n_alleles + 1);
     {   // device-side typing: allele numbers, one slot of max_len columns per locus
         HIPCHK(h, dmalloc(&h->d_allele_no, (u64)n_alleles)); HIPCHK(h, hipMemcpy(h->d_allele_no, allele_no, (u64)n_alleles * 4, hipMemcpyHostToDevice));
         h->fixed_colbase.assign(n_loci + 1, 0);
@@ -3556,26 +3791,43 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     HIPCHK(h, dmalloc(&h->d_locus_colbase, (u64)n_loci * 2 + 2));   // [colbase u64 x L][chosen int x L]
     HIPCHK(h, dmalloc(&h->d_pl_list, E.cap_items));
     HIPCHK(h, dmalloc(&h->d_tb, (u64)64 * 64 * MLST_MAX_READ_LEN * (2 * MAX_W + 1)));
+    HIPCHK(h, dmalloc(&h->d_acc64, (u64)n_alleles)); HIPCHK(h, hipMemset(h->d_acc64, 0, (u64)(n_alleles ? n_alleles : 1) * 8)); E.acc64 = h->d_acc64;
     HIPCHK(h, dmalloc(&h->d_E, (u64)1)); HIPCHK(h, hipMemcpy(h->d_E, &h->E, sizeof(EngineDev), hipMemcpyHostToDevice));
-    {   // k_extend launch shape: threads per work item from the largest locus (MLST_EXT_THREADS / MLST_EXT_BLOCKS override it)
-        // lanes = alleles.  An item costs a workgroup ~8 us of staging and barriers whatever its size, so what counts is how
-        // many items are in flight.  Up to 512 alleles per locus (at most 8 passes of one wave): one-wave workgroups, 7168
-        // of them -- cfg3 (300 alleles, 121 k items): 0.55 ms; 128 / 192 / 320 / 384 threads: 0.61 / 0.69 / 0.86 / 1.01 ms.
-        // Larger loci: 256 threads -- cfg2 (1430 alleles, 9 k items): 0.18 ms against 0.31 ms with one wave, whose 23 serial
-        // passes per item become the tail of the kernel.
-        u32 mx = 0; for (auto& L : loci) mx = std::max(mx, L.n_alleles);
-        int thr = mx <= 512 ? 64 : 256;
+    {   // Which extension kernel takes a locus (this engine's decision, in its own copy of the locus table):
+        // k_extend (block-haplotype summaries, one-wave workgroups) the loci that have the tables, at most MLST_EXT_HAP_MAX
+        // alleles (default 512: eight turns of one wave) and windows that fit the LDS budget (MLST_EXT_LDS_KB, default 96 of
+        // the CU's 160 KB; 0 = no locus); k_extend_pairs (every pair on its own, rounds 1-3) the others.  Measured on
+        // cfg2 (1,430 alleles per locus, 9 k items): haplotype form 0.40 / 0.25 / 0.19 ms with 64 / 128 / 256 threads per
+        // item, pair form 0.18 ms: few items, and an item's chain of phases does not get shorter with its width.
+        u32 hap_max = 512; const char* e0 = getenv("MLST_EXT_HAP_MAX"); if (e0 && atoi(e0) >= 0) hap_max = (u32)atoi(e0);
+        u32 budget_kb = 96; const char* e4 = getenv("MLST_EXT_LDS_KB"); if (e4 && atoi(e4) >= 0 && atoi(e4) <= 150) budget_kb = (u32)atoi(e4);
+        std::vector<LocusDev> lc = loci;
+        u32 mx_hap = 0, mx_pair = 0, n_hap = 0, n_pair = 0; h->hap_win_max[0] = h->hap_win_max[1] = 0;
+        for (auto& L : lc) {
+            const bool take = L.hap_ok && L.n_alleles <= hap_max && (u64)L.hap_win[1] * 16 <= (u64)budget_kb * 1024;
+            L.hap_ok = take ? 1u : 0u;
+            if (take) { n_hap++; mx_hap = std::max(mx_hap, L.n_alleles); for (int k = 0; k < 2; k++) h->hap_win_max[k] = std::max(h->hap_win_max[k], L.hap_win[k]); }
+            else { n_pair++; mx_pair = std::max(mx_pair, L.n_alleles); }
+        }
+        h->loci = lc; h->hap_loci = n_hap; h->pair_loci = n_pair;
+        HIPCHK(h, hipMemcpy(h->d_loci, lc.data(), (u64)n_loci * sizeof(LocusDev), hipMemcpyHostToDevice));
+        // launch shapes: threads per work item (lanes = alleles) and workgroups (the work queues balance the rest).
+        // MLST_EXT_THREADS / MLST_EXT_BLOCKS override those of the haplotype kernel, MLST_EXTP_THREADS / _BLOCKS the other's.
+        int thr = mx_hap <= 512 ? 64 : 256;
         const char* e1 = getenv("MLST_EXT_THREADS"); if (e1 && atoi(e1) >= 64 && atoi(e1) <= 1024 && atoi(e1) % 64 == 0) thr = atoi(e1);
-        int blocks = 1792 * 256 / thr;     // 7 waves per SIMD (k_extend_160 is held to 72 VGPRs); the work queue balances the rest
+        int blocks = 1280 * 256 / thr;     // 5 waves per SIMD at ~100 VGPRs (one-wave workgroups: 5,120)
         const char* e2 = getenv("MLST_EXT_BLOCKS"); if (e2 && atoi(e2) > 0) blocks = atoi(e2);
         h->ext_threads = thr; h->ext_blocks = blocks;
-        // haplotype summaries kept in LDS per work item: what the widest window of any locus needs, up to a budget
-        // (MLST_EXT_LDS_KB, default 96 of the CU's 160 KB; 0 switches the block-haplotype path off).  Loci whose windows
-        // need more take the pair-by-pair path inside the same launch.
-        u32 budget_kb = 96; const char* e4 = getenv("MLST_EXT_LDS_KB"); if (e4 && atoi(e4) >= 0 && atoi(e4) <= 150) budget_kb = (u32)atoi(e4);
-        h->ext_acc_cap = std::min<u32>((mx + 63u) & ~63u, 16384u);
+        // pair kernel: one-wave workgroups up to 512 alleles per locus, 256 threads beyond (cfg2: 0.18 ms against 0.31 with one wave)
+        int thr2 = mx_pair <= 512 ? 64 : 256;
+        const char* e5 = getenv("MLST_EXTP_THREADS"); if (e5 && atoi(e5) >= 64 && atoi(e5) <= 1024 && atoi(e5) % 64 == 0) thr2 = atoi(e5);
+        int blocks2 = 1792 * 256 / thr2;   // 7 waves per SIMD (k_extend_pairs_160 is held to 72 VGPRs)
+        const char* e6 = getenv("MLST_EXTP_BLOCKS"); if (e6 && atoi(e6) > 0) blocks2 = atoi(e6);
+        h->extp_threads = thr2; h->extp_blocks = blocks2;
+        // dynamic LDS of the haplotype kernel: the summaries of the widest window of its loci, the pending additions of an item
+        h->ext_acc_cap = std::min<u32>((mx_hap + 63u) & ~63u, 16384u);
         for (int k = 0; k < 2; k++) {
-            h->ext_lds_recs[k] = std::min<u32>(h->hap_win_max[k], budget_kb * 1024u / 16u);
+            h->ext_lds_recs[k] = h->hap_win_max[k];
             if (ext_lds_bytes(h, k) > 48u * 1024u)
                 HIPCHK(h, hipFuncSetAttribute(k ? (const void*)k_extend_320 : (const void*)k_extend_160, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ext_lds_bytes(h, k)));
         }
@@ -3682,7 +3934,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     if (h->sieve_kind == MLST_SIEVE_ROUTED) { int rc = ensure_route_buffers(h, n_reads, wpr); if (rc) return rc; }
     {   // item records of k_ext_prep: one per work item a sample may hold (allocated on first use of an instantiation)
         const int k = wpr <= 10 ? 0 : 1; const u64 words = k ? (u64)XRec<RW / 2>::WORDS : (u64)XRec<5>::WORDS;
-        if (!h->d_xrec[k]) { hipStreamSynchronize(h->stream); HIPCHK(h, dmalloc(&h->d_xrec[k], h->E.cap_items * words)); h->cap_xrec[k] = h->E.cap_items; }
+        if (h->hap_loci && !h->d_xrec[k]) { hipStreamSynchronize(h->stream); HIPCHK(h, dmalloc(&h->d_xrec[k], h->E.cap_items * words)); h->cap_xrec[k] = h->E.cap_items; }
     }
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
                                                (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand,
@@ -3736,13 +3988,19 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
       // (one pair of reads per workgroup and sweep, every sweep a chain of dependent scattered loads: a large grid keeps the
       // sweeps few -- 1024 workgroups took 59 sweeps = 112 us for the 121 k retained reads of cfg3)
       hipLaunchKernelGGL(k_retain, dim3(2048), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
-    { Prof pf(h, 12);     // item records (the read on the allele's block grid, the locus' fields, the block table)
-      if (wpr <= 10) hipLaunchKernelGGL(k_ext_prep<5>, dim3(2048), dim3(256), 0, h->stream, h->d_E, h->kp, h->d_xrec[0], h->cap_xrec[0]);
-      else hipLaunchKernelGGL(k_ext_prep<RW / 2>, dim3(2048), dim3(256), 0, h->stream, h->d_E, h->kp, h->d_xrec[1], h->cap_xrec[1]); }
-    { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
-      const int thr = h->ext_threads, blocks = h->ext_blocks;
-      if (wpr <= 10) hipLaunchKernelGGL(k_extend_160, dim3(blocks), dim3(thr), ext_lds_bytes(h, 0), h->stream, h->d_E, h->kp, h->ext_lds_recs[0], h->ext_acc_cap, h->d_xrec[0], h->cap_xrec[0]);
-      else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(thr), ext_lds_bytes(h, 1), h->stream, h->d_E, h->kp, h->ext_lds_recs[1], h->ext_acc_cap, h->d_xrec[1], h->cap_xrec[1]); }
+    if (h->hap_loci) {
+      { Prof pf(h, 12);     // item records (the read on the allele's block grid, the locus' fields, the block table)
+        if (wpr <= 10) hipLaunchKernelGGL(k_ext_prep<5>, dim3(2048), dim3(256), 0, h->stream, h->d_E, h->kp, h->d_xrec[0], h->cap_xrec[0]);
+        else hipLaunchKernelGGL(k_ext_prep<RW / 2>, dim3(2048), dim3(256), 0, h->stream, h->d_E, h->kp, h->d_xrec[1], h->cap_xrec[1]); }
+      { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
+        const int thr = h->ext_threads, blocks = h->ext_blocks;
+        if (wpr <= 10) hipLaunchKernelGGL(k_extend_160, dim3(blocks), dim3(thr), ext_lds_bytes(h, 0), h->stream, h->d_E, h->kp, h->ext_lds_recs[0], h->ext_acc_cap, h->d_xrec[0], h->cap_xrec[0]);
+        else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(thr), ext_lds_bytes(h, 1), h->stream, h->d_E, h->kp, h->ext_lds_recs[1], h->ext_acc_cap, h->d_xrec[1], h->cap_xrec[1]); }
+    }
+    if (h->pair_loci) { Prof pf(h, 2);      // the loci the haplotype kernel does not take
+      const int thr = h->extp_threads, blocks = h->extp_blocks;
+      if (wpr <= 10) hipLaunchKernelGGL(k_extend_pairs_160, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp);
+      else hipLaunchKernelGGL(k_extend_pairs_320, dim3(blocks), dim3(thr), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 3); hipLaunchKernelGGL(k_banded, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp); }
     { Prof pf(h, 4); hipLaunchKernelGGL(k_accumulate, dim3(1024), dim3(256), 0, h->stream, h->d_E, h->kp);
       hipLaunchKernelGGL(k_locus, dim3(128), dim3(1024), 0, h->stream, h->d_E, paired); }

@@ -110,6 +110,8 @@ def main():
     ref = None
     for v, e, _ in engines:
         info = e.extend_info()
+        if os.environ.get("MLST_X_SKIP") and hasattr(e.lib, "mlst_debug_ext_skip"):
+            e.lib.mlst_debug_ext_skip(int(os.environ["MLST_X_SKIP"]))
         e.reset_sample()
         e.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), n, wpr, qstride)
         st = e.stats()
@@ -136,13 +138,20 @@ def main():
             import ctypes as C
             buf = (C.c_uint64 * 8)()
             e.lib.mlst_debug_ext_trace(buf, 1)
+            if hasattr(e.lib, "mlst_debug_ext_cnt"):
+                e.lib.mlst_debug_ext_cnt((C.c_uint64 * 8)(), 1)
             e.reset_sample()
             e.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), n, wpr, qstride)
             e.synchronize()
             e.lib.mlst_debug_ext_trace(buf, 1)
             t = [int(v) for v in buf]
             names = ("record", "requests", "summaries", "composition", "counts+fused", "handover")
-            trace = {"items": t[6], "waves": t[7], "cycles_per_item": {k: round(v / max(t[6], 1), 1) for k, v in zip(names, t[:6])}}
+            cnt = None
+            if hasattr(e.lib, "mlst_debug_ext_cnt"):
+                b2 = (C.c_uint64 * 8)()
+                e.lib.mlst_debug_ext_cnt(b2, 1)
+                cnt = {"fast_items": int(b2[0]), "fallback_items": int(b2[1]), "span_pairs": int(b2[2]), "turns_with_span_pair": int(b2[3])}
+            trace = {"counts": cnt, "items": t[6], "waves": t[7], "cycles_per_item": {k: round(v / max(t[6], 1), 1) for k, v in zip(names, t[:6])}}
         out["variants"][v] = {"extend_ms_median": round(float(np.median(times)), 4), "prep_ms_median": round(float(np.median(prep)), 4), "min": round(min(times), 4), "max": round(max(times), 4),
                               "same_statistics_as_first": bool(same), "records": int(st.counters[0]), "info": info, "trace": trace}
         print(v, out["variants"][v], flush=True)
