@@ -45,7 +45,7 @@ ALG_BYTES_BASES = 40      # 2-bit bases of a 150 bp read, rounded to the 10-word
 ALG_BYTES_SURVEY = 188    # 38 B 2-bit bases + 150 B Phred per 150 bp read (reported beside, never used for frac)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GINSTR = 930.0  # measured simple-op issue rate of the whole chip, G wave-instructions/s (profiles/round1/valu_rate2.txt)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "round3")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "round4")
 
 
 def parse_args():
@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--host-profile", default=None, help="diagnostics: cProfile of the host loop over 200 extra (untimed) steps, written to this file")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="timed blocks of --steps steps are repeated until this much has been timed")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"], help="workload of the headline line")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "skewed"], help="workload of the headline line")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU and batch (default: 50 M for cfg3, 10 M for cfg2)")
     ap.add_argument("--species", type=int, default=150)
     ap.add_argument("--alleles", type=int, default=0, help="alleles per locus (default: 300 for cfg3, 1430 for cfg2)")
@@ -113,6 +113,17 @@ def build_workload(name, args, eng_factory, torch, device, rank, n_batches, tmp)
         w.label = ("cfg3: %d x %d bp SE reads per GPU, mixed metagenome of %d genomes (%.1f Mb each, log-normal abundances), synthetic DB-full "
                    "%d species x 7 loci x %d alleles (stand-in for metamlstDB_2022, which is not available offline)"
                    % (w.reads, args.read_len, len(w.plan), w.genome_size / 1e6, args.species, alleles))
+    elif name == "skewed":
+        # a PubMLST-shaped database (VERDICT r3 item 1 / missing 4; the real one, metaMLST_functions.py:39-57 with the schema of
+        # metamlst-index.py:62-65, has loci with tens to thousands of alleles): alleles per locus log-uniform 10 ... 10,000
+        w.reads = args.reads or 20_000_000
+        w.genome_size = args.genome_size or 2_000_000
+        w.sdb = synth.make_skewed_db(os.path.join(tmp, "skewed.db"), n_species=6, hi=10_000)
+        w.plan = synth.metagenome_plan(w.sdb, 6)
+        w.planted = {sp: st_row + 1 for sp, _, st_row in w.plan}
+        counts = sorted(w.sdb.n_alleles.values())
+        w.label = ("skewed: %d x %d bp SE reads, metagenome of %d genomes, PubMLST-shaped synthetic database: %d loci with %d ... %d alleles "
+                   "(median %d; synth.make_skewed_db)" % (w.reads, args.read_len, len(w.plan), len(counts), counts[0], counts[-1], counts[len(counts) // 2]))
     else:
         alleles = args.alleles or 1430
         w.reads = args.reads or 10_000_000
@@ -135,7 +146,7 @@ def build_workload(name, args, eng_factory, torch, device, rank, n_batches, tmp)
     t0 = time.time()
     w.batches, w.genomes = [], {}
     for b in range(n_batches):
-        if name == "cfg3":
+        if name in ("cfg3", "skewed"):
             packed, qrows, lens, wpr, qstride, n_total = synth.make_metagenome_gpu(
                 w.engines[0], torch, device, w.sdb, w.plan, w.reads, w.genome_size, seed=7 + 100 * rank + b, read_len=args.read_len, genomes=w.genomes)
         else:
@@ -166,12 +177,15 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
     # share at least one engine
     n_parts = max(1, min(args.cu_partitions, depth)) if args.cu_partitions else max(p2 for p2 in (1, 2, 4, 8) if p2 <= depth)
 
+    placed = {"on": False}
+
     def place(on: bool):
         """Engines on their own shares of the CUs (the timed blocks) or all on the whole device (isolated launches, serial
         steps: the figures behind `roofline` are those of a kernel that has the GPU to itself)."""
         for k, e in enumerate(engines):
             e.synchronize()
             e.set_cu_partition(k % n_parts if on else 0, n_parts if on else 1)
+        placed["on"] = bool(on)
 
     place(world > 1)      # N > 1: the shards run on the engines' own streams from the start (and the isolated launches on a share)
     shards = [StreamedShard(e, device) for e in engines] if world > 1 else None
@@ -252,51 +266,51 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
         return tail(k, None if host_driven else wait(k))
 
     calls = {}
+    # the loop itself is the product's: metamlst_amd/pipeline.py (cli type folder/, multigpu.type_many_samples run the same one)
+    from metamlst_amd.pipeline import TypingPipeline
+    pipe = TypingPipeline(engines, penalty=100)
 
     def run(n_steps):
-        """K steps through the `depth` engines.  An engine is free again as soon as its step's results are on the host, so
-        the next step for it is queued BEFORE the host tail of the one just fetched (.nfo lines, ST calls: 0.9 ms of
-        Python): the GPU always has `depth` steps to work on.  (Queued after the tail, as until round 3, the four steps
-        that start a block together also finish together, the host works off four tails in a row while the GPU runs dry,
-        and a block of 20 steps never leaves that pattern.)  Steps are fetched in the order they were queued (taking
-        whichever engine has finished first, or putting tails off while an engine waits for its next step, measured no
-        better: profiles/round3/ab.md); with N > 1 the ranks must issue their collectives in one order anyway."""
+        """K steps through the `depth` engines (TypingPipeline.run: an engine is free again as soon as its step's results are on
+        the host, so the next step for it is queued BEFORE the host tail of the one just fetched; steps are fetched in the
+        order they were queued -- with N > 1 the ranks must issue their collectives in one order anyway).  The host-driven
+        exchange (N > 1 when the streamed form is switched off) keeps its own loop: there the engine is busy until its tail
+        has run."""
         last = None
         calls.clear()
         host_driven = world > 1 and not mode["streamed"]
-        ahead = depth - 1 if host_driven else depth      # host-driven exchange: the engine is busy until its tail has run
-        # the first submissions of a block 0.75 ms apart when every engine has its own share of the CUs: started in the same
-        # instant the four launch sequences stay in step (all in k_route, then all in k_route_probe ...) for a round or two;
-        # 0.5-1 ms apart they mix from the start: 2.62-2.66 -> 2.56-2.57 ms per step in blocks of 20, the 2.3 ms of waiting
-        # included (1.5 ms apart: 2.62-2.64; 2.5 ms: 2.73)
-        stagger = (args.stagger_ms if args.stagger_ms is not None else (0.75 if n_parts > 1 else 0.0)) * 1e-3
-        for k in range(min(ahead, n_steps)):
-            if k and stagger:
-                time.sleep(stagger)
-            submit(k)
-        for k in range(n_steps):
-            if host_driven:
+        if host_driven:
+            ahead = depth - 1
+            for k in range(min(ahead, n_steps)):
+                submit(k)
+            for k in range(n_steps):
                 if k + ahead < n_steps:
                     submit(k + ahead)
                 last = tail(k)
-            elif world == 1:
-                # wait, queue the engine's next step, THEN copy the results of the finished one out of their pinned slot
-                # (mlst_typing_wait / mlst_typing_fetch_waited): on its own share of the CUs an engine idles from the end of a
-                # step to the submission of the next
-                e = engines[k % depth]
-                t_b = time.perf_counter()
-                e.typing_wait()
-                host_ms["wait_device"] += (time.perf_counter() - t_b) * 1e3
-                if k + ahead < n_steps:
-                    submit(k + ahead)
-                last = tail(k, e.typing_fetch(bool(mode.get("full_fetch")), waited=True))
-            else:
-                got = wait(k)
-                if k + ahead < n_steps:
-                    submit(k + ahead)
-                last = tail(k, got)
-            calls[k % depth] = last[0]       # the ST calls of the most recent step on every batch
-        return last
+                calls[k % depth] = last[0]
+            return last
+        # the first submissions of a block 0.75 ms apart when every engine has its own share of the CUs (2.62-2.66 -> 2.56-2.57 ms
+        # per step in blocks of 20, the waiting included; 1.5 ms apart: 2.62-2.64; 2.5 ms: 2.73)
+        pipe.shards = shards if world > 1 else None
+        pipe.stagger_s = (args.stagger_ms if args.stagger_ms is not None else (0.75 if n_parts > 1 else 0.0)) * 1e-3
+        pipe.partitions = n_parts if placed["on"] else 1
+        for k_ in pipe.host_ms:
+            pipe.host_ms[k_] = 0.0
+
+        def feed(e, k):
+            packed, qrows, lens, n = w.batches[k % depth]
+            e.set_read_index_base(rank * n)
+            e.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), n, w.wpr, w.qstride)
+
+        def tail_k(k, *got):
+            out = tail(k, got)
+            calls[k % depth] = out[0]
+            return out
+
+        outs = pipe.run(range(n_steps), feed, tail_k, per_allele=bool(mode.get("full_fetch")))
+        host_ms["submit"] += pipe.host_ms["submit"]
+        host_ms["wait_device"] += pipe.host_ms["wait_device"]
+        return outs[-1] if outs else None
 
     def fence():
         for e in engines:
@@ -473,7 +487,7 @@ def rooflines(w, res, eng):
         tr = pmc.get(kernel, {}).get("hbm_bytes_per_launch")
         return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": int(tr * w.n_reads / pmc.get("reads_per_launch", w.n_reads)) if tr else None,
-                "traffic_source": ("profiles/round3/pmc_%s.json: rocprofv3 --pmc passes of this command (profiles/pmc_round2.sh), committed -- not measured by this run" % w.name) if tr else None,
+                "traffic_source": ("profiles/round4/pmc_%s.json: rocprofv3 --pmc passes of this command (profiles/pmc_round2.sh), committed -- not measured by this run" % w.name) if tr else None,
                 "alg_bytes_per_read": ALG_BYTES_BASES, "reads_per_launch": w.n_reads, "avg_launch_ms": round(ms, 4),
                 "launch_ms_spread": res.get("iso_launch_spread", {}).get(key),
                 "duration_source": "HIP events on the engine's stream around each of 20 serial launches, median (= rocprofv3 --kernel-trace average of --pipeline 1)",
@@ -498,7 +512,7 @@ def rooflines(w, res, eng):
         scale = pairs / max(1, pmc.get("k_extend", {}).get("pairs_per_launch", pairs))
         rext["achieved"] = round(valu * scale / (ext_ms * 1e-3) / 1e9, 1)
         rext["frac"] = round(rext["achieved"] / VALU_PEAK_GINSTR, 4)
-        rext["valu_count_source"] = "profiles/round3/pmc_%s.json (SQ_INSTS_VALU of a rocprofv3 --pmc pass, committed); the duration is this run's" % w.name
+        rext["valu_count_source"] = "profiles/round4/pmc_%s.json (SQ_INSTS_VALU of a rocprofv3 --pmc pass, committed); the duration is this run's" % w.name
     return roof, rext
 
 
@@ -721,7 +735,7 @@ def main():
            "counters": {"records": int(stats.counters[0]), "ignored": int(stats.counters[1]), "candidates": int(stats.counters[3]),
                         "retained": int(stats.counters[4]), "items": int(stats.counters[5]), "banded_sw_pairs": int(stats.counters[6]),
                         "routed_filter_passes": int(stats.counters[7])},
-           "index_bytes": dict(zip(("allele_arena", "sieve", "seed_table"), eng.index_bytes()[:3])),
+           "index_bytes": dict(zip(("allele_arena_and_haplotype_tables", "sieve", "seed_table"), eng.index_bytes()[:3])), "extend": eng.extend_info(),
            "setup_s": {"database": round(w.t_db, 1), "index_host": round(w.t_index_host, 1), "index_device_x%d" % depth: round(w.t_index_dev, 1),
                        "resident_reads_x%d" % depth: round(w.t_reads, 1)},
            "world_size_reported_by_backend": (dist.get_world_size() if world > 1 else 1), "literal_parity_bowtie2": None}
@@ -743,6 +757,25 @@ def main():
                      "end_to_end": end_to_end(w2, a2, torch, device)}
         out["literal_parity_bowtie2"] = literal_leg(w2, a2, torch, tmp)
     out["secondary_cfg2"] = secondary
+    # ---- the same step on a PubMLST-shaped database (alleles per locus 10 ... 10,000): what the real database's skew does to it
+    skewed = None
+    if world == 1 and not args.no_secondary and args.workload == "cfg3":
+        for e in w2.engines:
+            e.close()
+        del w2.batches
+        torch.cuda.empty_cache()
+        a3 = argparse.Namespace(**vars(args)); a3.reads = 0; a3.alleles = 0; a3.genome_size = 0
+        w3 = build_workload("skewed", a3, lambda: Engine(local_rank), torch, device, rank, depth, tmp)
+        r3 = run_workload(w3, a3, torch, dist, device, rank, world, backend)
+        e3 = w3.engines[0]
+        skewed = {"config": summarize(w3, r3, e3, world, depth), "value": round(r3["value"], 2), "unit": "Mreads/s",
+                  "ms_per_step": round(r3["ms_per_step"], 4), "serial_ms_per_step": round(r3["serial_ms_per_step"], 4),
+                  "kernel_ms_per_launch_isolated": {k: round(v, 4) for k, v in r3["iso_launch_ms"].items()},
+                  "extend": e3.extend_info(), "items": int(r3["stats"].counters[5]), "records": int(r3["stats"].counters[0]),
+                  "species_typed_as_planted": "%d of %d (with thousands of alleles 3 %% apart many differ only in columns a local aligner clips: metamlst.py:244 then takes the lowest number)"
+                                               % (int(sum(r3["typed_ok"].values())), len(w3.planted)),
+                  "timed_region": {"blocks": r3["blocks"], "timed_s": r3["timed_s"]}}
+    out["secondary_skewed"] = skewed
     out["wall_s"] = round(time.time() - t_start, 1)
     print(json.dumps(out))
     if world > 1:

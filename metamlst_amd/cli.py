@@ -160,12 +160,19 @@ def run_type(a, argv=None) -> int:
     prm.max_retained_reads, prm.max_items, prm.max_pair_results = a.max_retained, a.max_items, a.max_pair_results
     eng = Engine(a.device, prm)
     eng.load_reference(idx)
+    engines = [eng]
+    if many:      # the pipelined loop (metamlst_amd/pipeline.py): a few engines take turns on this rank's samples
+        n_mine = (len(samples) + world - 1) // world
+        for _ in range(max(0, min(int(os.environ.get("MLST_PIPELINE_DEPTH", "4")), n_mine) - 1)):
+            e2 = Engine(a.device, prm)
+            e2.load_reference(idx)      # (the host index is cached inside the library: an upload, not a build)
+            engines.append(e2)
     targs = TypingArgs(penalty=a.penalty, minscore=a.minscore, max_xM=a.max_xM, min_read_len=a.min_read_len,
                        min_accuracy=a.min_accuracy, nloci=a.nloci, a=a.a, quiet=a.quiet, filter=a.filter, log=a.log)
     chunk_bytes = int(os.environ.get("MLST_FASTQ_CHUNK", str(256 << 20)))
     if many:
         from .multigpu import type_many_samples
-        rc = type_many_samples(eng, idx, database, targs, samples, rank, world, a.o, a.log, chunk_bytes,
+        rc = type_many_samples(engines, idx, database, targs, samples, rank, world, a.o, a.log, chunk_bytes,
                                printer=None if a.quiet else (lambda results: _print_results(a, results)))
         database.closeConnection()
         return rc
@@ -177,7 +184,7 @@ def run_type(a, argv=None) -> int:
         read_len, stride = (int(x) for x in a.tile.split(","))
         for chunk in tile_fasta(a.READS, read_len, stride, a.min_read_len):
             eng.submit_fastq(chunk, paired=False)
-        return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)
+        return _finish_type_device(a, eng, idx, database, targs)
     # Mates are unpaired reads for the aligner (bowtie2 -U r1,r2).  What a shared read name changes is sequenceBank
     # (metamlst.py:127: one entry per QNAME and locus): pairs whose files name both mates alike are submitted as pairs.
     paired = bool(a.mates) and mates_share_names(a.READS, a.mates)
@@ -198,7 +205,15 @@ def run_type(a, argv=None) -> int:
         return 0
     # FASTQ text goes to the GPU as is and is parsed there (mlst_submit_fastq); a reader thread stays two chunks ahead
     submit_sample_files(eng, paths, paired, chunk_bytes)
-    return _finish_type(a, idx, database, targs, eng.stats(), eng.pileup)
+    return _finish_type_device(a, eng, idx, database, targs)
+
+
+def _finish_type_device(a, eng, idx, database, targs) -> int:
+    """Allele choice (metamlst.py:133-151, 244), pile-up and majority consensus on the device, queued behind pass 1
+    (mlst_typing_enqueue): one host synchronisation per sample instead of three (statistics, host choice, pile-up)."""
+    eng.typing_enqueue(penalty=targs.penalty)
+    st, chosen, letters = eng.typing_fetch()
+    return _finish_type(a, idx, database, targs, st, None, typed=(chosen, letters))
 
 
 def submit_sample_files(eng, paths, paired: bool, chunk_bytes: int) -> None:
@@ -215,14 +230,14 @@ def submit_sample_files(eng, paths, paired: bool, chunk_bytes: int) -> None:
             eng.submit_fastq(chunk, paired=False)
 
 
-def _finish_type(a, idx, database, targs, st, pileup_fn) -> int:
+def _finish_type(a, idx, database, targs, st, pileup_fn, typed=None) -> int:
     fileName = sample_name(a.READS)
     if not os.path.isdir(a.o):
         os.mkdir(a.o)
     if a.log:   # metamlst.py:159-172
         with open(a.o + "/" + fileName + "_" + str(int(time.time())) + ".out", "w", newline="") as f:
             f.write(log_table(idx, st, targs, a.READS))
-    results = type_sample(idx, st, pileup_fn, database, fileName, targs, out_dir=a.o)
+    results = type_sample(idx, st, pileup_fn, database, fileName, targs, out_dir=a.o, typed=typed)
     if not a.quiet:
         _print_results(a, results)
     database.closeConnection()

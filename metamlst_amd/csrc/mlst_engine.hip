@@ -1851,7 +1851,7 @@ __global__ __launch_bounds__(256) void k_ext_prep(const EngineDev* __restrict__ 
     typedef XRec<NB> X;
     const EngineDev& E = *Ep;
     __shared__ u32 s_rl[4][RW / 2 + 2]; __shared__ u32 s_rh[4][RW / 2 + 2]; __shared__ u32 s_rn[4][RW / 2 + 2]; __shared__ u32 s_odd[4][RW / 2 + 2];
-    __shared__ u8 s_pen[4][RQ]; __shared__ u8 s_pentab[128]; __shared__ u32 s_w[4][X::WORDS];
+    __shared__ u8 s_pentab[128]; __shared__ u32 s_w[4][X::WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < 128; i += 256) s_pentab[i] = E.pen_tab[i];
     __syncthreads();
@@ -1866,13 +1866,39 @@ __global__ __launch_bounds__(256) void k_ext_prep(const EngineDev* __restrict__ 
             const u8 state = E.item_state[ii];
             if (!L.hap_ok) { if (lane < 32) s_w[wv][lane] = 0; }      // the other kernel's item: a record without XF_HAPOK
             else {
-            const int pen_def = stage_read_planes(E, P, it, n, s_rl[wv], s_rh[wv], s_rn[wv], s_odd[wv], s_pen[wv], s_pentab, lane, 64);
+            // the read's planes (as stage_read_planes makes them), with every load of the item requested in one batch:
+            // lane = read position modulo 64, five turns; the block table rides along
             const int q0 = it.diag >> 5; const u32 rs = 32u - ((u32)it.diag & 31u);      // 1..32
             u32* w = s_w[wv];
-            if (lane <= X::NBA) {
-                int q = q0 + lane; q = q < 0 ? 0 : (q > (int)L.pblocks ? (int)L.pblocks : q);
-                w[X::HB + lane] = L.hap_ok ? E.hap_blk[L.hblk_off + (u32)q] : 0u;
+            auto rb = E.ret_bases.g() + (u64)it.ret * RW; auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
+            constexpr int KT = RQ / 64;
+            u32 qv[KT], bw[KT], qmid = rq[n >> 1], hbv = 0;
+            #pragma unroll
+            for (int k = 0; k < KT; k++) {
+                const int i = lane + 64 * k, sp = i < n ? (it.strand ? n - 1 - i : i) : 0;
+                qv[k] = rq[sp]; bw[k] = rb[sp >> 4];
             }
+            if (lane <= X::NBA) { int q = q0 + lane; q = q < 0 ? 0 : (q > (int)L.pblocks ? (int)L.pblocks : q); hbv = E.hap_blk[L.hblk_off + (u32)q]; }
+            tie_all<KT>(qv); tie_all<KT>(bw); TIE1(qmid); TIE1(hbv);
+            const u8 pen_def_b = (qmid >> 7) ? (u8)P.n_penalty : s_pentab[qmid & 0x7Fu];
+            const int pen_def = (int)pen_def_b;
+            #pragma unroll
+            for (int k = 0; k < KT; k++) {
+                const int i = lane + 64 * k; u32 b = 0, isn = 0, odd = 0;
+                if (i < n) {
+                    const int sp = it.strand ? n - 1 - i : i;
+                    b = (bw[k] >> (2 * (sp & 15))) & 3u; if (it.strand) b ^= 3u;
+                    isn = qv[k] >> 7;
+                    const u8 pen = isn ? (u8)P.n_penalty : s_pentab[qv[k] & 0x7Fu];
+                    odd = pen != pen_def_b;
+                }
+                const u64 bl = __ballot(b & 1u), bh = __ballot(b >> 1), bn = __ballot(isn != 0), bo = __ballot(odd != 0);
+                if (lane == 0) {
+                    s_rl[wv][2 * k] = (u32)bl; s_rl[wv][2 * k + 1] = (u32)(bl >> 32); s_rh[wv][2 * k] = (u32)bh; s_rh[wv][2 * k + 1] = (u32)(bh >> 32);
+                    s_rn[wv][2 * k] = (u32)bn; s_rn[wv][2 * k + 1] = (u32)(bn >> 32); s_odd[wv][2 * k] = (u32)bo; s_odd[wv][2 * k + 1] = (u32)(bo >> 32);
+                }
+            }
+            if (lane <= X::NBA) w[X::HB + lane] = hbv;
             u32 any = 0;
             if (lane <= NB) {
                 auto sh = [&](const u32* A) { const u64 v2 = ((u64)(lane < NB ? A[lane] : 0u) << 32) | (u64)(lane > 0 ? A[lane - 1] : 0u); return (u32)(v2 >> rs); };

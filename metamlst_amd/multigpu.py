@@ -192,29 +192,39 @@ def deal_samples(sizes: list[int], world: int) -> list[int]:
     return owner
 
 
-def type_many_samples(eng, idx, database, targs, samples: list[list[str]], rank: int, world: int, out_dir: str, log: bool,
+def type_many_samples(engines, idx, database, targs, samples: list[list[str]], rank: int, world: int, out_dir: str, log: bool,
                       chunk_bytes: int, printer=None) -> int:
     """Multi-sample mode (BASELINE configs[3]: "RCCL gather of per-species ST tables"; the reference's real use is many
     samples into one folder, one metamlst.py run each, metamlst-merge.py:93-107 reads the folder).  Whole samples are
-    dealt to the ranks -- no collective on the data path --, every rank types its samples on its GPU, and rank 0
-    gathers the .nfo lines (and --log tables) and writes them, sample by sample in the order given: byte for byte what
-    one run per sample writes."""
+    dealt to the ranks -- no collective on the data path --, every rank sends its samples through the pipelined typing
+    loop on its GPU (metamlst_amd/pipeline.py: `engines` take turns, a sample's allele choice, pile-up and consensus run
+    on the device behind its pass 1, the host writes sample k's line while the GPU works on the samples behind it), and
+    rank 0 gathers the .nfo lines (and --log tables) and writes them, sample by sample in the order given: byte for
+    byte what one run per sample writes."""
     import time
     from .cli import submit_sample_files
+    from .pipeline import TypingPipeline
     from .typing import log_table, sample_name, type_sample
     sizes = [sum(os.path.getsize(f) for f in files) for files in samples]
     owner = deal_samples(sizes, world)
-    mine = []
-    for i, files in enumerate(samples):
-        if owner[i] != rank:
-            continue
-        eng.reset_sample()
-        submit_sample_files(eng, files, False, chunk_bytes)
-        st = eng.stats()
+    jobs = [(i, files) for i, files in enumerate(samples) if owner[i] == rank]
+    pipe = TypingPipeline(engines if isinstance(engines, (list, tuple)) else [engines], penalty=targs.penalty)
+    parts = int(os.environ.get("MLST_CU_PARTITIONS", "0")) or TypingPipeline.default_partitions(pipe.depth)
+    if parts > 1:
+        pipe.place(parts)
+        pipe.stagger_s = 0.75e-3
+
+    def feed(e, job):
+        submit_sample_files(e, job[1], False, chunk_bytes)
+
+    def tail(job, st, chosen, letters):
+        i, files = job
         name = sample_name(files[0])
-        res = type_sample(idx, st, eng.pileup, database, name, targs, out_dir=None)
-        mine.append({"i": i, "name": name, "nfo": [r.nfo_line for r in res if r.written],
-                     "log": log_table(idx, st, targs, files[0]) if log else None, "results": res if printer else None})
+        res = type_sample(idx, st, None, database, name, targs, out_dir=None, typed=(chosen, letters))
+        return {"i": i, "name": name, "nfo": [r.nfo_line for r in res if r.written],
+                "log": log_table(idx, st, targs, files[0]) if log else None, "results": res if printer else None}
+
+    mine = pipe.run(jobs, feed, tail, per_allele=True)
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world if rank == 0 else None

@@ -364,7 +364,14 @@ def type_sample(index: AlleleIndex, st: SampleStats, pileup_fn, database: mdb.me
             plan.append((res, a))
     # pass 2 once for every species that passed (identical to one buildConsensus per species)
     # consensus_fn(list of allele indices) -> {allele idx: consensus bytes} (mlst_consensus) replaces counts + majority
-    letters = (typed[1] if (typed is not None and fast) else
+    if typed is not None and not fast:
+        # the listing above is the host's (metamlst.py:213-230 prints every allele's figures); choice and consensus came from
+        # the device (mlst_typing_enqueue).  The two statements of metamlst.py:244 are tested equal; should they ever differ,
+        # that is an error to be seen, not to be papered over with the host's pile-up
+        for _, a in plan:
+            if a not in typed[1]:
+                raise RuntimeError("device-side allele choice differs from metamlst.py:244 for %s" % index.label(a))
+    letters = (typed[1] if typed is not None else
                consensus_fn([a for _, a in plan]) if (plan and consensus_fn is not None) else None)
     counts = pileup_fn([a for _, a in plan]) if (plan and letters is None) else {}
     # gap-fill and SNP counts (the tail of buildConsensus) for all species at once when the letters come from the engine
