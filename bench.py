@@ -46,6 +46,7 @@ ALG_BYTES_SURVEY = 188    # 38 B 2-bit bases + 150 B Phred per 1
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GINSTR = 930.0  # measured simple-op issue rate of the whole chip, G wave-instructions/s (profiles/round1/valu_rate2.txt)
 PROFILE_DIR = os.path.join(ROOT, "profiles", "round4")
+_KEEP_ALIVE: list = []
 
 
 def parse_args():
@@ -187,8 +188,13 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
             e.set_cu_partition(k % n_parts if on else 0, n_parts if on else 1)
         placed["on"] = bool(on)
 
-    place(world > 1)      # N > 1: the shards run on the engines' own streams from the start (and the isolated launches on a share)
-    shards = [StreamedShard(e, device) for e in engines] if world > 1 else None
+    place(False)          # isolated launches and serial steps see the whole device at every N (the SCALE lines' `roofline` is BENCH's)
+    # N > 1: one process group per engine slot.  torch's NCCL backend runs a group's collectives on that group's own
+    # communicator and internal stream: with every engine on the default group, engine k + 1's statistics all-reduce would
+    # queue behind engine k's counts all-reduce, which waits for k's allele choice and pile-up (head-of-line blocking).
+    groups = [dist.new_group(ranks=list(range(world))) for _ in engines] if world > 1 else None
+    _KEEP_ALIVE.append(groups)      # (until dist.destroy_process_group(): a group dropped while the backend lives has taken the process down)
+    shards = [StreamedShard(e, device, group=g) for e, g in zip(engines, groups)] if world > 1 else None
     ports = [DeviceStatsPort(e, device) for e in engines] if world > 1 else None
     mode = {"streamed": world > 1}
     matcher = EngineMatcher(eng, idx)
@@ -389,8 +395,11 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
     serial_ms = (time.perf_counter() - t0) / n_serial * 1e3
     if world == 1 and n_parts > 1 and not args.cu_partitions and sum(v[0] for k_, v in isolated.items() if k_ in ("sieve", "seed", "extend", "banded_sw", "accumulate", "pileup")) < 1.0:
         n_parts = 1      # a step of well under a millisecond of kernels (cfg2: 0.35 ms) gains nothing from shares (0.342 -> 0.351 ms)
-    if world == 1 and n_parts > 1:      # from here on every engine has its own share of the CUs; graphs are rebuilt, warm-up again
+    if n_parts > 1:      # from here on every engine has its own share of the CUs; graphs are rebuilt, warm-up again
         place(True)
+        if shards:
+            for sh in shards:
+                sh.rebind()                  # (an engine's stream is created anew with its CU mask)
         for e_i in range(depth):
             for _ in range(3):
                 submit(e_i)
@@ -452,8 +461,11 @@ def run_workload(w, args, torch, dist, device, rank, world, backend):
             "iso_launch_ms": iso_launch, "iso_launch_spread": spread, "stats": stats, "st_call": st_call, "typed_ok": typed_ok, "batches_checked": len(calls),
             "collectives": ("streamed on a torch stream" if mode["streamed"] else "host-driven") if world > 1 else None,
             "cu_partitions": n_parts,
-            "iso_measured_on": ("whole device" if (world == 1 or n_parts == 1) else "share 1/%d of the CUs (N > 1: the engines keep their shares throughout)" % n_parts),
-            "exchange": ({"statistics_bytes": int(shards[0].t_all.numel()) * 8, "counts_layout": "compact" if shards[0].compact else "fixed",
+            "iso_measured_on": "whole device",
+            "exchange": ({"statistics_bytes": int(shards[0].stats_bytes_last), "statistics_bytes_fixed_layout": int(shards[0].t_all.numel()) * 8,
+                          "statistics_loci_listed": len(shards[0].listed), "process_groups": len(groups),
+                          "steps_repeated_for_statistics": sum(sh.stats_repeats for sh in shards),
+                          "counts_layout": "compact" if shards[0].compact else "fixed",
                           "counts_bytes": int(shards[0].cap_cols) * 16, "counts_bytes_fixed_layout": int(shards[0].total_cols) * 16,
                           "counts_columns_needed": (shards[0].needs[-1] if shards[0].needs else None),
                           "steps_repeated_for_capacity": sum(sh.repeats for sh in shards)} if (world > 1 and mode["streamed"]) else None)}
@@ -501,6 +513,7 @@ def rooflines(w, res, eng):
         ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         roof = {"kernel": cands[dom], "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None, "alg_bytes_per_pair": 48, "pairs_per_launch": pairs, "avg_launch_ms": round(ms, 4),
+                "measured_on": res.get("iso_measured_on", "whole device"),
                 "note": "VALU-bound kernel: see roofline_extend"}
     roof["dominant_by_time"] = dom
     roof["sieve_kernels"] = {v: hbm_roof(k, v) for k, v in stream_kernels.items()}

@@ -201,6 +201,29 @@ def pair_chunks(path1: str, path2: str, chunk_bytes: int = 128 << 20):
             c1, c2 = c1[a:], c2[b:]
 
 
+def pair_cuts(path1: str, path2: str, chunk_bytes: int = 128 << 20) -> list[tuple[int, int, int, int]]:
+    """(offset 1, bytes 1, offset 2, bytes 2) of the chunk pairs pair_chunks yields, for uncompressed files: ONE rank walks the
+    mate files (the cuts have to fall after the same record number in both, so somebody has to count lines) and the others
+    read their chunks by offset (multigpu.submit_fastq_shard)."""
+    cuts, o1, o2 = [], 0, 0
+    s1, s2 = os.path.getsize(path1), os.path.getsize(path2)
+    for c1, c2 in pair_chunks(path1, path2, chunk_bytes):
+        n1, n2 = min(len(c1), s1 - o1), min(len(c2), s2 - o2)      # (a newline added behind an unterminated last line is not in the file)
+        cuts.append((o1, n1, o2, n2))
+        o1 += n1; o2 += n2
+    return cuts
+
+
+def read_pair_cut(path1: str, path2: str, cut: tuple[int, int, int, int]) -> tuple[bytes, bytes]:
+    out = []
+    for path, off, n in ((path1, cut[0], cut[1]), (path2, cut[2], cut[3])):
+        with open(path, "rb") as f:
+            f.seek(off)
+            b = f.read(n)
+        out.append(b if b.endswith(b"\n") or not b else b + b"\n")
+    return out[0], out[1]
+
+
 def mates_share_names(path1: str, path2: str) -> bool:
     """True when the first records of the two mate files carry the same read name (the part of the header line before
     the first blank): `@x 1:N:0` / `@x 2:N:0` do, `@x/1` / `@x/2` do not -- and neither would they share a QNAME in the

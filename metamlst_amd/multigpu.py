@@ -120,17 +120,32 @@ def submit_fastq_shard(eng, paths: list[str], rank: int, world: int, chunk_bytes
     record boundary (fastq.text_chunks(start, end)): host reads and PCIe traffic are 1 / N of the file per rank.
     bgzip'd FASTQ: the same by whole BGZF blocks (fastq.bgzf_range_plan); the inflated text is resynchronised on the GPU side
     of the boundary (mlst_submit_fastq_bgzf's resync flags).
-    gzip (one deflate stream, no random access) and mate files (pairs are matched by record number): every rank walks
-    the files and submits the chunks whose number is its rank modulo N.
+    Mate files (pairs are matched by record number): rank 0 walks the two files once and broadcasts the byte offsets of the
+    chunk pairs (fastq.pair_cuts); every rank reads the chunks whose number is its rank modulo N by offset.
+    gzip (one deflate stream, no random access): every rank walks the file and submits the chunks whose number is its rank
+    modulo N -- the wall time of the decompression is that of one rank doing it alone either way, only host CPU is spent N
+    times; bgzip the file to shard it by blocks.
 
     Read-index bases are ORDER KEYS, not indices: what the typing needs from a read index is the first-seen order of loci
     (Q6, metamlst.py:244 iterates a dict filled in BAM order); a shard's base only has to be larger than every index
     of the shards before it.  Range r of file f gets (f * N + r) << 40, chunk k of a walked file k << 36 -- no rank has
     to know how many records the others hold."""
-    from .fastq import is_bgzf, pair_chunks, prefetch, text_chunks
+    from .fastq import is_bgzf, pair_chunks, pair_cuts, prefetch, read_pair_cut, text_chunks
     if paired:
         if len(paths) != 2:
             raise ValueError("paired input is two files of mates")
+        import torch.distributed as dist
+        plain = not any(p.endswith(".gz") or is_bgzf(p) for p in paths)
+        if plain and world > 1 and dist.is_initialized():
+            # rank 0 walks the two files once (the cuts must fall after the same record number in both: lines are counted)
+            # and hands the byte offsets out; every rank then reads only its own chunks (round 3: every rank walked both files)
+            box = [pair_cuts(paths[0], paths[1], chunk_bytes // 2) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            mine = [(k, cut) for k, cut in enumerate(box[0]) if k % world == rank]
+            for k, (c1, c2) in prefetch(((k, read_pair_cut(paths[0], paths[1], cut)) for k, cut in mine)):
+                eng.set_read_index_base(k << 36)
+                eng.submit_fastq_pair(c1, c2)
+            return
         for k, (c1, c2) in enumerate(prefetch(pair_chunks(paths[0], paths[1], chunk_bytes // 2))):
             if k % world == rank:
                 eng.set_read_index_base(k << 36)

@@ -211,3 +211,8 @@ def test_bench_five_ranks_on_one_gpu_reports_the_world():
     ex = line["config"]["exchange_per_step"]
     assert line["config"]["collectives"].startswith("streamed") and ex["counts_layout"] == "compact"
     assert ex["counts_columns_needed"] * 16 <= ex["counts_bytes"] < ex["counts_bytes_fixed_layout"] and ex["steps_repeated_for_capacity"] == 0
+    # ... the statistics of the loci that had hits in the steps before (4 x 7 of 84 loci), every engine slot on its own process
+    # group, and the kernel figures behind `roofline` taken with the whole device at N > 1 as at N = 1
+    assert ex["statistics_loci_listed"] == 28 and ex["statistics_bytes"] < ex["statistics_bytes_fixed_layout"] // 2
+    assert ex["steps_repeated_for_statistics"] == 0 and ex["process_groups"] == 2
+    assert line["roofline"]["measured_on"] == "whole device" 

@@ -514,18 +514,26 @@ def test_streamed_shard_step_on_a_torch_stream():
         sh = StreamedShard(eng, torch.device("cuda", 0), force_collectives=True)
         assert sh.compact and sh.cap_cols == sh.total_cols      # the first step exchanges the fixed layout's size
         need = sum(int(idx.locus_maxlen[l]) for l in want)       # slots of the loci with a chosen allele
-        caps = []
-        for k in range(4):                       # reuse across samples, as the bench loop does
+        caps, sbytes = [], []
+        fixed_bytes = int(sh.t_all.numel()) * 8
+        for k in range(5):                       # reuse across samples, as the bench loop does
             if k == 3:
                 sh.cap_cols = 1024               # too small for the seven loci: the second half runs again with the full layout
+            if k == 4:
+                sh._set_listed([0])              # a statistics layout that misses six of the seven hit loci: exchanged again, fixed
             caps.append(sh.cap_cols)
             sh.enqueue(lambda: (eng.reset_sample(), eng.submit_reads(fb, fq, off)))
             st, chosen, letters = sh.fetch()
+            sbytes.append(sh.stats_bytes_last)
             fx.assert_stats_equal(st, s0)
             assert chosen == want
             assert {a: bytes(v) for a, v in letters.items()} == {a: bytes(v) for a, v in cons.items()}
             assert sh.needs[-1] == need
         assert caps[1] == caps[2] == max(1024, min(sh.total_cols, (need * 3 // 2 + 2047) // 1024 * 1024)) and sh.repeats == 1
+        # statistics: the first step in the fixed layout, then the loci that had hits (all seven here, so about the same size
+        # on this one-species database; 140 of 1,050 loci on cfg3); the misfit of step 4 was seen and repaired
+        assert sbytes[0] == fixed_bytes and sh.listed == tuple(range(idx.n_loci)) and sh.stats_repeats == 1
+        assert sbytes[1] == (2 * idx.n_alleles + idx.n_loci + 8 + 1 + idx.n_loci) * 8
         sh.close()
         # the fixed-layout exchange stays available (MLST_COMPACT_EXCHANGE=0)
         sh = StreamedShard(eng, torch.device("cuda", 0), force_collectives=True, compact=False)

@@ -176,3 +176,24 @@ def test_spawn_ranks_leaves_no_rank_behind_when_the_parent_is_interrupted(tmp_pa
         except OSError:
             alive = False
         assert not alive
+
+
+def test_pair_cuts_are_the_chunks_pair_chunks_yields(tmp_path):
+    """Mate files at N > 1: rank 0 walks the two files once and broadcasts byte offsets (fastq.pair_cuts); what a rank
+    reads by offset must be exactly the chunk pair pair_chunks yields there, also when the second file ends without a
+    newline and when the records of the two files have different lengths (`-U r1,r2` of /root/reference/README.md:20)."""
+    from metamlst_amd import fastq
+    a, b = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    with open(a, "wb") as f:
+        for k in range(700):
+            f.write(b"@x%d 1:N:0\n" % k + b"ACGT" * (5 + k % 7) + b"\n+\n" + b"I" * (4 * (5 + k % 7)) + b"\n")
+    with open(b, "wb") as f:
+        for k in range(700):
+            f.write(b"@x%d 2:N:0\n" % k + b"TTGCA" * (3 + k % 5) + b"\n+\n" + b"@" * (5 * (3 + k % 5)) + b"\n")
+        f.seek(-1, 2)
+        f.truncate()                                     # no newline behind the last quality line
+    for chunk in (2048, 5000, 1 << 20):
+        want = list(fastq.pair_chunks(a, b, chunk))
+        cuts = fastq.pair_cuts(a, b, chunk)
+        assert [fastq.read_pair_cut(a, b, c) for c in cuts] == want
+        assert sum(c[1] for c in cuts) == os.path.getsize(a) and sum(c[3] for c in cuts) == os.path.getsize(b)
