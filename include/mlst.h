@@ -129,14 +129,6 @@ int mlst_submit_fastq_pair(mlst_handle* h, const uint8_t* text1, uint64_t n1, co
 int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out,
                            uint64_t* n_consumed_out);
 
-/* Test hook: the deflate decoder of the call above run on the HOST on one raw deflate stream (returns 0 or a negative
- * code of csrc/inflate_dev.h; *produced = bytes written).  Not a data path. */
-int mlst_selftest_inflate(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced);
-
-/* Test hook of the DEVICE decoder (csrc/inflate_wave.h): whole BGZF blocks in, their inflated text out (host buffers);
- * kernel_ms (optional) receives the duration of the inflate kernel alone (HIP events). */
-int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, uint8_t* out, uint64_t cap, uint64_t* produced, double* kernel_ms);
-
 /* Same, with the three arrays already in DEVICE memory (GPU-side FASTQ decode feeds this). */
 int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
                              const uint64_t* d_off, uint64_t n_reads, uint32_t max_len, int paired);
@@ -293,15 +285,6 @@ typedef struct mlst_item {     /* one (read, locus, strand, diagonal) unit of ex
 } mlst_item;
 int mlst_get_items(mlst_handle* h, mlst_item* out, uint64_t cap, uint64_t* n);
 
-/* Per-kernel device time measured with HIP events on the engine's stream.
- * which: 0=sieve (all its kernels) 1=seed 2=extend 3=banded-SW 4=accumulate 5=pileup 6=pack; 9 = k_route, 10 =
- * k_route_probe and 11 = k_route_verify, the three kernels of the routed sieve (inside 0) (events bracket the launch on the engine's
- * stream, so with several engines on one GPU they include the time a kernel queues behind another stream's kernel);
- * 7 = the sieve's execution window measured inside the kernel (wall clock at the first workgroup's start and the last
- * one's end; one submission per sample), added up when the sample's statistics are fetched;
- * 8 = the longest residency of one workgroup of that launch (LDS sieve; one workgroup per CU, each doing an equal share):
- * what the launch takes once its workgroups run -- when it shares the GPU with another stream's kernel its workgroups
- * start one by one as CUs free up, which stretches the window (7) without the kernel being any slower. */
 /* Run the engine on the caller's HIP stream (hipStream_t; NULL = back on the engine's own stream).  Work queued so
  * far is waited for.  With the engine on the stream a torch.distributed collective is ordered against, a multi-GPU
  * step needs no host synchronisation between its kernels and its collectives (metamlst_amd/dist.py). */
@@ -318,6 +301,15 @@ int mlst_export_stats_device_async(mlst_handle* h, int64_t* d_sum, int64_t* d_mi
 int mlst_import_stats_device_async(mlst_handle* h, const int64_t* d_sum, const int64_t* d_min);
 
 int mlst_set_profiling(mlst_handle* h, int on);   /* 0 = off, 1 = events + sieve window, 2 = sieve window only (keeps the hipGraph replay of the launch sequences, which event profiling turns off) */
+/* Per-kernel device time measured with HIP events on the engine's stream.
+ * which: 0=sieve (all its kernels) 1=seed 2=extend (k_extend + k_extend_pairs) 3=banded-SW 4=accumulate 5=pileup 6=pack 12=k_ext_prep (the item records of k_extend); 9 = k_route, 10 =
+ * k_route_probe and 11 = k_route_verify, the three kernels of the routed sieve (inside 0) (events bracket the launch on the engine's
+ * stream, so with several engines on one GPU they include the time a kernel queues behind another stream's kernel);
+ * 7 = the sieve's execution window measured inside the kernel (wall clock at the first workgroup's start and the last
+ * one's end; one submission per sample), added up when the sample's statistics are fetched;
+ * 8 = the longest residency of one workgroup of that launch (LDS sieve; one workgroup per CU, each doing an equal share):
+ * what the launch takes once its workgroups run -- when it shares the GPU with another stream's kernel its workgroups
+ * start one by one as CUs free up, which stretches the window (7) without the kernel being any slower. */
 int mlst_get_kernel_time(mlst_handle* h, int which, double* total_ms, uint64_t* launches);
 int mlst_reset_kernel_time(mlst_handle* h);
 /* Bytes of the device-resident index structures: [0]=allele arena [1]=sieve [2]=seed table;
@@ -334,17 +326,6 @@ int mlst_get_sieve_info(mlst_handle* h, uint64_t out[4]);
  * blocks (what a read of <= 160 / <= 320 bases covers), [5] / [6] = bytes of LDS a work item of k_extend_160 / _320 gets
  * for the summaries (MLST_EXT_LDS_KB bounds it; loci that need more are aligned pair by pair), [7] = threads per work item. */
 int mlst_get_extend_info(mlst_handle* h, uint64_t out[8]);
-/* Diagnostics of the routed sieve (profiles/route_modes.py; no reference counterpart, not a data path).
- * mlst_get_route_trace: the first call switches the trace on; later calls wait for the stream and return, for the last
- * submission, out[0] = producer workgroups P, [1] = arena address, [2] = packed-row address, [3] = wall-clock kHz,
- * [4] = region capacity, [5] = filter address, [6] = flag address, [7] = arena capacity in entries, then four words per
- * workgroup (P producers, then the 256 consumers): XCC_ID | HW_ID << 32, wall clock at start, at end, 0.
- * *n_words = words needed (0 while nothing has been traced).
- * mlst_debug_route_realloc: free the routing arena (the next submission allocates it again), keeping pad_bytes of
- * device memory allocated in between so that the new arena lands elsewhere; pad_bytes = UINT64_MAX keeps the old arena itself
- * allocated (until mlst_destroy), so that the new one is different memory for certain. */
-int mlst_get_route_trace(mlst_handle* h, uint64_t* out, uint64_t cap_words, uint64_t* n_words);
-int mlst_debug_route_realloc(mlst_handle* h, uint64_t pad_bytes);
 /* Block until all work queued on the engine's stream is done. */
 int mlst_synchronize(mlst_handle* h);
 

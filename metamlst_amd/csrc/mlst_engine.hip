@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "mlst.h"
+#include "mlst_debug.h"
 #include "inflate_dev.h"
 #include "inflate_wave.h"
 #include "mlst_policy.h"

@@ -18,10 +18,10 @@ def lib():
     return engine.load_library()
 
 
-def declared_functions():
-    txt = open(os.path.join(ROOT, "include", "mlst.h")).read()
+def declared_functions(header="mlst.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(mlst_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(mlst_[a-z_0-9]+)\s*\(", txt)))
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
@@ -29,7 +29,14 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), "libmlst_hip.so does not export " + n
-    assert set(names) == set(lib._mlst_symbols), "engine.py binds a different set than mlst.h declares"
+    # diagnostics and test hooks live in their own header (include/mlst_debug.h): exported and bound as well, but no part of
+    # the drop-in boundary
+    debug = declared_functions("mlst_debug.h")
+    assert debug and not set(debug) & set(names)
+    assert all(n.startswith(("mlst_selftest_", "mlst_debug_", "mlst_get_route_trace")) for n in debug), debug
+    for n in debug:
+        assert hasattr(lib, n), "libmlst_hip.so does not export " + n
+    assert set(names) | set(debug) == set(lib._mlst_symbols), "engine.py binds a different set than the headers declare"
 
 
 def test_struct_layouts_match_header():
