@@ -1090,6 +1090,8 @@ __global__ __launch_bounds__(1024) void k_route_probe(const u32* __restrict__ pa
 
 // candidate flags -> candidate list (one atomic per 1024-thread workgroup that holds candidates)
 #define FLAG_U 8      /* flag words per thread and turn of k_flag_compact */
+// between the slices of a sub-batched routed sieve (MLST_RT_SLICE): the producers' tile counter and the parked list start over
+__global__ void k_rt_reset(Counters* ctr) { ctr->rt_next = 0; ctr->rt_parked = 0; }
 __global__ __launch_bounds__(1024) void k_flag_compact(u32* __restrict__ flags, u64 n_reads, u32* __restrict__ cand, Counters* __restrict__ ctr, int paired) {
     __shared__ u32 s_cnt[16]; __shared__ u64 s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -3180,7 +3182,7 @@ struct mlst_handle {
     // CU-routed sieve (K1c): filter slices (reference) and the per-submission arena
     int sieve_kind = 0; u32 sieve_chain = 0; u64 n_keys = 0;
     u32* d_rfilter = nullptr; u32* d_rt_arena = nullptr; u64 cap_rt_arena = 0; u32* d_rt_counts = nullptr; u32* d_rt_emitted = nullptr; u64 cap_rt_emitted = 0;
-    u32 rt_prod = 0, rt_cap = 0, rt_tiles_max = 0, rt_nw = 16, rt_pf = 2;
+    u32 rt_prod = 0, rt_cap = 0, rt_tiles_max = 0, rt_nw = 16, rt_pf = 2; u64 rt_slice = 0;
     u64* d_rt_parked = nullptr; u64 cap_rt_parked = 0;      // entries that passed the LDS filter (k_route_probe -> k_route_verify)
     u64* d_rt_trace = nullptr; bool rt_trace_on = false; const void* rt_last_packed = nullptr;      // mlst_get_route_trace
     std::vector<void*> dbg_pads;                 // mlst_debug_route_realloc: allocations kept to move the arena elsewhere
@@ -3859,6 +3861,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
                 HIPCHK(h, hipFuncSetAttribute(k ? (const void*)k_extend_320 : (const void*)k_extend_160, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ext_lds_bytes(h, k)));
         }
         const char* e3 = getenv("MLST_SIEVE_BLOCKS"); if (e3 && atoi(e3) > 0) h->sieve_g_blocks = atoi(e3);
+        const char* e7 = getenv("MLST_RT_SLICE"); h->rt_slice = (e7 && atoll(e7) > 0) ? (u64)atoll(e7) : 0;
     }
     h->have_ref = h->have_state = true;
     int rc = reset_sample_state(h); if (rc) return rc;
@@ -3905,7 +3908,7 @@ extern "C" int mlst_pack_reads_device(mlst_handle* h, const uint8_t* d_bases, co
 }
 
 // arena / list buffers of the CU-routed sieve for a batch of n_reads (grow-only; must run outside stream capture)
-static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
+static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr, u64 n_reads_flags = 0) {
     u32 nw = 16;                                        // waves per producer workgroup (tile = nw groups of 64 reads)
     { const char* e = getenv("MLST_ROUTE_WAVES"); if (e && atoi(e) == 8) nw = 8; }
     { const char* e = getenv("MLST_PROBE_PF"); h->rt_pf = (e && atoi(e) == 4) ? 4u : 2u; }
@@ -3935,7 +3938,7 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr) {
     // beyond which the consumer examines in place
     const u64 need_p = std::max<u64>(n_reads / 4, 1ull << 16);
     if (h->cap_rt_parked < need_p) { hipStreamSynchronize(h->stream); hipFree(h->d_rt_parked); h->d_rt_parked = nullptr; HIPCHK(h, dmalloc(&h->d_rt_parked, need_p)); h->cap_rt_parked = need_p; }
-    const u64 n_flag_words = (n_reads + 31) >> 5;
+    const u64 n_flag_words = ((n_reads_flags > n_reads ? n_reads_flags : n_reads) + 31) >> 5;
     if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words;
                                             HIPCHK(h, hipMemset(h->d_bin_flags, 0, n_flag_words * 4)); }
     return MLST_OK;
@@ -3958,7 +3961,12 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     if (h->cap_cand < n_reads) { hipStreamSynchronize(h->stream); hipFree(h->d_cand); h->d_cand = nullptr; HIPCHK(h, dmalloc(&h->d_cand, n_reads)); h->cap_cand = n_reads; }
     EngineDev& E = h->E;
     if (wpr > h->max_wpr) h->max_wpr = wpr;
-    if (h->sieve_kind == MLST_SIEVE_ROUTED) { int rc = ensure_route_buffers(h, n_reads, wpr); if (rc) return rc; }
+    // Sub-batched routed sieve (experiment b of VERDICT r3 item 2; MLST_RT_SLICE = reads per slice, 0 = off): route -> probe ->
+    // verify slice by slice, every slice's entries into the same small arena, which then never leaves the 256 MiB
+    // Infinity Cache -- measured: profiles/round4/sieve_experiments.md
+    u64 rt_slice = 0;
+    if (h->sieve_kind == MLST_SIEVE_ROUTED && h->rt_slice) { rt_slice = (h->rt_slice + 1023) & ~1023ull; if (rt_slice >= n_reads) rt_slice = 0; }
+    if (h->sieve_kind == MLST_SIEVE_ROUTED) { int rc = ensure_route_buffers(h, rt_slice ? rt_slice : n_reads, wpr, n_reads); if (rc) return rc; }
     {   // item records of k_ext_prep: one per work item a sample may hold (allocated on first use of an instantiation)
         const int k = wpr <= 10 ? 0 : 1; const u64 words = k ? (u64)XRec<RW / 2>::WORDS : (u64)XRec<5>::WORDS;
         if (h->hap_loci && !h->d_xrec[k]) { hipStreamSynchronize(h->stream); HIPCHK(h, dmalloc(&h->d_xrec[k], h->E.cap_items * words)); h->cap_xrec[k] = h->E.cap_items; }
@@ -3966,7 +3974,7 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
     const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
                                                (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand,
                                                (u64)(uintptr_t)h->d_bin_flags, (u64)(uintptr_t)h->d_rt_arena, (u64)(uintptr_t)h->d_rt_counts,
-                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw, (u64)paired, (u64)(uintptr_t)h->d_rt_trace, (u64)(uintptr_t)h->d_rt_parked, (u64)h->cap_rt_parked, (u64)h->rt_pf});
+                                               (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw, (u64)paired, (u64)(uintptr_t)h->d_rt_trace, (u64)(uintptr_t)h->d_rt_parked, (u64)h->cap_rt_parked, (u64)h->rt_pf, rt_slice});
     if (gs == 1) { h->reads_seen += n_reads; return MLST_OK; }
     { Prof pf(h, 0);
       if (h->sieve_kind == MLST_SIEVE_LDS) {      // LDS first level: one 1024-thread workgroup per CU
@@ -3977,29 +3985,34 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
 #undef SIEVE_CASE
       } else if (h->sieve_kind == MLST_SIEVE_ROUTED) {      // seeds routed to the CU that owns their filter slice (K1c)
         const u64 n_flag_words = (n_reads + 31) >> 5;      // (all zero: cleared at allocation and again by every k_flag_compact)
-        RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags; R.trace = h->d_rt_trace; R.parked = h->d_rt_parked; R.parked_cap = h->cap_rt_parked;
+        for (u64 sl_first = 0; sl_first < n_reads; sl_first += (rt_slice ? rt_slice : n_reads)) {
+        const u64 sl_n = rt_slice ? std::min<u64>(rt_slice, n_reads - sl_first) : n_reads;
+        const u32* sl_packed = d_packed + (sl_first >> 6) * 64 * wpr; const u16* sl_lens = d_lens + sl_first;
+        if (sl_first) hipLaunchKernelGGL(k_rt_reset, dim3(1), dim3(1), 0, h->stream, E.ctr);
+        RouteDev R; R.arena = h->d_rt_arena; R.counts = h->d_rt_counts; R.emitted = h->d_rt_emitted; R.filter = h->d_rfilter; R.flags = h->d_bin_flags + (sl_first >> 5); R.trace = h->d_rt_trace; R.parked = h->d_rt_parked; R.parked_cap = h->cap_rt_parked;
         h->rt_last_packed = d_packed;
         R.cap = h->rt_cap; R.n_prod = h->rt_prod; R.tiles_max = h->rt_tiles_max; R.nw = h->rt_nw;
         { const char* e = getenv("MLST_RT_DEBUG"); R.dbg = e ? (u32)atoi(e) : 0u; if (R.dbg & 2u) R.parked_cap = 0; }      // 2 = examine in place (no k_route_verify work)
         { Prof pa(h, 9);
-#define SIEVE_CASE(W) case W: if (h->rt_nw == 8) hipLaunchKernelGGL((k_route<W, 8>), dim3(h->rt_prod), dim3(512), 0, h->stream, d_packed, d_lens, (u64)n_reads, R, E.ctr); \
-                              else hipLaunchKernelGGL((k_route<W, 16>), dim3(h->rt_prod), dim3(1024), 0, h->stream, d_packed, d_lens, (u64)n_reads, R, E.ctr); break;
+#define SIEVE_CASE(W) case W: if (h->rt_nw == 8) hipLaunchKernelGGL((k_route<W, 8>), dim3(h->rt_prod), dim3(512), 0, h->stream, sl_packed, sl_lens, (u64)sl_n, R, E.ctr); \
+                              else hipLaunchKernelGGL((k_route<W, 16>), dim3(h->rt_prod), dim3(1024), 0, h->stream, sl_packed, sl_lens, (u64)sl_n, R, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
         }
         { Prof pb(h, 10);
-#define SIEVE_CASE(W) case W: if (h->rt_pf == 4) hipLaunchKernelGGL((k_route_probe<W, 4>), dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); \
-                              else hipLaunchKernelGGL((k_route_probe<W, 2>), dim3(RT_OWNERS), dim3(1024), 0, h->stream, d_packed, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); break;
+#define SIEVE_CASE(W) case W: if (h->rt_pf == 4) hipLaunchKernelGGL((k_route_probe<W, 4>), dim3(RT_OWNERS), dim3(1024), 0, h->stream, sl_packed, (u64)sl_n, E.sieve, E.sieve_mask, R, E.ctr); \
+                              else hipLaunchKernelGGL((k_route_probe<W, 2>), dim3(RT_OWNERS), dim3(1024), 0, h->stream, sl_packed, (u64)sl_n, E.sieve, E.sieve_mask, R, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
         }
         { Prof pc(h, 11);
-#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_route_verify<W>, dim3(2048), dim3(256), 0, h->stream, d_packed, (u64)n_reads, E.sieve, E.sieve_mask, R, E.ctr); break;
+#define SIEVE_CASE(W) case W: hipLaunchKernelGGL(k_route_verify<W>, dim3(2048), dim3(256), 0, h->stream, sl_packed, (u64)sl_n, E.sieve, E.sieve_mask, R, E.ctr); break;
         switch (wpr) { SIEVE_CASE(2) SIEVE_CASE(4) SIEVE_CASE(6) SIEVE_CASE(8) SIEVE_CASE(10) SIEVE_CASE(12) SIEVE_CASE(14)
                        SIEVE_CASE(16) SIEVE_CASE(18) SIEVE_CASE(20) default: return fail(h, MLST_E_INVALID, "words_per_read %u unsupported", wpr); }
 #undef SIEVE_CASE
+        }
         }
         hipLaunchKernelGGL(k_flag_compact, dim3(grid_for((n_flag_words + FLAG_U - 1) / FLAG_U, 1024, 512)), dim3(1024), 0, h->stream, h->d_bin_flags, (u64)n_reads, h->d_cand, E.ctr, paired);
       } else {      // hashed first-level bitmap in global memory, 256-thread workgroups (MLST_SIEVE=global; databases without seeds)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--hi", type=int, default=10_000)
     ap.add_argument("--species", type=int, default=6)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--kernels", default="", help="further kernel groups to report (ms per SUBMISSION, all launches of the group): e.g. sieve,sieve_route,sieve_probe,sieve_verify,seed")
     a = ap.parse_args()
     import __graft_entry__ as ge
     ge.build()
@@ -123,6 +124,7 @@ def main():
             same = all(np.array_equal(x, y) for x, y in zip(ref, key))
         e.set_profiling(1)
         times, prep = [], []
+        more = {k_: [] for k_ in a.kernels.split(",") if k_}
         for _ in range(a.launches):
             e.reset_sample()
             e.reset_kernel_time()
@@ -132,6 +134,9 @@ def main():
             times.append(ms / max(k, 1))
             ms, k = e.kernel_time("extend_prep")
             prep.append(ms / max(k, 1))
+            for name in more:
+                ms, k = e.kernel_time(name)
+                more[name].append(ms)
         e.set_profiling(0)
         trace = None
         if hasattr(e.lib, "mlst_debug_ext_trace"):      # profiling build (-DMLST_EXT_TRACE): cycles per phase, summed over waves
@@ -153,7 +158,8 @@ def main():
                 cnt = {"fast_items": int(b2[0]), "fallback_items": int(b2[1]), "span_pairs": int(b2[2]), "turns_with_span_pair": int(b2[3])}
             trace = {"counts": cnt, "items": t[6], "waves": t[7], "cycles_per_item": {k: round(v / max(t[6], 1), 1) for k, v in zip(names, t[:6])}}
         out["variants"][v] = {"extend_ms_median": round(float(np.median(times)), 4), "prep_ms_median": round(float(np.median(prep)), 4), "min": round(min(times), 4), "max": round(max(times), 4),
-                              "same_statistics_as_first": bool(same), "records": int(st.counters[0]), "info": info, "trace": trace}
+                              "same_statistics_as_first": bool(same), "records": int(st.counters[0]), "candidates": int(st.counters[3]), "info": info, "trace": trace,
+                              "ms_per_submission": {k_: round(float(np.median(v)), 4) for k_, v in more.items()}}
         print(v, out["variants"][v], flush=True)
     s = json.dumps(out)
     print(s)
