@@ -73,7 +73,7 @@ def parse_args():
     ap.add_argument("--stagger-ms", type=float, default=None,
                     help="time between the first submissions of a block (default: 0.75 ms when the engines have their own CU shares, else 0)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg2 block and the end-to-end rates")
-    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end (host FASTQ text -> ST) measurement")
+    ap.add_argument("--e2e-reads", type=int, default=24_000_000, help="reads of the end-to-end (host FASTQ text -> ST) measurements (cfg2's legs: its 10 M)")
     ap.add_argument("--calibrate", action="store_true",
                     help="before the timed region copy the Phred rows 3x with torch (a known-size wide coalesced stream) "
                          "so a rocprofv3 --pmc FETCH_SIZE pass of this command can be calibrated")
@@ -591,7 +591,7 @@ def end_to_end(w, args, torch, device):
         return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
                 + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
 
-    with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:      # zlib releases the GIL
+    with ThreadPoolExecutor(max(1, min(64, os.cpu_count() or 1))) as ex:      # zlib releases the GIL
         parts = list(ex.map(bgzf_block, [raw[at:at + 65280] for at in range(0, len(raw), 65280)]))
     comp = np.frombuffer(b"".join(parts) + bgzf_block(b""), np.uint8)
 
@@ -605,6 +605,32 @@ def end_to_end(w, args, torch, device):
     ts = []
     for _ in range(3):
         t0 = time.perf_counter(); calls = run_bgzf(); ts.append(time.perf_counter() - t0)
+    # ---- host-packed transfer (mlst_submit_packed_host): bases + lengths over the link, the candidates' Phred rows behind them
+    from metamlst_amd.engine import pack_fastq_host
+    chunks_txt = [text_host[at * rec:(at + min(chunk_reads, n - at)) * rec] for at in range(0, n, chunk_reads)]
+
+    def run_packed(prepacked=None):
+        eng.reset_sample()
+        for k, ct in enumerate(chunks_txt):
+            pk = prepacked[k] if prepacked is not None else pack_fastq_host(ct, ((L + 31) // 32) * 32)
+            eng.submit_packed_host(*pk)
+        eng.typing_enqueue(penalty=100)
+        return tail()
+
+    t0 = time.perf_counter()
+    pre = [pack_fastq_host(ct, ((L + 31) // 32) * 32) for ct in chunks_txt]
+    t_pack = time.perf_counter() - t0
+    run_packed(pre)
+    tp = []
+    for _ in range(3):
+        t0 = time.perf_counter(); calls_p = run_packed(pre); tp.append(time.perf_counter() - t0)
+    link_bytes = sum(int(p[0].nbytes) + 2 * p[3] for p in pre)
+    out["packed_host_to_st"] = {"Mreads_per_s": round(n / min(tp) / 1e6, 1), "seconds": round(min(tp), 4), "bytes_over_the_link_before_the_sieve": link_bytes,
+                                "species_called": len(calls_p),
+                                "note": "arrays packed beforehand (mlst_pack_fastq_host, %d host threads: %.2f s = %.1f Mreads/s, %.1f GB/s of text); with the packing inside the timed loop: see fastq_text_packed_on_host_to_st"
+                                        % (os.cpu_count() or 1, t_pack, n / t_pack / 1e6, text_host.size / t_pack / 1e9)}
+    t0 = time.perf_counter(); calls_q = run_packed(None); t_q = time.perf_counter() - t0
+    out["fastq_text_packed_on_host_to_st"] = {"Mreads_per_s": round(n / t_q / 1e6, 1), "seconds": round(t_q, 4), "species_called": len(calls_q)}
     out["bgzip_to_st"] = {"reads": nz, "Mreads_per_s": round(nz / min(ts) / 1e6, 1), "compressed_bytes": int(comp.size), "zlib_level": 6, "seconds": round(min(ts), 4),
                           "species_called": len(calls)}
     return out

@@ -129,6 +129,20 @@ int mlst_submit_fastq_pair(mlst_handle* h, const uint8_t* text1, uint64_t n1, co
 int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out,
                            uint64_t* n_consumed_out);
 
+/* Host-packed input: what crosses the link is 2-bit bases + lengths (42 bytes per 150-base read instead of the 316 of its
+ * FASTQ text); the Phred rows stay on the host and only those of the reads that pass the seed sieve (one in ~400 of a
+ * metagenome) follow.  mlst_pack_fastq_host: FASTQ text (whole 4-line records) -> `packed` in the engine's resident layout
+ * (ceil(n / 64) * 64 * words_per_read words: groups of 64 reads, transposed in 8-byte units), `qrows` (n x qual_stride raw
+ * Phred, bit 7 = non-ACGT base), `lens` (bit 15 = the read holds such a base) -- byte for byte what mlst_submit_fastq's
+ * device-side parser makes of the same text; all host threads (threads <= 0: as many as the machine has, at most 128).
+ * No handle: pure host code.  mlst_submit_packed_host: pass 1 from such arrays in HOST memory; one host synchronisation in
+ * the middle (the candidate list comes back before the quality rows go out), so this entry is not replayed as a graph.
+ * Replaces, like mlst_submit_fastq, the user-run `bowtie2 ... -U <fastq>` of /root/reference/README.md:20. */
+int mlst_pack_fastq_host(const uint8_t* text, uint64_t n_bytes, uint32_t words_per_read, uint32_t qual_stride, uint32_t* packed,
+                         uint8_t* qrows, uint16_t* lens, uint64_t cap_reads, uint64_t* n_reads_out, int threads);
+int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, const uint8_t* qrows, const uint16_t* lens, uint64_t n_reads,
+                            uint32_t words_per_read, uint32_t qual_stride, int paired);
+
 /* Same, with the three arrays already in DEVICE memory (GPU-side FASTQ decode feeds this). */
 int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals,
                              const uint64_t* d_off, uint64_t n_reads, uint32_t max_len, int paired);

@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstddef>
+#include <functional>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -188,6 +190,7 @@ struct EngineDev {
     GP<long long> sum_score; GP<u32> n_hits; GP<u64> locus_len; GP<u64> locus_first;
     GP<Counters> ctr;
     GP<u32> ret_bases; GP<u8> ret_quals; GP<u16> ret_len; GP<u64> ret_ridx; GP<u32> ret_nrec;
+    GP<u32> ret_cpos;         // position of the read in the submission's candidate list (quality rows that hold the candidates only: mlst_submit_packed_host)
     GP<u32> ret_mate; GP<u32> ret_item0; GP<u8> ret_nitems;      // Q3: slot of the mate (or ~0), first work item and number of items of the read
     GP<ItemDev> items; GP<u8> item_state; GP<u32> res; GP<u64> dp_list;
     u64 cap_ret, cap_items, cap_res, cap_dp;
@@ -1270,7 +1273,7 @@ __device__ inline bool table_find(const EngineDev& E, u32 lo, u32 hi, u32& val) 
 
 __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, const u32* __restrict__ packed, const u8* __restrict__ qrows,
                                                const u16* __restrict__ lens, u32 wpr, u32 qstride, u64 read_base,
-                                               const u32* __restrict__ cand, int paired) {
+                                               const u32* __restrict__ cand, int paired, int qcompact) {
     const EngineDev& E = *Ep;     // device-resident descriptor: fields are scalar-loaded on demand
     // a lane's eight 12-byte bins = 24 words: left at that stride the 64 lanes share 4 of the 32 LDS banks (16-way conflicts
     // on every access of the vote loops); one word of padding per lane makes the stride odd
@@ -1287,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
             r = cand[c];
             lw = lens[r]; n = lw & 0x7FFFu; bool has_n = (lw & 0x8000u) != 0;
             const u32* row = packed + packed_index(r, wpr, 0);      // word c of the row: row[(c >> 1) * 128 + (c & 1)]
-            const u8* qrow = qrows + (u64)r * qstride;
+            const u8* qrow = qrows + (qcompact ? c : (u64)r) * qstride;      // qcompact: row k belongs to candidate k
             Bin* bins = reinterpret_cast<Bin*>(s_bins[tid]); int nb = 0;
             int nseeds = n >= MLST_SEED_LEN ? (int)((n - MLST_SEED_LEN) / MLST_SEED_STEP) + 1 : 0;
             // The lane's work is a chain of dependent look-ups (key -> value -> postings); a kernel over ~10^4
@@ -1400,7 +1403,7 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
         for (int w = 0; w < (tid >> 6); w++) { ib0 += s_tot[w][1]; ro0 += s_tot[w][2]; }
         // the 400-byte copy of each kept read is left to k_retain (one half-block per read, all reads in parallel);
         // doing it here, read after read inside the wave, was the longest chain of this kernel
-        if (no > 0) { E.ret_len[slot] = (u16)lw; E.ret_ridx[slot] = read_base + r; E.ret_nrec[slot] = 0; }
+        if (no > 0) { E.ret_len[slot] = (u16)lw; E.ret_ridx[slot] = read_base + r; E.ret_nrec[slot] = 0; E.ret_cpos[slot] = (u32)c; }
         // Q3: the mate (the neighbouring candidate when the two are reads 2k, 2k+1) and where this read's items start
         u32 mate_slot = 0xFFFFFFFFu;
         if (paired) {
@@ -1428,7 +1431,7 @@ __global__ __launch_bounds__(256) void k_seed(const EngineDev* __restrict__ Ep, 
 // the kernel waiting for them 30 times over (67 us on cfg3), so it takes eight reads per turn and has their loads in flight
 // together.
 __global__ __launch_bounds__(256) void k_retain(const EngineDev* __restrict__ Ep, const u32* __restrict__ packed, const u8* __restrict__ qrows,
-                                                 u32 wpr, u32 qstride, u64 read_base) {
+                                                 u32 wpr, u32 qstride, u64 read_base, int qcompact) {
     const EngineDev& E = *Ep;
     constexpr int U = 8;
     const u64 begin = E.ctr->ret_done, end = E.ctr->n_ret < E.cap_ret ? E.ctr->n_ret : E.cap_ret;
@@ -1436,11 +1439,11 @@ __global__ __launch_bounds__(256) void k_retain(const EngineDev* __restrict__ Ep
     if (sub >= RW + RQ / 4) return;
     const bool is_base = sub < RW; const u32 w = is_base ? sub : sub - RW;
     for (u64 s0 = begin + ((u64)blockIdx.x * 2 + (threadIdx.x >> 7)) * U; s0 < end; s0 += (u64)gridDim.x * 2 * U) {
-        u64 rr[U]; u32 nn[U];
+        u64 rr[U], qr[U]; u32 nn[U];
         #pragma unroll
         for (int u = 0; u < U; u++) {
-            const u64 sl = s0 + u; rr[u] = 0; nn[u] = 0;
-            if (sl < end) { rr[u] = E.ret_ridx[sl] - read_base; nn[u] = E.ret_len[sl] & 0x7FFFu; }
+            const u64 sl = s0 + u; rr[u] = 0; nn[u] = 0; qr[u] = 0;
+            if (sl < end) { rr[u] = E.ret_ridx[sl] - read_base; nn[u] = E.ret_len[sl] & 0x7FFFu; qr[u] = qcompact ? (u64)E.ret_cpos[sl] : rr[u]; }
         }
         u32 val[U];
         #pragma unroll
@@ -1450,7 +1453,7 @@ __global__ __launch_bounds__(256) void k_retain(const EngineDev* __restrict__ Ep
             if (is_base) { if (w < wpr) val[u] = packed[packed_index(rr[u], wpr, w)]; }
             else {
                 const u32 nq = nn[u] < qstride ? nn[u] : qstride;        // bytes to keep; rows hold zeros beyond the read length
-                if (w * 4 < nq) val[u] = reinterpret_cast<const u32*>(qrows + rr[u] * qstride)[w];
+                if (w * 4 < nq) val[u] = reinterpret_cast<const u32*>(qrows + qr[u] * qstride)[w];
             }
         }
         tie_all<U>(val);
@@ -3172,6 +3175,7 @@ struct mlst_handle {
     HapRec* d_hap_rec = nullptr; u32* d_hap_blk = nullptr; u32* d_hap_id = nullptr; u64 bytes_hap = 0, n_hap_rec = 0; u32 hap_win_max[2] = {0, 0}, hap_loci = 0;
     u32 ext_lds_recs[2] = {0, 0};                // k_extend_160 / _320: haplotype summaries (16 B each) the launch keeps in LDS
     u32 ext_acc_cap = 0;                         // alleles per locus for which k_extend keeps the pending additions of an item in LDS (2 B each)
+    u8* h_qc = nullptr; u8* d_qc = nullptr; u64 cap_hostq = 0, cap_qc = 0;      // mlst_submit_packed_host: the candidates' Phred rows (pinned staging, device)
     u64* d_acc64 = nullptr;                      // k_extend's additions of a submission, count << 40 | sum of scores per allele (k_accumulate hands them on)
     u32* d_xrec[2] = {nullptr, nullptr}; u64 cap_xrec[2] = {0, 0};      // item records of k_ext_prep (one per work item of a submission), per instantiation
     u64 bytes_arena = 0, bytes_sieve = 0, bytes_table = 0; double bitmap_fill = 0.0;
@@ -3364,10 +3368,11 @@ static void free_state(mlst_handle* h) {
     hipFree(h->d_stats); h->d_stats = nullptr; if (h->h_stats) { hipHostFree(h->h_stats); h->h_stats = nullptr; }
     for (int k = 0; k < 2; k++) if (h->h_tstats[k]) { hipHostFree(h->h_tstats[k]); h->h_tstats[k] = nullptr; }
     hipFree(E.ret_bases); hipFree(E.ret_quals); hipFree(E.ret_len); hipFree(E.ret_ridx); hipFree(E.ret_nrec);
-    hipFree(E.ret_mate); hipFree(E.ret_item0); hipFree(E.ret_nitems); E.ret_mate = nullptr; E.ret_item0 = nullptr; E.ret_nitems = nullptr;
+    hipFree(E.ret_mate); hipFree(E.ret_item0); hipFree(E.ret_nitems); hipFree(E.ret_cpos); E.ret_mate = nullptr; E.ret_item0 = nullptr; E.ret_nitems = nullptr; E.ret_cpos = nullptr;
     hipFree(E.items); hipFree(E.item_state); hipFree(E.res); hipFree(E.dp_list);
     for (int k = 0; k < 2; k++) { hipFree(h->d_xrec[k]); h->d_xrec[k] = nullptr; h->cap_xrec[k] = 0; }
     hipFree(h->d_acc64); h->d_acc64 = nullptr;
+    hipFree(h->d_qc); h->d_qc = nullptr; h->cap_qc = 0; if (h->h_qc) { hipHostFree(h->h_qc); h->h_qc = nullptr; h->cap_hostq = 0; }
     hipFree(h->d_locus_chosen); hipFree(h->d_locus_colbase); hipFree(h->d_pl_list); hipFree(h->d_tb);
     E.sum_score = nullptr; E.n_hits = nullptr; E.locus_len = E.locus_first = nullptr; E.ctr = nullptr; E.ret_bases = nullptr; E.ret_quals = nullptr;
     E.ret_len = nullptr; E.ret_ridx = nullptr; E.ret_nrec = nullptr; E.items = nullptr; E.item_state = nullptr; E.res = nullptr; E.dp_list = nullptr;
@@ -3815,7 +3820,7 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
     }
     HIPCHK(h, dmalloc(&E.ret_bases, E.cap_ret * RW)); HIPCHK(h, dmalloc(&E.ret_quals, E.cap_ret * RQ));
     HIPCHK(h, dmalloc(&E.ret_len, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_ridx, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_nrec, E.cap_ret));
-    HIPCHK(h, dmalloc(&E.ret_mate, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_item0, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_nitems, E.cap_ret));
+    HIPCHK(h, dmalloc(&E.ret_mate, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_item0, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_nitems, E.cap_ret)); HIPCHK(h, dmalloc(&E.ret_cpos, E.cap_ret));
     HIPCHK(h, dmalloc(&E.items, E.cap_items)); HIPCHK(h, dmalloc(&E.item_state, E.cap_items)); HIPCHK(h, dmalloc(&E.res, E.cap_res)); HIPCHK(h, dmalloc(&E.dp_list, E.cap_dp));
     HIPCHK(h, dmalloc(&h->d_locus_colbase, (u64)n_loci * 2 + 2));   // [colbase u64 x L][chosen int x L]
     HIPCHK(h, dmalloc(&h->d_pl_list, E.cap_items));
@@ -3944,13 +3949,21 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr, u64 n_read
     return MLST_OK;
 }
 
+// phase 0 = a whole submission (the only one replayed as a hipGraph); 1 = the sieve alone (candidate list), 2 = everything behind
+// the sieve with d_qrows holding the rows of the CANDIDATES only, in candidate order (mlst_submit_packed_host)
+static int submit_impl(mlst_handle* h, const uint32_t* d_packed, const uint8_t* d_qrows, const uint16_t* d_lens,
+                       uint64_t n_reads, uint32_t wpr, uint32_t qstride, int paired, int phase);
 extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packed, const uint8_t* d_qrows, const uint16_t* d_lens,
                                          uint64_t n_reads, uint32_t wpr, uint32_t qstride, int paired) {
+    return submit_impl(h, d_packed, d_qrows, d_lens, n_reads, wpr, qstride, paired, 0);
+}
+static int submit_impl(mlst_handle* h, const uint32_t* d_packed, const uint8_t* d_qrows, const uint16_t* d_lens,
+                       uint64_t n_reads, uint32_t wpr, uint32_t qstride, int paired, int phase) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);
     if (wpr == 0 || wpr > RW || (wpr & 1)) return fail(h, MLST_E_INVALID, "words_per_read must be even and in 2..%d", RW);
     if (qstride < 4 || qstride > RQ || (qstride & 3)) return fail(h, MLST_E_INVALID, "qual_stride must be a multiple of 4 in 4..%d", RQ);
-    if (((uintptr_t)d_qrows & 3) != 0) return fail(h, MLST_E_INVALID, "quality rows must be 4-byte aligned");
+    if (phase != 1 && (!d_qrows || ((uintptr_t)d_qrows & 3) != 0)) return fail(h, MLST_E_INVALID, "quality rows must be 4-byte aligned");
     if (n_reads >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "a batch holds at most 2^32-1 reads");
     if (((uintptr_t)d_packed & 15) != 0) return fail(h, MLST_E_INVALID, "packed rows must be 16-byte aligned");
     if (n_reads == 0) return MLST_OK;
@@ -3971,12 +3984,12 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
         const int k = wpr <= 10 ? 0 : 1; const u64 words = k ? (u64)XRec<RW / 2>::WORDS : (u64)XRec<5>::WORDS;
         if (h->hap_loci && !h->d_xrec[k]) { hipStreamSynchronize(h->stream); HIPCHK(h, dmalloc(&h->d_xrec[k], h->E.cap_items * words)); h->cap_xrec[k] = h->E.cap_items; }
     }
-    const int gs = graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
+    const int gs = phase ? 0 : graph_enter(h, h->g_submit, {(u64)(uintptr_t)d_packed, (u64)(uintptr_t)d_qrows, (u64)(uintptr_t)d_lens, (u64)n_reads, (u64)wpr,
                                                (u64)qstride, (u64)h->reads_seen, (u64)(uintptr_t)h->d_cand,
                                                (u64)(uintptr_t)h->d_bin_flags, (u64)(uintptr_t)h->d_rt_arena, (u64)(uintptr_t)h->d_rt_counts,
                                                (u64)(uintptr_t)h->d_rt_emitted, (u64)h->rt_cap, (u64)h->rt_prod, (u64)h->rt_nw, (u64)paired, (u64)(uintptr_t)h->d_rt_trace, (u64)(uintptr_t)h->d_rt_parked, (u64)h->cap_rt_parked, (u64)h->rt_pf, rt_slice});
     if (gs == 1) { h->reads_seen += n_reads; return MLST_OK; }
-    { Prof pf(h, 0);
+    if (phase != 2) { Prof pf(h, 0);
       if (h->sieve_kind == MLST_SIEVE_LDS) {      // LDS first level: one 1024-thread workgroup per CU
         dim3 grid(grid_for((n_reads + 1023) / 1024, 1, 256)), block(1024);
 #define SIEVE_CASE(W) case W: hipLaunchKernelGGL((k_sieve_q<W, true>), grid, block, 0, h->stream, d_packed, d_lens, (u64)n_reads, E.sieve, E.sieve_mask, E.bitmap, 0u, h->d_cand, E.ctr, paired); break;
@@ -4023,11 +4036,12 @@ extern "C" int mlst_submit_packed_device(mlst_handle* h, const uint32_t* d_packe
 #undef SIEVE_CASE
       }
     }
+    if (phase == 1) { HIPCHK(h, hipGetLastError()); return MLST_OK; }
     { Prof pf(h, 1);
-      hipLaunchKernelGGL(k_seed, dim3(1024), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand, paired);
+      hipLaunchKernelGGL(k_seed, dim3(1024), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, d_lens, wpr, qstride, h->reads_seen, h->d_cand, paired, phase == 2 ? 1 : 0);
       // (one pair of reads per workgroup and sweep, every sweep a chain of dependent scattered loads: a large grid keeps the
       // sweeps few -- 1024 workgroups took 59 sweeps = 112 us for the 121 k retained reads of cfg3)
-      hipLaunchKernelGGL(k_retain, dim3(2048), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen); }
+      hipLaunchKernelGGL(k_retain, dim3(2048), dim3(256), 0, h->stream, h->d_E, d_packed, d_qrows, wpr, qstride, h->reads_seen, phase == 2 ? 1 : 0); }
     if (h->hap_loci) {
       { Prof pf(h, 12);     // item records (the read on the allele's block grid, the locus' fields, the block table)
         if (wpr <= 10) hipLaunchKernelGGL(k_ext_prep<5>, dim3(2048), dim3(256), 0, h->stream, h->d_E, h->kp, h->d_xrec[0], h->cap_xrec[0]);
@@ -4200,6 +4214,114 @@ static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, u
     HIPCHK(h, hipEventRecord(h->ev_packed[h->fq_slot], h->stream));      // the text buffer may be overwritten from here on
     if (n_reads_out) *n_reads_out = n_reads;
     return mlst_submit_packed_device(h, h->d_packed, h->d_qrows, h->d_lens, n_reads, wpr, qstride, paired);
+}
+
+// ---- Host-packed input (VERDICT r3 missing 8).  FASTQ text costs the link 2 L + ~16 bytes per read, and all of
+// it crosses although the sieve reads the bases only and 0.24 % of the reads ever need their Phred values.  Here the HOST
+// packs (mlst_pack_fastq_host: all host threads, the resident 2-bit layout + raw Phred rows + lengths, byte for byte what
+// k_pack_text makes of the same text) and only bases and lengths cross -- 42 bytes per 150-base read; the sieve runs; the
+// candidate list comes back (4 bytes per candidate); the host gathers the candidates' Phred rows and sends those: 152 bytes for
+// one read in 400.  One host synchronisation in the middle of the submission, outside any hipGraph.
+static void par_for(u64 n, int threads, const std::function<void(u64, u64, int)>& fn) {
+    if (threads < 1) threads = 1;
+    if ((u64)threads > n) threads = (int)(n ? n : 1);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(fn, n * t / threads, n * (t + 1) / threads, t);
+    fn(0, n / threads, 0);
+    for (auto& th : pool) th.join();
+}
+extern "C" int mlst_pack_fastq_host(const uint8_t* text, uint64_t n_bytes, uint32_t wpr, uint32_t qstride, uint32_t* packed, uint8_t* qrows,
+                                    uint16_t* lens, uint64_t cap_reads, uint64_t* n_reads_out, int threads) {
+    if (!text || !packed || !qrows || !lens || !n_reads_out) return MLST_E_INVALID;
+    if (wpr == 0 || wpr > RW || (wpr & 1) || qstride < 4 || qstride > RQ || (qstride & 3)) return MLST_E_INVALID;
+    if (threads <= 0) { threads = (int)std::thread::hardware_concurrency(); if (threads < 1) threads = 1; if (threads > 128) threads = 128; }
+    *n_reads_out = 0;
+    // line starts: per-thread lists of the newlines of a slice of the text, then one table
+    std::vector<std::vector<u64>> nl(threads);
+    par_for(n_bytes, threads, [&](u64 lo, u64 hi, int t) {
+        std::vector<u64>& v = nl[t]; v.reserve((hi - lo) / 64 + 16);
+        const u8* p = text + lo; const u8* e = text + hi;
+        while (p < e) { const u8* q = (const u8*)memchr(p, '\n', (size_t)(e - p)); if (!q) break; v.push_back((u64)(q - text) + 1); p = q + 1; }
+    });
+    std::vector<u64> first(threads + 1, 0);
+    for (int t = 0; t < threads; t++) first[t + 1] = first[t] + nl[t].size();
+    u64 n_lines = first[threads] + ((n_bytes && text[n_bytes - 1] != '\n') ? 1 : 0);      // an unterminated last line counts
+    if (n_lines % 4) return MLST_E_INVALID;
+    const u64 n = n_lines / 4;
+    if (n > cap_reads) return MLST_E_CAPACITY;
+    std::vector<u64> ls(n_lines + 1); ls[0] = 0;
+    par_for((u64)threads, threads, [&](u64 lo, u64 hi, int) { for (u64 t = lo; t < hi; t++) if (!nl[t].empty()) memcpy(&ls[1 + first[t]], nl[t].data(), nl[t].size() * 8); });
+    if (n_lines > first[threads]) ls[n_lines] = n_bytes + 1;      // (as if a newline followed the text)
+    std::atomic<int> bad(0);
+    u8 lut[256]; for (int c = 0; c < 256; c++) { const int u = c & 0xDF; lut[c] = (u8)(u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4); }      // bit 2 = not ACGT (packed as A)
+    const u64 n_groups = (n + 63) >> 6;
+    par_for(n_groups, threads, [&](u64 glo, u64 ghi, int) {
+        u32 words[64 * RW];
+        for (u64 grp = glo; grp < ghi; grp++) {
+            memset(words, 0, sizeof(u32) * 64 * wpr);
+            for (u32 i = 0; i < 64; i++) {
+                const u64 r = grp * 64 + i; if (r >= n) break;
+                u64 s0 = ls[4 * r + 1], se = ls[4 * r + 2] - 1, q0 = ls[4 * r + 3], qe = ls[4 * r + 4] - 1;
+                if (se > s0 && text[se - 1] == '\r') se--;
+                if (qe > q0 && text[qe - 1] == '\r') qe--;
+                u64 L = se - s0;
+                if (text[ls[4 * r]] != '@' || L != qe - q0) { bad.store(1); L = L < qe - q0 ? L : qe - q0; }
+                if (L > MLST_MAX_READ_LEN || L > (u64)wpr * 16) { bad.store(2); L = std::min<u64>(MLST_MAX_READ_LEN, (u64)wpr * 16); }
+                u8* qr = qrows + r * qstride;
+                const u8* sp = text + s0; const u8* qp = text + q0;
+                const u64 Lq = L < qstride ? L : qstride;
+                u32 anyn = 0; u32* wrow = words + i * wpr;
+                for (u64 w0 = 0; w0 < L; w0 += 16) {                      // sixteen bases = one packed word
+                    const u64 e = L - w0 < 16 ? L - w0 : 16; u32 word = 0;
+                    for (u64 k = 0; k < e; k++) { const u32 c = lut[sp[w0 + k]]; word |= (c & 3u) << (2 * k); anyn |= c >> 2; }
+                    wrow[w0 >> 4] = word;
+                }
+                for (u64 p2 = 0; p2 < Lq; p2++) { int q = (int)qp[p2] - 33; q = q < 0 ? 0 : (q > 127 ? 127 : q); qr[p2] = (u8)(q | ((lut[sp[p2]] >> 2) << 7)); }
+                if (Lq < qstride) memset(qr + Lq, 0, qstride - Lq);
+                lens[r] = (u16)(L | (anyn << 15));
+            }
+            u32* out = packed + grp * 64 * wpr;      // resident order: word o of the group = unit o >> 7, read (o >> 1) & 63, half o & 1
+            for (u32 o = 0; o < 64 * wpr; o++) out[o] = words[((o >> 1) & 63u) * wpr + ((o >> 7) << 1) + (o & 1u)];
+        }
+    });
+    if (bad.load()) return MLST_E_INVALID;
+    *n_reads_out = n;
+    return MLST_OK;
+}
+extern "C" int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, const uint8_t* qrows, const uint16_t* lens, uint64_t n_reads,
+                                       uint32_t wpr, uint32_t qstride, int paired) {
+    if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    if (!packed || !qrows || !lens) return fail(h, MLST_E_INVALID, "NULL argument");
+    hipSetDevice(h->device);
+    if (wpr == 0 || wpr > RW || (wpr & 1)) return fail(h, MLST_E_INVALID, "words_per_read must be even and in 2..%d", RW);
+    if (qstride < 4 || qstride > RQ || (qstride & 3)) return fail(h, MLST_E_INVALID, "qual_stride must be a multiple of 4 in 4..%d", RQ);
+    if (n_reads == 0) return MLST_OK;
+    // bases + lengths cross the link; the quality buffer on the device only ever holds candidates' rows
+    if (h->cap_packed_words < packed_words(n_reads, wpr) + 4 || h->cap_lens < n_reads + 2) {
+        hipStreamSynchronize(h->stream);
+        hipFree(h->d_packed); hipFree(h->d_lens); h->d_packed = nullptr; h->d_lens = nullptr;
+        HIPCHK(h, dmalloc(&h->d_packed, packed_words(n_reads, wpr) + 4)); HIPCHK(h, dmalloc(&h->d_lens, n_reads + 2));
+        h->cap_packed_words = packed_words(n_reads, wpr) + 4; h->cap_lens = n_reads + 2;
+        if (h->cap_qrow_bytes) { hipFree(h->d_qrows); h->d_qrows = nullptr; h->cap_qrow_bytes = 0; }      // (sized with the other two elsewhere: start over)
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_packed, packed, packed_words(n_reads, wpr) * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_lens, lens, n_reads * 2, hipMemcpyHostToDevice, h->stream));
+    int rc = submit_impl(h, h->d_packed, nullptr, h->d_lens, n_reads, wpr, qstride, paired, 1);
+    if (rc) return rc;
+    // the candidate list
+    u64 n_cand = 0;
+    HIPCHK(h, hipMemcpyAsync(&n_cand, (const u8*)h->E.ctr.p + offsetof(Counters, n_cand), 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_cand > n_reads) n_cand = n_reads;
+    std::vector<u32> cand(n_cand ? n_cand : 1);
+    if (n_cand) HIPCHK(h, hipMemcpy(cand.data(), h->d_cand, n_cand * 4, hipMemcpyDeviceToHost));
+    const u64 qbytes = n_cand * qstride;
+    if (h->cap_hostq < qbytes) { if (h->h_qc) hipHostFree(h->h_qc); h->h_qc = nullptr; HIPCHK(h, hipHostMalloc((void**)&h->h_qc, qbytes + 64, hipHostMallocDefault)); h->cap_hostq = qbytes + 64; }
+    if (h->cap_qc < qbytes) { hipFree(h->d_qc); h->d_qc = nullptr; HIPCHK(h, dmalloc(&h->d_qc, qbytes + 64)); h->cap_qc = qbytes + 64; }
+    int thr = (int)std::thread::hardware_concurrency(); if (thr < 1) thr = 1; if (thr > 32) thr = 32; if (n_cand < 4096) thr = 1;
+    par_for(n_cand, thr, [&](u64 lo, u64 hi, int) { for (u64 k = lo; k < hi; k++) memcpy(h->h_qc + k * qstride, qrows + (u64)cand[k] * qstride, qstride); });
+    if (qbytes) HIPCHK(h, hipMemcpyAsync(h->d_qc, h->h_qc, qbytes, hipMemcpyHostToDevice, h->stream));
+    return submit_impl(h, h->d_packed, h->d_qc, h->d_lens, n_reads, wpr, qstride, paired, 2);
 }
 
 extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int paired, uint64_t* n_reads_out) {

@@ -93,6 +93,8 @@ def load_library(path: str | None = None):
         "mlst_submit_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_int]),
         "mlst_pack_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, u32p, u8p, u16p, C.c_uint32, C.c_uint32]),
         "mlst_submit_packed_device": (C.c_int, [H, u32p, u8p, u16p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
+        "mlst_pack_fastq_host": (C.c_int, [u8p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, u8p, u16p, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
+        "mlst_submit_packed_host": (C.c_int, [H, u32p, u8p, u16p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
         "mlst_get_allele_stats": (C.c_int, [H, i64p, u32p, u64p, u64p, u64p]),
         "mlst_stats_flat_sizes": (C.c_int, [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mlst_export_stats_device": (C.c_int, [H, i64p, i64p]),
@@ -152,6 +154,29 @@ def load_library(path: str | None = None):
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def pack_fastq_host(text, read_len_max: int = 160, threads: int = 0):
+    """FASTQ text (bytes / uint8 array of whole records) -> (packed, qrows, lens, n_reads, words_per_read, qual_stride): the engine's
+    resident read format made on the host by all its threads (mlst_pack_fastq_host), for Engine.submit_packed_host."""
+    lib = load_library()
+    buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+    wpr = ((int(read_len_max) + 31) // 32) * 2
+    qstride = (int(read_len_max) + 7) // 8 * 8
+    cap = int(buf.size // 8 + 64)                       # a record is at least 8 bytes
+    cap = min(cap, int(np.count_nonzero(buf[:1 << 20] == 10) * (buf.size / max(1, min(buf.size, 1 << 20))) / 4 * 1.1) + 4096)
+    packed = np.zeros(((cap + 63) // 64) * 64 * wpr, np.uint32)
+    qrows = np.empty((cap, qstride), np.uint8)
+    lens = np.empty(cap, np.uint16)
+    n = C.c_uint64()
+    rc = lib.mlst_pack_fastq_host(_ptr(buf), buf.size, wpr, qstride, _ptr(packed), _ptr(qrows), _ptr(lens), cap, C.byref(n), int(threads))
+    if rc == -4:                                        # MLST_E_CAPACITY: the estimate from the first megabyte was too low
+        cap = int(buf.size // 8 + 64)
+        packed = np.zeros(((cap + 63) // 64) * 64 * wpr, np.uint32); qrows = np.empty((cap, qstride), np.uint8); lens = np.empty(cap, np.uint16)
+        rc = lib.mlst_pack_fastq_host(_ptr(buf), buf.size, wpr, qstride, _ptr(packed), _ptr(qrows), _ptr(lens), cap, C.byref(n), int(threads))
+    if rc != 0:
+        raise MlstError("mlst_pack_fastq_host failed (%d): not whole 4-line FASTQ records, or a read longer than %d bases" % (rc, read_len_max))
+    return packed, qrows, lens, int(n.value), wpr, qstride
 
 
 class Engine:
@@ -307,6 +332,13 @@ class Engine:
                              qual_stride: int, paired: bool = False):
         self._check(self.lib.mlst_submit_packed_device(self._h, d_packed, d_qual_rows, d_lens, n_reads, words_per_read,
                                                        qual_stride, int(paired)), "mlst_submit_packed_device")
+
+    def submit_packed_host(self, packed: np.ndarray, qrows: np.ndarray, lens: np.ndarray, n_reads: int, words_per_read: int, qual_stride: int,
+                           paired: bool = False):
+        """Pass 1 from host-packed arrays (pack_fastq_host): bases and lengths cross the link, Phred rows of the sieve's
+        candidates only."""
+        self._check(self.lib.mlst_submit_packed_host(self._h, _ptr(packed), _ptr(qrows), _ptr(lens), int(n_reads), int(words_per_read),
+                                                     int(qual_stride), 1 if paired else 0), "mlst_submit_packed_host")
 
     def stats(self) -> SampleStats:
         nA, nL = self.index.n_alleles, self.index.n_loci

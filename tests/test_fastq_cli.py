@@ -242,3 +242,87 @@ def test_cli_alignment_input_sam_and_bam_end_to_end():
     assert main(["merge", d + "/out", "-d", db.path]) == 0
     rep = sorted(open(d + "/out/merged/ecoli_report.txt").read().splitlines()[1:])
     assert [r.split("\t") for r in rep] == [[str(st_row + 1), "100.0", "alnB"], [str(st_row + 1), "100.0", "alnS"]]
+
+
+def _ragged_records(g, rng, n=4000):
+    recs = []
+    for k in range(n):
+        L = int(rng.choice([150, 150, 101, 75, 36, 160, 1]))
+        at = int(rng.integers(0, len(g) - L))
+        r = bytearray(g[at:at + L].tobytes())
+        if k % 7 == 0 and L > 5:
+            r[int(rng.integers(L))] = ord("N")
+        if k % 11 == 0:
+            r = bytearray(bytes(r).lower())
+        q = bytes((rng.integers(2, 42, size=L)).astype(np.uint8) + 33)
+        recs.append((b"r%d x" % k, bytes(r), q))
+    return recs
+
+
+def test_host_packer_makes_the_resident_read_format():
+    """mlst_pack_fastq_host (the threaded host packer behind mlst_submit_packed_host; replaces, like mlst_submit_fastq, the
+    user-run `bowtie2 -U <fastq>` of /root/reference/README.md:20): 2-bit rows in the group-transposed resident layout, raw
+    Phred rows with bit 7 on non-ACGT bases, lengths with bit 15 on reads that hold one -- for LF / CRLF, with and without a
+    final newline, ragged lengths, lower case, any number of threads."""
+    import torch
+    from metamlst_amd.engine import MlstError, pack_fastq_host
+    rng = np.random.default_rng(5)
+    g = np.frombuffer(bytes(rng.choice(list(b"ACGT"), size=30_000).astype(np.uint8)), np.uint8)
+    recs = _ragged_records(g, rng, 1500)
+    code = np.full(256, 4, np.uint8)
+    for k, c in enumerate(b"ACGT"):
+        code[c] = k; code[c + 32] = k
+    for eol, final, threads in ((b"\n", True, 1), (b"\r\n", True, 3), (b"\n", False, 8)):
+        text = eol.join(b"@" + n + eol + r + eol + b"+" + eol + q for n, r, q in recs) + (eol if final else b"")
+        packed, qrows, lens, n, wpr, qstride = pack_fastq_host(text, 160, threads)
+        assert n == len(recs) and wpr == 10 and qstride == 160
+        rows = synth.tiled_to_rows(torch.from_numpy(packed.view(np.int32)), n, wpr).numpy().view(np.uint32)
+        for k, (_, r, q) in enumerate(recs):
+            c = code[np.frombuffer(r, np.uint8)]
+            L = len(r)
+            assert int(lens[k]) == (L | (0x8000 if (c == 4).any() else 0)), k
+            want = np.zeros(wpr, np.uint32)
+            for i in range(L):
+                want[i >> 4] |= np.uint32((int(c[i]) & 3 if c[i] < 4 else 0) << (2 * (i & 15)))
+            assert np.array_equal(rows[k], want), k
+            wq = (np.frombuffer(q, np.uint8) - 33) | ((c == 4).astype(np.uint8) << 7)
+            assert np.array_equal(qrows[k, :L], wq) and not qrows[k, L:].any(), k
+    with pytest.raises(MlstError):
+        pack_fastq_host(b"@a\nACGT\n+\n", 160)                      # not whole records
+    with pytest.raises(MlstError):
+        pack_fastq_host(b"@a\nACGT\n+\nIII\n", 160)                 # sequence and quality of different lengths
+    with pytest.raises(MlstError):
+        pack_fastq_host(b"@a\n" + b"A" * 200 + b"\n+\n" + b"I" * 200 + b"\n", 160)
+
+
+@pytest.mark.gpu
+def test_packed_host_submit_equals_the_text_path():
+    """mlst_submit_packed_host (bases + lengths over the link, the sieve's candidates' Phred rows behind them) = mlst_submit_fastq
+    on the same text: statistics, work items, allele choice and consensus; single reads with N and ragged lengths, pairs, two
+    submissions in a row."""
+    from metamlst_amd.engine import Engine, pack_fastq_host
+    import fixtures as fx2
+    db, idx = fx2.ecoli_small(40)
+    rng = np.random.default_rng(8)
+    g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][2], size=60_000)
+    recs = _ragged_records(g, rng, 6000)
+    text = b"\n".join(b"@" + n + b"\n" + r + b"\n+\n" + q for n, r, q in recs) + b"\n"
+    eng = Engine(0)
+    eng.load_reference(idx)
+    for paired in (False, True):
+        eng.reset_sample()
+        assert eng.submit_fastq(text, paired=paired) == len(recs)
+        assert eng.submit_fastq(text, paired=paired) == len(recs)            # a second submission: read indices go on
+        eng.typing_enqueue()
+        want, want_ch, want_let = eng.typing_fetch()
+        want_items = fx2.sorted_items(eng.items(1 << 16))
+        eng.reset_sample()
+        packed, qrows, lens, n, wpr, qstride = pack_fastq_host(text, 160)
+        eng.submit_packed_host(packed, qrows, lens, n, wpr, qstride, paired=paired)
+        eng.submit_packed_host(packed, qrows, lens, n, wpr, qstride, paired=paired)
+        eng.typing_enqueue()
+        got, got_ch, got_let = eng.typing_fetch()
+        fx2.assert_stats_equal(got, want)
+        assert np.array_equal(fx2.sorted_items(eng.items(1 << 16)), want_items)
+        assert got_ch == want_ch and {a: bytes(v) for a, v in got_let.items()} == {a: bytes(v) for a, v in want_let.items()}
+    eng.close()
