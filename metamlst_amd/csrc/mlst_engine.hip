@@ -1854,84 +1854,119 @@ template <int NB> struct XRec {
 
 template <int NB>
 __global__ __launch_bounds__(256) void k_ext_prep(const EngineDev* __restrict__ Ep, KParams P, u32* __restrict__ xrec, u64 cap_xrec) {
+    // A wave takes FOUR items per turn: an item's record hangs on a chain of three round trips (item -> locus, length ->
+    // rows), and with one item per wave and turn that chain, 15 times per wave, was the kernel (0.09 ms for the 121 k items of
+    // cfg3).  Lanes 0-3 walk the first two links for the four items side by side; the rows of all four are requested in
+    // one batch; 16 lanes per item then shift its planes onto the allele's block grid.  LDS is private to the wave: no barriers.
     typedef XRec<NB> X;
+    constexpr int B = 4, KT = RQ / 64;
     const EngineDev& E = *Ep;
-    __shared__ u32 s_rl[4][RW / 2 + 2]; __shared__ u32 s_rh[4][RW / 2 + 2]; __shared__ u32 s_rn[4][RW / 2 + 2]; __shared__ u32 s_odd[4][RW / 2 + 2];
-    __shared__ u8 s_pentab[128]; __shared__ u32 s_w[4][X::WORDS];
+    __shared__ u32 s_pl[4][B][4][RW / 2 + 2];      // per wave and item: low plane, high plane, N mask, non-default-penalty mask
+    __shared__ u8 s_pentab[128]; __shared__ __attribute__((aligned(16))) u32 s_w[4][B][X::WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < 128; i += 256) s_pentab[i] = E.pen_tab[i];
     __syncthreads();
-    const u64 begin = E.ctr->items_done, end = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
-    for (u64 i0 = begin + (u64)blockIdx.x * 4; i0 < end; i0 += (u64)gridDim.x * 4) {      // block-uniform trip count (the barrier below)
-        const u64 ii = i0 + wv;                                   // wave = item
-        const bool live = ii < end && ii - begin < cap_xrec;
-        if (live) {
-            const ItemDev it = E.items[ii];
-            const LocusDev L = E.loci[it.locus];
-            const u32 lw = E.ret_len[it.ret]; const int n = (int)(lw & 0x7FFFu);
-            const u8 state = E.item_state[ii];
-            if (!L.hap_ok) { if (lane < 32) s_w[wv][lane] = 0; }      // the other kernel's item: a record without XF_HAPOK
-            else {
-            // the read's planes (as stage_read_planes makes them), with every load of the item requested in one batch:
-            // lane = read position modulo 64, five turns; the block table rides along
-            const int q0 = it.diag >> 5; const u32 rs = 32u - ((u32)it.diag & 31u);      // 1..32
-            u32* w = s_w[wv];
-            auto rb = E.ret_bases.g() + (u64)it.ret * RW; auto rq = E.ret_quals.g() + (u64)it.ret * RQ;
-            constexpr int KT = RQ / 64;
-            u32 qv[KT], bw[KT], qmid = rq[n >> 1], hbv = 0;
+    const u64 begin = E.ctr->items_done, end0 = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items;
+    const u64 end = end0 - begin > cap_xrec ? begin + cap_xrec : end0;
+    for (u64 i0 = begin + ((u64)blockIdx.x * 4 + wv) * B; i0 < end; i0 += (u64)gridDim.x * 4 * B) {      // wave-uniform
+        const int n_live = (int)(end - i0 < (u64)B ? end - i0 : (u64)B);
+        // ---- links one and two of the chain, lane j for item j
+        const bool mine = lane < n_live;
+        ItemDev it; it.res_off = 0; it.ret = 0; it.locus = 0; it.diag = 0; it.strand = 0; it.votes = 0;
+        if (mine) it = E.items[i0 + lane];
+        TIE1(it.ret); TIE1(it.locus);
+        u32 lw = 0, st = 0; LocusDev L; memset(&L, 0, sizeof L);
+        if (mine) { L = E.loci[it.locus]; lw = E.ret_len[it.ret]; st = E.item_state[i0 + lane]; }
+        TIE1(lw); TIE1(L.hap_ok); TIE1(L.hblk_off); TIE1(L.pblocks);
+        const int n_l = (int)(lw & 0x7FFFu);
+        const int floor_l = mine ? E.floor_tab[n_l] : 0;
+        // ---- the rows of the four items, one batch: lane = read position modulo 64, KT turns per item
+        u32 qv[B][KT], bw[B][KT], qmid[B];
+        #pragma unroll
+        for (int k = 0; k < B; k++) {
+            const u32 ret_k = __shfl(it.ret, k); const int n_k = __shfl(n_l, k); const int strand_k = __shfl((int)it.strand, k);
+            auto rb = E.ret_bases.g() + (u64)ret_k * RW; auto rq = E.ret_quals.g() + (u64)ret_k * RQ;
+            qmid[k] = k < n_live ? (u32)rq[n_k >> 1] : 0u;
             #pragma unroll
-            for (int k = 0; k < KT; k++) {
-                const int i = lane + 64 * k, sp = i < n ? (it.strand ? n - 1 - i : i) : 0;
-                qv[k] = rq[sp]; bw[k] = rb[sp >> 4];
+            for (int t = 0; t < KT; t++) {
+                const int i = lane + 64 * t, sp = (k < n_live && i < n_k) ? (strand_k ? n_k - 1 - i : i) : 0;
+                qv[k][t] = rq[sp]; bw[k][t] = rb[sp >> 4];
             }
-            if (lane <= X::NBA) { int q = q0 + lane; q = q < 0 ? 0 : (q > (int)L.pblocks ? (int)L.pblocks : q); hbv = E.hap_blk[L.hblk_off + (u32)q]; }
-            tie_all<KT>(qv); tie_all<KT>(bw); TIE1(qmid); TIE1(hbv);
-            const u8 pen_def_b = (qmid >> 7) ? (u8)P.n_penalty : s_pentab[qmid & 0x7Fu];
-            const int pen_def = (int)pen_def_b;
+        }
+        // the block table: lane = t + 16 k, block t of item k
+        const int kk = lane >> 4, tt = lane & 15;
+        const int diag_g = __shfl(it.diag, kk); const u32 pbl_g = __shfl(L.pblocks, kk), hoff_g = __shfl(L.hblk_off, kk), hok_g = __shfl(L.hap_ok, kk);
+        u32 hbv = 0;
+        if (kk < n_live && tt <= X::NBA && hok_g) { int q = (diag_g >> 5) + tt; q = q < 0 ? 0 : (q > (int)pbl_g ? (int)pbl_g : q); hbv = E.hap_blk[hoff_g + (u32)q]; }
+        #pragma unroll
+        for (int k = 0; k < B; k++) { tie_all<KT>(qv[k]); tie_all<KT>(bw[k]); }
+        tie_all<B>(qmid); TIE1(hbv);
+        // ---- planes of each item (ballots), to the wave's LDS
+        int pen_def_k[B];
+        #pragma unroll
+        for (int k = 0; k < B; k++) {
+            const int n_k = __shfl(n_l, k); const int strand_k = __shfl((int)it.strand, k);
+            const u8 pd = (qmid[k] >> 7) ? (u8)P.n_penalty : s_pentab[qmid[k] & 0x7Fu];
+            pen_def_k[k] = (int)pd;
             #pragma unroll
-            for (int k = 0; k < KT; k++) {
-                const int i = lane + 64 * k; u32 b = 0, isn = 0, odd = 0;
-                if (i < n) {
-                    const int sp = it.strand ? n - 1 - i : i;
-                    b = (bw[k] >> (2 * (sp & 15))) & 3u; if (it.strand) b ^= 3u;
-                    isn = qv[k] >> 7;
-                    const u8 pen = isn ? (u8)P.n_penalty : s_pentab[qv[k] & 0x7Fu];
-                    odd = pen != pen_def_b;
+            for (int t = 0; t < KT; t++) {
+                const int i = lane + 64 * t; u32 b = 0, isn = 0, odd = 0;
+                if (k < n_live && i < n_k) {
+                    const int sp = strand_k ? n_k - 1 - i : i;
+                    b = (bw[k][t] >> (2 * (sp & 15))) & 3u; if (strand_k) b ^= 3u;
+                    isn = qv[k][t] >> 7;
+                    const u8 pen = isn ? (u8)P.n_penalty : s_pentab[qv[k][t] & 0x7Fu];
+                    odd = pen != pd;
                 }
                 const u64 bl = __ballot(b & 1u), bh = __ballot(b >> 1), bn = __ballot(isn != 0), bo = __ballot(odd != 0);
                 if (lane == 0) {
-                    s_rl[wv][2 * k] = (u32)bl; s_rl[wv][2 * k + 1] = (u32)(bl >> 32); s_rh[wv][2 * k] = (u32)bh; s_rh[wv][2 * k + 1] = (u32)(bh >> 32);
-                    s_rn[wv][2 * k] = (u32)bn; s_rn[wv][2 * k + 1] = (u32)(bn >> 32); s_odd[wv][2 * k] = (u32)bo; s_odd[wv][2 * k + 1] = (u32)(bo >> 32);
+                    s_pl[wv][k][0][2 * t] = (u32)bl; s_pl[wv][k][0][2 * t + 1] = (u32)(bl >> 32); s_pl[wv][k][1][2 * t] = (u32)bh; s_pl[wv][k][1][2 * t + 1] = (u32)(bh >> 32);
+                    s_pl[wv][k][2][2 * t] = (u32)bn; s_pl[wv][k][2][2 * t + 1] = (u32)(bn >> 32); s_pl[wv][k][3][2 * t] = (u32)bo; s_pl[wv][k][3][2 * t + 1] = (u32)(bo >> 32);
                 }
             }
-            if (lane <= X::NBA) w[X::HB + lane] = hbv;
-            u32 any = 0;
-            if (lane <= NB) {
-                auto sh = [&](const u32* A) { const u64 v2 = ((u64)(lane < NB ? A[lane] : 0u) << 32) | (u64)(lane > 0 ? A[lane - 1] : 0u); return (u32)(v2 >> rs); };
-                auto vw = [&](int k) { const int c = n - 32 * k; return (k < 0 || k >= NB) ? 0u : (c >= 32 ? 0xFFFFFFFFu : (c > 0 ? ((1u << c) - 1u) : 0u)); };
-                const u32 rn_t = sh(s_rn[wv]), od_t = sh(s_odd[wv]);
-                w[X::PL + 4 * lane] = sh(s_rl[wv]); w[X::PL + 4 * lane + 1] = sh(s_rh[wv]); w[X::PL + 4 * lane + 2] = rn_t; w[X::PL + 4 * lane + 3] = od_t;
-                w[X::VR + lane] = (u32)((((u64)vw(lane) << 32) | (u64)vw(lane - 1)) >> rs);
+        }
+        // ---- the records: 16 lanes per item (lane t of them = block t), lane 16 k its header
+        u32 any = 0;
+        const int n_g = __shfl(n_l, kk);
+        if (kk < n_live) {
+            u32* w = s_w[wv][kk];
+            const u32 rs = 32u - ((u32)diag_g & 31u);      // 1..32
+            if (tt <= X::NBA) w[X::HB + tt] = hbv;
+            if (tt <= NB) {
+                auto sh = [&](const u32* A) { const u64 v2 = ((u64)(tt < NB ? A[tt] : 0u) << 32) | (u64)(tt > 0 ? A[tt - 1] : 0u); return (u32)(v2 >> rs); };
+                auto vw = [&](int j) { const int c = n_g - 32 * j; return (j < 0 || j >= NB) ? 0u : (c >= 32 ? 0xFFFFFFFFu : (c > 0 ? ((1u << c) - 1u) : 0u)); };
+                const u32 rn_t = sh(s_pl[wv][kk][2]), od_t = sh(s_pl[wv][kk][3]);
+                w[X::PL + 4 * tt] = sh(s_pl[wv][kk][0]); w[X::PL + 4 * tt + 1] = sh(s_pl[wv][kk][1]); w[X::PL + 4 * tt + 2] = rn_t; w[X::PL + 4 * tt + 3] = od_t;
+                w[X::VR + tt] = (u32)((((u64)vw(tt) << 32) | (u64)vw(tt - 1)) >> rs);
                 any = rn_t | od_t;
             }
-            const bool special = __any(any != 0) || L.has_n;
-            if (lane == 0) {
+        }
+        // (does any of the item's 16 lanes see a special column?  an OR over the item's quarter of the wave)
+        #pragma unroll
+        for (int o = 8; o > 0; o >>= 1) any |= __shfl_xor(any, o);
+        const u32 special_l = __shfl(any, lane * 16);      // lane j < 4: the OR of item j's lanes (lane 16 j holds it)
+        if (mine) {
+            u32* w = s_w[wv][lane];
+            if (!L.hap_ok) { for (int j = 0; j < 32; j++) w[j] = 0; }      // the other kernel's item: a record without XF_HAPOK
+            else {
                 const bool res_ok = it.res_off + L.n_pad <= E.cap_res;
-                w[0] = ((state & IS_SINGLE) ? XF_SINGLE : 0u) | (res_ok ? XF_RESOK : 0u) | (L.hap_ok ? XF_HAPOK : 0u) | ((lw & 0x8000u) ? XF_READN : 0u)
-                     | (special ? XF_SPECIAL : 0u) | (it.strand ? XF_STRAND : 0u);
-                w[1] = (u32)n | ((u32)pen_def << 16); w[2] = (u32)it.diag; w[3] = it.ret; w[4] = it.locus; w[5] = (u32)it.res_off; w[6] = (u32)(it.res_off >> 32);
+                w[0] = ((st & IS_SINGLE) ? XF_SINGLE : 0u) | (res_ok ? XF_RESOK : 0u) | XF_HAPOK | ((lw & 0x8000u) ? XF_READN : 0u)
+                     | ((special_l || L.has_n) ? XF_SPECIAL : 0u) | (it.strand ? XF_STRAND : 0u);
+                int pd = pen_def_k[0];
+                #pragma unroll
+                for (int k = 1; k < B; k++) pd = lane == k ? pen_def_k[k] : pd;
+                w[1] = (u32)n_l | ((u32)pd << 16); w[2] = (u32)it.diag; w[3] = it.ret; w[4] = it.locus; w[5] = (u32)it.res_off; w[6] = (u32)(it.res_off >> 32);
                 w[7] = L.a_begin; w[8] = L.n_alleles; w[9] = L.n_pad; w[10] = L.hap_off; w[11] = (u32)L.hid_off; w[12] = (u32)(L.hid_off >> 32);
-                w[13] = (u32)E.floor_tab[n]; w[14] = L.pblocks; w[15] = L.hap_win[NB > 5 ? 1 : 0];
-                w[31] = (u32)ii;                                  // (max_items < 2^32)
+                w[13] = (u32)floor_l; w[14] = L.pblocks; w[15] = L.hap_win[NB > 5 ? 1 : 0];
             }
-            }
+            w[31] = (u32)(i0 + lane);                        // (max_items < 2^32)
         }
-        __syncthreads();
-        if (live) {
-            u32* dst = xrec + (ii - begin) * X::WORDS;
-            for (int j = lane; j < X::WORDS; j += 64) dst[j] = s_w[wv][j];
+        #pragma unroll
+        for (int k = 0; k < B; k++) {
+            if (k >= n_live) break;
+            u32* dst = xrec + (i0 + k - begin) * X::WORDS;
+            for (int j = lane; j < X::WORDS; j += 64) dst[j] = s_w[wv][k][j];
         }
-        __syncthreads();
     }
 }
 
