@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""pmc_counters.json (profiles/pmc_extract.py) + the bench line of the same workload -> profiles/round3/pmc_<workload>.json,
+"""pmc_counters.json (profiles/pmc_extract.py) + the bench line of the same workload -> profiles/round4/pmc_<workload>.json,
 the per-launch figures bench.py's `roofline.traffic` / `roofline_extend` quote.
 
-    python3 profiles/pmc_to_bench.py gpurun_out/<tag>/pmc_counters.json gpurun_out/<tag>/bench.json cfg3 > profiles/round3/pmc_cfg3.json
+    python3 profiles/pmc_to_bench.py gpurun_out/<tag>/pmc_counters.json gpurun_out/<tag>/bench.json cfg3 > profiles/round4/pmc_cfg3.json
 
 HBM bytes per launch = 2 x 1024 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 bytes: MI355X_MICROARCH.md) +
 1024 x WRITE_SIZE.  Counter passes run `bench.py --pipeline 1 --no-secondary`: every launch of these kernels in them is a
