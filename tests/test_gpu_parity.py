@@ -42,6 +42,42 @@ def check_pileup(eng, orc, idx, s):
     return chosen, pc
 
 
+def test_extension_kernel_choice_and_addition_forms_agree_with_the_oracle():
+    """k_extend scores block haplotypes (loci up to MLST_EXT_HAP_MAX alleles), k_extend_pairs aligns pair by pair; the fast pass adds
+    count and sum in one 64-bit addition while a submission holds fewer than 2^24 items and in two otherwise.  Every combination
+    = the oracle (align_pair of oracle/mlst_oracle.c is the specification), on a database with indel alleles (banded SW, the
+    aligned-span test) and on an isolate."""
+    import os
+    for alleles, indel in ((80, 0), (60, 7)):
+        db, idx = fx.ecoli_small(alleles, indel_every=indel)
+        fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 3, n_reads=12_000)
+        orc = oracle_lib.Oracle(idx)
+        orc.submit_reads(fb, fq, off)
+        so, items_o = orc.stats(want_items=1 << 18)
+        for env, max_items in (({}, 0), ({"MLST_EXT_HAP_MAX": "0"}, 0), ({"MLST_EXT_LDS_KB": "0"}, 0), ({"MLST_EXT_HAP_MAX": "40"}, 0), ({}, 1 << 24)):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                p = default_params()
+                p.max_items = max_items
+                eng = Engine(0, p)
+                eng.load_reference(idx)
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            info = eng.extend_info()
+            assert info["loci"] == (idx.n_loci if not env else 0), (env, info)      # (40 < every locus' allele count)
+            for _ in range(2):                                                       # the second submission replays the hipGraph
+                eng.reset_sample()
+                eng.submit_reads(fb, fq, off)
+                fx.assert_stats_equal(eng.stats(), so)
+            assert np.array_equal(fx.sorted_items(eng.items(1 << 18)), fx.sorted_items(items_o))
+            eng.close()
+
+
 def test_ecoli_isolate_pass1_and_pileup():
     db, idx = fx.ecoli_small(80)
     fb, fq, off, _, _ = fx.isolate_reads(db, "ecoli", 5)
