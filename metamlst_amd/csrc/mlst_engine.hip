@@ -3442,6 +3442,7 @@ static inline int base_code(u8 c) {
 static int reset_sample_state(mlst_handle* h) {
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, h->stats_zero_bytes, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_stats + h->off_first, 0xFF, h->stats_bytes - h->off_first, h->stream));
+    if (h->d_acc64 && h->n_alleles) HIPCHK(h, hipMemsetAsync(h->d_acc64, 0, (u64)h->n_alleles * 8, h->stream));      // (zero after every complete submission already: k_accumulate; this is for one that was cut short)
     h->reads_seen = 0; h->fq_carry_len = 0; h->max_wpr = 0;
     return MLST_OK;
 }

@@ -54,7 +54,8 @@ def test_extension_kernel_choice_and_addition_forms_agree_with_the_oracle():
         orc = oracle_lib.Oracle(idx)
         orc.submit_reads(fb, fq, off)
         so, items_o = orc.stats(want_items=1 << 18)
-        for env, max_items in (({}, 0), ({"MLST_EXT_HAP_MAX": "0"}, 0), ({"MLST_EXT_LDS_KB": "0"}, 0), ({"MLST_EXT_HAP_MAX": "40"}, 0), ({}, 1 << 24)):
+        for env, max_items in (({}, 0), ({"MLST_EXT_HAP_MAX": "0"}, 0), ({"MLST_EXT_LDS_KB": "0"}, 0), ({"MLST_EXT_HAP_MAX": "40"}, 0), ({}, 1 << 24),
+                               ({"MLST_EXT_THREADS": "256"}, 0)):      # (the last: four waves per work item in the haplotype kernel)
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
             try:
@@ -69,7 +70,7 @@ def test_extension_kernel_choice_and_addition_forms_agree_with_the_oracle():
                     else:
                         os.environ[k] = v
             info = eng.extend_info()
-            assert info["loci"] == (idx.n_loci if not env else 0), (env, info)      # (40 < every locus' allele count)
+            assert info["loci"] == (idx.n_loci if (not env or "MLST_EXT_THREADS" in env) else 0), (env, info)      # (40 < every locus' allele count)
             for _ in range(2):                                                       # the second submission replays the hipGraph
                 eng.reset_sample()
                 eng.submit_reads(fb, fq, off)
