@@ -198,6 +198,13 @@ int mlst_import_stats_device(mlst_handle* h, const int64_t* d_sum, const int64_t
 int mlst_pileup(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n, uint32_t* counts);
 int mlst_pileup_device(mlst_handle* h, const uint32_t* chosen_allele_idx, uint32_t n,
                        uint32_t* d_counts /* device, n_cols*4, zeroed by the call */, uint64_t* n_cols);
+/* pysam's pileup(max_depth = 8000) (metaMLST_functions.py:255-259; policy MLST_DEPTH_CAP of mlst_policy.h) as a switch.
+ * cap = 0 (default): every record counts.  cap = n: a column of a chosen allele sees only the first n records that span it
+ * (aligned columns first to last, deleted columns inside included), records ordered by (read index, strand); every record
+ * of the aligner counts towards the depth, the AS / XM / Phred / ACGT filters apply to what a column saw.  Applies to every
+ * pile-up that follows (mlst_pileup*, mlst_consensus, mlst_typing_*); ~40 extra passes over the work items, so a
+ * literal-parity mode.  Single-engine samples only: a rank of a sharded sample knows its own reads' records only. */
+int mlst_set_depth_cap(mlst_handle* h, uint32_t cap);
 
 /* Pass 2 with the majority rule applied on the GPU: the string cmseq's
  * reference_free_consensus(mincov, noneCharacter, ...) returns for each chosen contig

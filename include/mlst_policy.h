@@ -49,7 +49,9 @@
 
 /* ---- cmseq / pysam pileup policy [NOT IN TREE] ---- */
 #define MLST_TIE_ORDER "ACGT"       /* majority-base ties resolve alphabetically (host side) */
-#define MLST_DEPTH_CAP          0   /* pysam max_depth=8000 is order dependent; 0 = not applied (documented deviation) */
+#define MLST_DEPTH_CAP          0   /* default of mlst_set_depth_cap: pysam's max_depth=8000 depends on the order of the BAM
+                                       file; 0 = not applied.  As a switch it is "the first n records that span a column,
+                                       in (read index, strand) order" -- oracle: orc_pileup_capped */
 
 /* ---- hard limits of the packed formats ---- */
 #define MLST_MAX_READ_LEN     320   /* 20 packed words; xm field of the packed score is 8 bits */

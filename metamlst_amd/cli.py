@@ -63,6 +63,9 @@ def _type_parser(sub):
     p.add_argument("--max-retained", default=0, type=int, metavar="READS", help="capacity of the on-locus read store (default 4 M)")
     p.add_argument("--max-items", default=0, type=int, metavar="ITEMS", help="capacity of the (read, locus, strand) work-item list (default 8 M)")
     p.add_argument("--max-pair-results", default=0, type=int, metavar="PAIRS", help="capacity of the (item, allele) result arena (default 256 M)")
+    p.add_argument("--depth-cap", default=0, type=int, metavar="N",
+                   help="pysam's pileup(max_depth) as a switch (metaMLST_functions.py:255-259 runs with 8000): a consensus column sees the "
+                        "first N alignment records that span it, in read order; 0 (default) = all of them")
     return p
 
 
@@ -158,14 +161,21 @@ def run_type(a, argv=None) -> int:
     prm = default_params()
     prm.minscore, prm.max_xm, prm.min_read_len = a.minscore, a.max_xM, a.min_read_len
     prm.max_retained_reads, prm.max_items, prm.max_pair_results = a.max_retained, a.max_items, a.max_pair_results
+    if a.depth_cap and world > 1 and not many:
+        print("--depth-cap orders the records of the whole sample by read index: one sample on several GPUs cannot apply it (use --gpus 1)")
+        return 1
     eng = Engine(a.device, prm)
     eng.load_reference(idx)
+    if a.depth_cap:
+        eng.set_depth_cap(a.depth_cap)
     engines = [eng]
     if many:      # the pipelined loop (metamlst_amd/pipeline.py): a few engines take turns on this rank's samples
         n_mine = (len(samples) + world - 1) // world
         for _ in range(max(0, min(int(os.environ.get("MLST_PIPELINE_DEPTH", "4")), n_mine) - 1)):
             e2 = Engine(a.device, prm)
             e2.load_reference(idx)      # (the host index is cached inside the library: an upload, not a build)
+            if a.depth_cap:
+                e2.set_depth_cap(a.depth_cap)
             engines.append(e2)
     targs = TypingArgs(penalty=a.penalty, minscore=a.minscore, max_xM=a.max_xM, min_read_len=a.min_read_len,
                        min_accuracy=a.min_accuracy, nloci=a.nloci, a=a.a, quiet=a.quiet, filter=a.filter, log=a.log)

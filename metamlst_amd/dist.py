@@ -152,6 +152,9 @@ class StreamedShard:
         self.n_sum, self.n_min = n_sum, max(1, n_min)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self.world > 1 and getattr(engine, "depth_cap", 0):
+            raise ValueError("the depth-capped pile-up (mlst_set_depth_cap) orders records by read index over the whole sample; "
+                             "a rank of a sharded sample holds its own reads' records only: type capped samples on one engine")
         # ONE all-reduce(SUM) per statistics exchange: [additive part | world x n_min slots].  Every rank writes its
         # first-read vector into its own slot (the other slots are zero), so after the sum every rank holds every rank's
         # vector and takes the minimum locally -- a second collective (MIN) costs more host time than two tiny kernels.

@@ -100,6 +100,7 @@ def load_library(path: str | None = None):
         "mlst_export_stats_device": (C.c_int, [H, i64p, i64p]),
         "mlst_import_stats_device": (C.c_int, [H, i64p, i64p]),
         "mlst_pileup": (C.c_int, [H, u32p, C.c_uint32, u32p]),
+        "mlst_set_depth_cap": (C.c_int, [H, C.c_uint32]),
         "mlst_pileup_device": (C.c_int, [H, u32p, C.c_uint32, u32p, C.POINTER(C.c_uint64)]),
         "mlst_consensus": (C.c_int, [H, u32p, C.c_uint32, C.c_uint32, C.c_char, u8p, u32p]),
         "mlst_consensus_from_counts_device": (C.c_int, [H, u32p, C.c_uint64, C.c_uint32, C.c_char, u8p]),
@@ -193,6 +194,7 @@ class Engine:
             msg = self.lib.mlst_last_error(None)
             raise MlstError("mlst_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
         self.device = device
+        self.depth_cap = 0
         self.index: AlleleIndex | None = None
 
     def close(self):
@@ -461,6 +463,12 @@ class Engine:
         self._check(self.lib.mlst_import_stats_device(self._h, d_sum, d_min), "mlst_import_stats_device")
 
     # ---- pass 2 ----
+    def set_depth_cap(self, cap: int) -> None:
+        """Policy MLST_DEPTH_CAP as a switch (pysam max_depth, metaMLST_functions.py:255-259): 0 = off; n = a column sees
+        the first n records that span it in (read index, strand) order.  Every pile-up that follows."""
+        self._check(self.lib.mlst_set_depth_cap(self._h, int(cap)), "mlst_set_depth_cap")
+        self.depth_cap = int(cap)
+
     def pileup(self, chosen: list[int]) -> dict[int, np.ndarray]:
         """{allele idx: uint32[len, 4]} for the chosen alleles (A,C,G,T columns)."""
         ch = np.ascontiguousarray(chosen, dtype=np.uint32)

@@ -586,6 +586,67 @@ int orc_pileup(const orc_ref* r, const uint8_t* bases, const uint8_t* quals, con
     return 0;
 }
 
+/* Pass 2 under a per-column depth cap (policy MLST_DEPTH_CAP of include/mlst_policy.h; pysam's pileup(max_depth=8000),
+ * metaMLST_functions.py:255-259, stated as a rule that does not depend on the order of a BAM file): a column of a
+ * chosen allele sees only the first `cap` records that SPAN it -- records ordered by (read index, strand), the span of a
+ * record being its aligned allele columns from the first to the last, deleted columns inside included (they sit in a pysam
+ * pile-up column as is_del entries and count towards its depth).  Every record of the BAM file counts towards the depth
+ * (score >= the aligner's floor), whether or not it passes the AS / XM tag filter; the filters (tags, Phred, ACGT) apply to
+ * what was seen.  cap = 0: orc_pileup.  Serial in read order: this is the statement of the rule, not a fast path. */
+int orc_pileup_capped(const orc_ref* r, const uint8_t* bases, const uint8_t* quals, const uint64_t* off,
+                      uint64_t n_reads, const uint32_t* chosen, uint32_t n_chosen, uint32_t cap, uint32_t* counts, uint32_t* depth_seen) {
+    if (cap == 0) return orc_pileup(r, bases, quals, off, n_reads, chosen, n_chosen, counts, 0);
+    const uint32_t nL = r->n_loci;
+    int64_t* col_base = (int64_t*)malloc(sizeof(int64_t) * nL);
+    uint32_t* chosen_of = (uint32_t*)malloc(sizeof(uint32_t) * nL);
+    for (uint32_t l = 0; l < nL; l++) { col_base[l] = -1; chosen_of[l] = 0; }
+    uint64_t ncols = 0;
+    for (uint32_t k = 0; k < n_chosen; k++) {
+        uint32_t a = chosen[k]; if (a >= r->n_alleles) { free(col_base); free(chosen_of); return -1; }
+        uint32_t L = r->locus_of[a]; if (col_base[L] >= 0) { free(col_base); free(chosen_of); return -1; }
+        col_base[L] = (int64_t)ncols; chosen_of[L] = a; ncols += r->len[a];
+    }
+    memset(counts, 0, sizeof(uint32_t) * 4 * ncols);
+    uint32_t* depth = (uint32_t*)calloc(ncols ? ncols : 1, sizeof(uint32_t));      /* records that span the column, all of them */
+    uint8_t* seen = (uint8_t*)malloc(MLST_MAX_ALLELE_LEN + 1);
+    aln_t* al = (aln_t*)malloc(sizeof(aln_t));
+    for (uint64_t ri = 0; ri < n_reads; ri++) {
+        int n = (int)(off[ri + 1] - off[ri]);
+        if (n > MLST_MAX_READ_LEN || n < K) continue;
+        uint8_t code[MLST_MAX_READ_LEN], phred[MLST_MAX_READ_LEN];
+        for (int i = 0; i < n; i++) {
+            code[i] = base_code(bases[off[ri] + i]);
+            int q = (int)quals[off[ri] + i] - 33; phred[i] = (uint8_t)(q < 0 ? 0 : (q > 127 ? 127 : q));
+        }
+        cand_t items[MLST_MAX_CAND];
+        int ni = seed_read(r, code, n, items);
+        for (int strand = 0; strand < 2; strand++)      /* the order of a read's records: forward strand first (a read has one item per locus and strand) */
+        for (int it = 0; it < ni; it++) {
+            if (items[it].strand != strand) continue;
+            uint32_t L = items[it].locus; if (col_base[L] < 0) continue;
+            uint8_t rb[MLST_MAX_READ_LEN], pen[MLST_MAX_READ_LEN], q[MLST_MAX_READ_LEN];
+            orient_read(r, code, phred, n, items[it].strand, rb, pen, q);
+            align_pair(r, rb, pen, n, chosen_of[L], items[it].diag, al);
+            if (al->score < r->floor_tab[n] || al->score <= 0 || al->n_cols <= 0) continue;      /* no record */
+            int j0 = al->cj[0], j1 = al->cj[0];
+            for (int k = 1; k < al->n_cols; k++) { if (al->cj[k] < j0) j0 = al->cj[k]; if (al->cj[k] > j1) j1 = al->cj[k]; }
+            for (int j = j0; j <= j1; j++) {
+                uint32_t* dp = &depth[(uint64_t)col_base[L] + (uint64_t)j];
+                seen[j] = *dp < cap; (*dp)++;
+            }
+            if (al->score < r->prm.minscore || al->xm > r->prm.max_xm) continue;                 /* BAM_tagFilter AS, XM */
+            for (int k = 0; k < al->n_cols; k++) {
+                int i = al->ci[k], j = al->cj[k];
+                if (!seen[j] || rb[i] > 3 || q[i] < r->prm.minqual) continue;
+                counts[((uint64_t)col_base[L] + (uint64_t)j) * 4 + rb[i]]++;
+            }
+        }
+    }
+    if (depth_seen) memcpy(depth_seen, depth, sizeof(uint32_t) * ncols);
+    free(al); free(seen); free(depth); free(col_base); free(chosen_of);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ exhaustive mode (measurement of the seeding policy)
  *
  * What bowtie2 -a would report if it examined EVERYTHING: for every read, every allele and both strands the best

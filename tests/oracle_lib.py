@@ -41,6 +41,8 @@ def lib():
         _lib.orc_accumulate_records.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         _lib.orc_pileup.restype = C.c_int
         _lib.orc_pileup.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_int]
+        _lib.orc_pileup_capped.restype = C.c_int
+        _lib.orc_pileup_capped.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, vp, vp]
         _lib.orc_align_one.restype = C.c_int
         _lib.orc_align_one.argtypes = [vp, vp, vp, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         for fn in ("orc_exhaustive", "orc_pass1_dense"):
@@ -137,12 +139,23 @@ class Oracle:
             raise RuntimeError("orc_accumulate_records rc=%d" % rc)
         return s
 
-    def pileup(self, chosen):
+    def pileup(self, chosen, depth_cap: int = 0, depth_out: dict = None):
+        """depth_cap > 0: orc_pileup_capped (the first `depth_cap` records per column in (read index, strand) order);
+        depth_out, when given, receives {allele: records that span each column} (uncapped)."""
         b, q, off = self._reads
         ch = np.ascontiguousarray(chosen, np.uint32)
         lens = [int(self.index.off[a + 1] - self.index.off[a]) for a in chosen]
         counts = np.zeros((sum(lens), 4), np.uint32)
-        rc = lib().orc_pileup(self._r, _p(b), _p(q), _p(off), len(off) - 1, _p(ch), len(ch), _p(counts), self.threads)
+        if depth_cap:
+            depth = np.zeros(sum(lens), np.uint32)
+            rc = lib().orc_pileup_capped(self._r, _p(b), _p(q), _p(off), len(off) - 1, _p(ch), len(ch), int(depth_cap), _p(counts), _p(depth))
+            if depth_out is not None:
+                at = 0
+                for a, L in zip(chosen, lens):
+                    depth_out[int(a)] = depth[at:at + L]
+                    at += L
+        else:
+            rc = lib().orc_pileup(self._r, _p(b), _p(q), _p(off), len(off) - 1, _p(ch), len(ch), _p(counts), self.threads)
         if rc != 0:
             raise RuntimeError("orc_pileup rc=%d" % rc)
         out, at = {}, 0
