@@ -1786,17 +1786,21 @@ __device__ __forceinline__ void extend_pairs_body(const EngineDev* __restrict__ 
         u32 tot_rec = 0, tot_dp = 0;
         for (int w = 0; w < nwv; w++) { tot_rec += s_cnt[w][0]; tot_dp += s_cnt[w][1]; }
         if (tid == 0 && tot_rec) atomicAdd(&E.ret_nrec[it.ret], tot_rec);   // per-read record count (Q1)
-        // Fused accumulation (metamlst.py:101-130) when everything about this read is known here:
-        // it has a single work item and no pair is waiting for the banded SW.
-        if (res_ok && (state & IS_SINGLE) && tot_dp == 0) {
+        // Fused accumulation (metamlst.py:101-130) when everything about this read is known here: no pair is waiting for the
+        // banded SW, and whether the read has exactly one record (Q1: column 15 is then XO) does not depend on its other work
+        // items -- it has none, or this item alone holds two records or more (then it has not), or none at all.  (On databases
+        // with near-duplicate loci most reads hold several items, each with hundreds of records: left to k_accumulate, which
+        // walks open items one per workgroup turn, they were 0.39 ms of the skewed database's step.)
+        if (res_ok && tot_dp == 0 && ((state & IS_SINGLE) || !P.quirk || tot_rec != 1)) {
             bool use_xo = P.quirk && tot_rec == 1;
+            const bool packed_acc = E.cap_items < (1ull << 24);      // count << 40 | sum in one 64-bit addition (see extend_body)
             u32 acc = 0, ign = 0;
             for (u32 a = tid; a < L.n_alleles; a += nthr) {
                 u32 r = E.res[it.res_off + a];
                 if (!(r & R_REC)) continue;
                 if (accept_rec(P, r, n, use_xo)) {
-                    atomicAdd((u64*)&E.sum_score[L.a_begin + a], (u64)(r & 0x3FF));
-                    atomicAdd(&E.n_hits[L.a_begin + a], 1u);
+                    if (packed_acc) atomicAdd(&E.acc64[L.a_begin + a], (1ull << 40) | (u64)(r & 0x3FF));
+                    else { atomicAdd((u64*)&E.sum_score[L.a_begin + a], (u64)(r & 0x3FF)); atomicAdd(&E.n_hits[L.a_begin + a], 1u); }
                     acc++;
                 } else ign++;
             }
@@ -2303,7 +2307,8 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                 const int clipped = overlap - blen;          // overlap columns the ungapped alignment left out (gap_trigger)
                 return mm > P.trig && score >= floor_n && clipped >= P.clip && 2 * (mm - xm) >= clipped;
             };
-            bool slow = !(flags & XF_SINGLE) || P.trig < 0 || n_alleles > acc_cap;
+            const bool single = (flags & XF_SINGLE) != 0;
+            bool slow = P.trig < 0 || n_alleles > acc_cap;
             if (!slow) {
                 // A read with one work item (nearly all): what metamlst.py:101-130 would add for each record is noted beside the
                 // summaries (LDS) while the alleles are composed, and added once the item's counts say that no pair needs the
@@ -2337,6 +2342,7 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                     for (int w = 0; w < nwv; w++) { tot_rec += s_cnt[w][0]; tot_acc += s_cnt[w][1]; tot_track += s_cnt[w][2]; }
                     __syncthreads();
                 }
+                // (a read with several work items: this item alone settles Q1 unless it holds exactly one record -- see extend_pairs_body)
                 if (tot_track == 0 && !(P.quirk && tot_rec == 1)) {      // block-uniform
                     // The device performs ~95 G additions a second (the rate that binds k_pileup too), and two per accepted record --
                     // sum and count -- were 0.42 of this kernel's 0.46 ms however few instructions it issued: count and sum travel in
@@ -2351,7 +2357,7 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
                     if (tid == 0) {
                         if (tot_rec) atomicAdd(&E.ret_nrec[ret], tot_rec);      // per-read record count (Q1)
                         c_tot += tot_rec; c_ign += tot_rec - tot_acc;
-                        E.item_state[ii] = (u8)(IS_SINGLE | IS_DONE | (tot_acc ? IS_ACC : 0));
+                        E.item_state[ii] = (u8)((single ? IS_SINGLE : 0) | IS_DONE | (tot_acc ? IS_ACC : 0));
                     }
                     done_fast = true;
                 } else { slow = true; nrec = 0; ntrack = 0; }
@@ -2389,15 +2395,15 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
         if (tid == 0 && tot_rec) atomicAdd(&E.ret_nrec[ret], tot_rec);   // per-read record count (Q1)
         // Fused accumulation (metamlst.py:101-130) when everything about this read is known here:
         // it has a single work item and no pair is waiting for the banded SW.
-        if (res_ok && (flags & XF_SINGLE) && tot_dp == 0) {
+        if (res_ok && tot_dp == 0 && ((flags & XF_SINGLE) || !P.quirk || tot_rec != 1)) {
             bool use_xo = P.quirk && tot_rec == 1;
             u32 acc = 0, ign = 0;
             for (u32 a = tid; a < n_alleles; a += nthr) {
                 u32 r = E.res[res_off + a];
                 const bool rec = r & R_REC, ok = rec && accept_rec(P, r, n, use_xo);
                 if (ok) {
-                    atomicAdd((u64*)&E.sum_score[a_begin + a], (u64)(r & 0x3FF));
-                    atomicAdd(&E.n_hits[a_begin + a], 1u);
+                    if (packed_acc) atomicAdd(&E.acc64[a_begin + a], (1ull << 40) | (u64)(r & 0x3FF));
+                    else { atomicAdd((u64*)&E.sum_score[a_begin + a], (u64)(r & 0x3FF)); atomicAdd(&E.n_hits[a_begin + a], 1u); }
                 }
                 acc += (u32)__popcll(__ballot(ok)); ign += (u32)__popcll(__ballot(rec && !ok));
             }
