@@ -633,7 +633,59 @@ def end_to_end(w, args, torch, device):
     out["fastq_text_packed_on_host_to_st"] = {"Mreads_per_s": round(n / t_q / 1e6, 1), "seconds": round(t_q, 4), "species_called": len(calls_q)}
     out["bgzip_to_st"] = {"reads": nz, "Mreads_per_s": round(nz / min(ts) / 1e6, 1), "compressed_bytes": int(comp.size), "zlib_level": 6, "seconds": round(min(ts), 4),
                           "species_called": len(calls)}
+    del raw, parts
+    out["cli_folder_to_nfo"] = folder_leg(w, text_host, n, rec)
     return out
+
+
+def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=1 << 20):
+    """The product command on a folder of samples (`cli type folder/` = multigpu.type_many_samples: files -> reader thread -> GPU
+    parser -> the pipelined loop of metamlst_amd/pipeline.py on the workload's engines -> one .nfo file per sample;
+    /root/reference/metamlst-merge.py:93-107 reads that folder).  FASTQ text files in memory-backed storage, so what is
+    timed is the path from the page cache on -- file reads, link, device and host tail -- not a disk."""
+    import shutil
+    from metamlst_amd.multigpu import type_many_samples
+    from metamlst_amd.typing import TypingArgs
+    per = min(reads_per_file, n // n_files)
+    if per < 1000:
+        return {"skipped": "slice too small"}
+    root = tempfile.mkdtemp(prefix="mlst_folder_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        files = []
+        for k in range(n_files):
+            f = os.path.join(root, "s%02d.fastq" % k)
+            text_host[k * per * rec:(k + 1) * per * rec].tofile(f)
+            files.append([f])
+        ts = []
+        for r in range(3):
+            od = os.path.join(root, "out%d" % r)
+            prof = None
+            if r == 2 and os.environ.get("MLST_PROFILE_FOLDER"):
+                import cProfile
+                prof = cProfile.Profile(); prof.enable()
+            t0 = time.perf_counter()
+            tm = {}
+            rc = type_many_samples(w.engines, w.idx, w.database, TypingArgs(quiet=True), files, 0, 1, od, False, 256 << 20, timing=tm)
+            ts.append((time.perf_counter() - t0, tm))
+            if prof is not None:
+                import pstats
+                prof.disable()
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
+            assert rc == 0
+        written = sorted(os.listdir(od))
+        lines = sum(open(os.path.join(od, x)).read().count("\n") for x in written)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+        for e in w.engines:      # (type_many_samples puts the engines on their CU shares)
+            e.synchronize()
+            e.set_cu_partition(0, 1)
+    t, tm = min(ts, key=lambda x: x[0])
+    return {"samples": n_files, "reads_per_sample": per, "engines": len(w.engines), "seconds": round(t, 4),
+            "prologue_s": round(tm["prologue_s"], 4), "samples_s": round(tm["samples_s"], 4), "ms_per_sample": round(tm["samples_s"] / n_files * 1e3, 3),
+            "Mreads_per_s": round(n_files * per / tm["samples_s"] / 1e6, 1), "Mreads_per_s_with_prologue": round(n_files * per / t / 1e6, 1),
+            "nfo_files": len(written), "species_lines": lines,
+            "note": "prologue = what the command pays once (the database's look-up tables for the host tail, CU shares); per sample the path is FASTQ text "
+                    "over the link (%d B/read) like fastq_text_to_st -- not the resident batches of the headline" % rec}
 
 
 def literal_leg(w, args, torch, tmp):

@@ -99,6 +99,11 @@ void mlst_release_index_cache(void);
 int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uint8_t* quals,
                       const uint64_t* off, uint64_t n_reads, int paired);
 
+/* Page-locked host memory for the caller's input buffers (FASTQ text read from files, packed arrays): host-to-device copies
+ * from it are DMA transfers at the link's rate, without the runtime's staging copy.  Process-wide; no engine needed. */
+int mlst_alloc_host(uint64_t n_bytes, void** out);
+int mlst_free_host(void* p);
+
 /* Pass 1 straight from FASTQ TEXT (uncompressed, 4 lines per record, LF or CRLF) held in host memory: the bytes
  * cross PCIe once and are parsed on the GPU (line starts by block newline counts + scan, then packed).  The chunk
  * must hold whole records (cut it after a multiple of four lines).  Replaces the FASTQ reader in front of

@@ -166,6 +166,9 @@ def run_type(a, argv=None) -> int:
         return 1
     eng = Engine(a.device, prm)
     eng.load_reference(idx)
+    from . import fastq as _fq
+    from .engine import pinned_array
+    _fq.set_buffer_allocator(pinned_array)      # file chunks are read into page-locked buffers
     if a.depth_cap:
         eng.set_depth_cap(a.depth_cap)
     engines = [eng]
@@ -226,18 +229,43 @@ def _finish_type_device(a, eng, idx, database, targs) -> int:
     return _finish_type(a, idx, database, targs, st, None, typed=(chosen, letters))
 
 
-def submit_sample_files(eng, paths, paired: bool, chunk_bytes: int) -> None:
-    """All reads of one sample's FASTQ file(s) into one engine."""
+class _FileReader:
+    """prefetch(text_chunks(path, reuse=True)) whose buffers go back to the pool when the consumer says it is done (close)."""
+
+    def __init__(self, path: str, chunk_bytes: int, lo: int = 0, hi=None):
+        self.ring: list = []
+        self.it = prefetch(text_chunks(path, chunk_bytes, lo, hi, reuse=True, ring=self.ring))
+
+    def __iter__(self):
+        return self.it
+
+    def close(self) -> None:
+        from .fastq import release_buffers
+        release_buffers(self.ring)
+
+
+def open_sample_reader(paths, paired: bool, chunk_bytes: int):
+    """The reader thread of a sample's FIRST file, started now (None when that file is not plain or gzip FASTQ text): a caller
+    with many samples opens sample k + 1 before it feeds sample k, and k + 1's first chunks are read meanwhile."""
+    if paired or not paths or is_bgzf(paths[0]):
+        return None
+    return _FileReader(paths[0], chunk_bytes)
+
+
+def submit_sample_files(eng, paths, paired: bool, chunk_bytes: int, first_reader=None) -> None:
+    """All reads of one sample's FASTQ file(s) into one engine (first_reader: open_sample_reader(paths, ...), if opened ahead)."""
     if paired:
         for c1, c2 in prefetch(pair_chunks(paths[0], paths[1], chunk_bytes // 2)):
             eng.submit_fastq_pair(c1, c2)
         return
-    for path in paths:
+    for k, path in enumerate(paths):
         if is_bgzf(path):      # bgzip'd FASTQ: the compressed blocks go to the GPU and are inflated there
             eng.submit_fastq_bgzf_file(path, paired=False)
             continue
-        for chunk in prefetch(text_chunks(path, chunk_bytes)):
-            eng.submit_fastq(chunk, paired=False)
+        reader = first_reader if (k == 0 and first_reader is not None) else _FileReader(path, chunk_bytes)
+        for chunk in reader:
+            eng.submit_fastq(chunk, paired=False)      # (returns when the chunk has left the host buffer)
+        reader.close()
 
 
 def _finish_type(a, idx, database, targs, st, pileup_fn, typed=None) -> int:

@@ -4437,6 +4437,23 @@ extern "C" int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, c
     return submit_impl(h, h->d_packed, h->d_qc, h->d_lens, n_reads, wpr, qstride, paired, 2);
 }
 
+// Page-locked host memory for a caller's input buffers (FASTQ text read from files): a copy from such a buffer is one DMA
+// transfer at the link's rate; from ordinary memory the runtime first copies through its own staging buffers on a host
+// thread.  Process-wide (no engine needed); released by mlst_free_host.
+extern "C" int mlst_alloc_host(uint64_t n_bytes, void** out) {
+    if (!out) return MLST_E_INVALID;
+    *out = nullptr;
+    if (n_bytes == 0) return MLST_E_INVALID;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n_bytes, hipHostMallocDefault) != hipSuccess || !p) { (void)hipGetLastError(); return MLST_E_HIP; }
+    *out = p;
+    return MLST_OK;
+}
+extern "C" int mlst_free_host(void* p) {
+    if (!p) return MLST_OK;
+    return hipHostFree(p) == hipSuccess ? MLST_OK : MLST_E_HIP;
+}
+
 extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int paired, uint64_t* n_reads_out) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     if (n_reads_out) *n_reads_out = 0;

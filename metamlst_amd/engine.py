@@ -95,6 +95,8 @@ def load_library(path: str | None = None):
         "mlst_submit_packed_device": (C.c_int, [H, u32p, u8p, u16p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
         "mlst_pack_fastq_host": (C.c_int, [u8p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, u8p, u16p, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
         "mlst_submit_packed_host": (C.c_int, [H, u32p, u8p, u16p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
+        "mlst_alloc_host": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
+        "mlst_free_host": (C.c_int, [C.c_void_p]),
         "mlst_get_allele_stats": (C.c_int, [H, i64p, u32p, u64p, u64p, u64p]),
         "mlst_stats_flat_sizes": (C.c_int, [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mlst_export_stats_device": (C.c_int, [H, i64p, i64p]),
@@ -178,6 +180,20 @@ def pack_fastq_host(text, read_len_max: int = 160, threads: int = 0):
     if rc != 0:
         raise MlstError("mlst_pack_fastq_host failed (%d): not whole 4-line FASTQ records, or a read longer than %d bases" % (rc, read_len_max))
     return packed, qrows, lens, int(n.value), wpr, qstride
+
+
+def pinned_array(n_bytes: int) -> np.ndarray:
+    """uint8 array of n_bytes in page-locked host memory (mlst_alloc_host); the memory is released when the array is collected.
+    Needs the GPU runtime: raises MlstError where there is none."""
+    import weakref
+    lib = load_library()
+    p = C.c_void_p()
+    rc = lib.mlst_alloc_host(int(n_bytes), C.byref(p))
+    if rc != 0 or not p.value:
+        raise MlstError("mlst_alloc_host(%d) failed (%d)" % (n_bytes, rc))
+    arr = np.frombuffer((C.c_uint8 * int(n_bytes)).from_address(p.value), np.uint8)
+    weakref.finalize(arr, lib.mlst_free_host, C.c_void_p(p.value)).atexit = False      # (at interpreter exit the runtime may be gone: the OS takes the pages)
+    return arr
 
 
 class Engine:

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import gzip
 import os
+import threading
 
 import numpy as np
 
@@ -97,15 +98,184 @@ def last_record_start(buf, window: int = 1 << 16) -> int:
         w = min(n, w * 4)
 
 
-def text_chunks(path: str, chunk_bytes: int = 256 << 20, start: int = 0, end: int | None = None):
+# ---- plain files: positional reads by a few threads into buffers that are used again
+# One Python thread moves ~1 GB/s from the page cache through f.read() + slicing (two or three copies of every byte): a
+# sample of a million reads took 0.3 s to reach the library, which needs 7 ms for it.  os.preadv releases the GIL, so a few
+# threads fill one numpy buffer side by side (no copy afterwards: the chunk handed to the library is a view of it), and
+# the buffers go round (a fresh 256 MB array costs its page faults again).
+_READ_PIECE = 4 << 20
+_pool_lock = threading.Lock()
+_pool_bufs: list = []          # idle buffers (uint8 arrays), at most _POOL_MAX of them
+_POOL_MAX = 6
+_readers = None
+
+
+def _reader_pool():
+    global _readers
+    if _readers is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _readers = ThreadPoolExecutor(max(2, min(int(os.environ.get("MLST_READ_THREADS", "32")), (os.cpu_count() or 2) // 2)), thread_name_prefix="fastq-read")
+    return _readers
+
+
+_alloc = None                  # set_buffer_allocator: n bytes -> uint8 array (page-locked memory when a GPU runtime is there)
+
+
+def set_buffer_allocator(fn) -> None:
+    """Where the read buffers of text_chunks(reuse=True) come from: fn(n_bytes) -> uint8 array, None = numpy.  The CLI passes
+    engine.pinned_array: a chunk then crosses the link as one DMA transfer instead of through the runtime's staging copy."""
+    global _alloc
+    with _pool_lock:
+        if fn is _alloc:
+            return
+        _alloc = fn
+        _pool_bufs.clear()
+
+
+def _take_buffer(n: int) -> np.ndarray:
+    with _pool_lock:
+        for k, b in enumerate(_pool_bufs):
+            if b.size >= n:
+                return _pool_bufs.pop(k)
+        if len(_pool_bufs) >= _POOL_MAX:
+            _pool_bufs.pop(0)
+        fn = _alloc
+    size = max(1 << 20, 1 << (int(n) - 1).bit_length())      # powers of two: a buffer fits the next file's chunks too
+    if fn is not None:
+        try:
+            return fn(size)
+        except Exception:      # noqa: BLE001 -- no page-locked memory to be had: ordinary memory does
+            pass
+    return np.empty(size, np.uint8)
+
+
+def _give_buffer(b: np.ndarray) -> None:
+    with _pool_lock:
+        if len(_pool_bufs) < _POOL_MAX:
+            _pool_bufs.append(b)
+
+
+def _pread_into(fd: int, buf: np.ndarray, lo: int, hi: int) -> None:
+    """bytes [lo, hi) of the file into buf[:hi - lo], pieces of 4 MB read side by side"""
+    mv = memoryview(buf)
+
+    def piece(a: int) -> None:
+        e = min(a + _READ_PIECE, hi)
+        at = a
+        while at < e:
+            got = os.preadv(fd, [mv[at - lo:e - lo]], at)
+            if got <= 0:
+                raise OSError("short read at byte %d" % at)
+            at += got
+
+    starts = range(lo, hi, _READ_PIECE)
+    if len(starts) <= 1:
+        for a in starts:
+            piece(a)
+    else:
+        list(_reader_pool().map(piece, starts))
+
+
+def release_buffers(ring: list) -> None:
+    """The consumer is done with every chunk of a text_chunks(reuse=True, ring=ring) walk: its buffers may serve the next file."""
+    while ring:
+        _give_buffer(ring.pop())
+
+
+def _plain_chunks(path: str, chunk_bytes: int, start: int, end: int | None, reuse: bool, ring: list | None = None):
+    """text_chunks for an uncompressed file (same chunks, same byte ranges): positional reads, chunks are uint8 arrays.
+    reuse=True: a chunk's memory is used again once the consumer has taken the chunk after the next THREE (prefetch() holds two,
+    the consumer one) -- for consumers that are done with a chunk when they ask for the next; reuse=False: every chunk its own array.
+    The walk never hands its buffers to another walk by itself -- its last chunks may still be in the consumer's hands when it
+    ends: a consumer that passes `ring` gets the buffers listed there and gives them back with release_buffers(ring)."""
+    size = os.path.getsize(path)
+    if size == 0:
+        return
+    fd = os.open(path, os.O_RDONLY)
+    if ring is None:
+        ring = []
+    try:
+        def peek(lo: int, n: int) -> bytes:
+            return os.pread(fd, max(0, min(n, size - lo)), lo)
+
+        examined = [0]
+
+        def first_start(at: int) -> int:
+            """first record start at or after byte `at` (absolute), -1 if none can be told"""
+            if at <= 0:
+                return 0
+            w = 1 << 16
+            while True:
+                head = peek(at - 1, w)                       # one byte early: a record that starts exactly at `at` counts
+                examined[0] = at - 1 + len(head)
+                s0 = record_start(head, 1)
+                if s0 >= 0:
+                    return at - 1 + s0
+                if examined[0] >= size or w >= (64 << 20):
+                    return -1
+                w *= 4
+
+        pos = first_start(start) if start else 0
+        if pos < 0:
+            if end is not None and examined[0] < end:
+                raise ValueError("%s: no FASTQ record boundary after byte %d" % (path, start))
+            return                                           # the range holds the inside of the file's last record only
+        if end is not None and pos >= end:
+            return                                           # the first record at or after `start` belongs to the next range
+        stop = size
+        if end is not None and end < size:
+            s1 = first_start(end)                            # the record that starts last before `end` is ours in full
+            stop = s1 if s1 >= 0 else size
+        while pos < stop:
+            e = min(pos + chunk_bytes, stop)
+            cut = e
+            if e < stop:                                     # cut at the last record start inside [pos, e)
+                w = 1 << 16
+                while True:
+                    lo = max(pos, e - w)
+                    k = last_record_start(peek(lo, e - lo))
+                    if k > 0 or (k == 0 and lo > pos):
+                        cut = lo + k
+                        break
+                    if lo == pos:                            # no whole record in the chunk (a record longer than it): read on
+                        chunk_bytes *= 2
+                        cut = -1
+                        break
+                    w *= 4
+                if cut < 0:
+                    continue
+            n = cut - pos
+            if reuse and len(ring) >= 4:
+                buf = ring.pop(0)
+                if buf.size < n:
+                    _give_buffer(buf)
+                    buf = _take_buffer(n)
+            else:
+                buf = _take_buffer(n) if reuse else np.empty(n, np.uint8)
+            _pread_into(fd, buf, pos, cut)
+            if reuse:
+                ring.append(buf)
+            chunk = buf[:n]
+            if cut < size or n > 4096 or chunk.tobytes().strip():      # (a file's whitespace-only tail is not a chunk)
+                yield chunk
+            pos = cut
+    finally:
+        os.close(fd)
+
+
+def text_chunks(path: str, chunk_bytes: int = 256 << 20, start: int = 0, end: int | None = None, reuse: bool = False, ring: list | None = None):
     """Yield byte chunks of an uncompressed (or .gz) FASTQ that each hold whole records, for Engine.submit_fastq.
     The host never scans the text: a chunk is cut at the last record start found in its tail (record_start); parsing
     happens on the GPU.  start / end (plain files only) restrict the walk to the records that START in the byte range
     [start, end): the first record is found by resynchronising at `start`, the last one is completed beyond `end` --
-    N ranks given consecutive ranges read every record exactly once and touch only their share of the file."""
+    N ranks given consecutive ranges read every record exactly once and touch only their share of the file.
+    Plain files are read by positional reads of a few threads (_plain_chunks; reuse: see there); .gz through gzip."""
     gz = path.endswith(".gz")
     if gz and (start or end is not None):
         raise ValueError("byte ranges need an uncompressed FASTQ (gzip has no random access; bgzip files are sharded by block)")
+    if not gz:
+        yield from _plain_chunks(path, chunk_bytes, start, end, reuse, ring)
+        return
     carry = b""
     with _open(path) as f:
         pos = 0
@@ -233,31 +403,43 @@ def mates_share_names(path1: str, path2: str) -> bool:
     return bool(h1) and bool(h2) and h1[0] == h2[0]
 
 
-def prefetch(it, depth: int = 2):
+class prefetch:
     """Run the iterator `it` in a thread, `depth` items ahead: file reads (which release the GIL) overlap the consumer's
-    GPU submissions.  Exceptions of the producer are raised in the consumer."""
-    import queue
-    import threading
-    q: queue.Queue = queue.Queue(maxsize=depth)
-    END = object()
+    GPU submissions.  Exceptions of the producer are raised in the consumer.  The thread starts at once (not at the first
+    next()): a caller that opens the reader of sample k + 1 before it consumes sample k has the first chunks of k + 1
+    read meanwhile."""
 
-    def work():
-        try:
-            for x in it:
-                q.put(x)
-            q.put(END)
-        except BaseException as e:      # noqa: BLE001 -- handed to the consumer
-            q.put(e)
+    def __init__(self, it, depth: int = 2):
+        import queue
+        self._q: queue.Queue = queue.Queue(maxsize=depth)
+        self._end = object()
+        self._done = False
 
-    t = threading.Thread(target=work, daemon=True)
-    t.start()
-    while True:
-        x = q.get()
-        if x is END:
-            return
+        def work():
+            try:
+                for x in it:
+                    self._q.put(x)
+                self._q.put(self._end)
+            except BaseException as e:      # noqa: BLE001 -- handed to the consumer
+                self._q.put(e)
+
+        self._t = threading.Thread(target=work, daemon=True)
+        self._t.start()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._done:
+            raise StopIteration
+        x = self._q.get()
+        if x is self._end:
+            self._done = True
+            raise StopIteration
         if isinstance(x, BaseException):
+            self._done = True
             raise x
-        yield x
+        return x
 
 
 def tile_fasta(path: str, read_len: int = 150, stride: int = 25, min_len: int = 50, chunk_reads: int = 500_000):

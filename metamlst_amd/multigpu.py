@@ -167,7 +167,7 @@ def submit_fastq_shard(eng, paths: list[str], rank: int, world: int, chunk_bytes
             size = os.path.getsize(path)
             lo, hi = size * rank // world, (size * (rank + 1) // world if rank + 1 < world else None)
             eng.set_read_index_base((f * world + rank) << ORDER_SHIFT)
-            for chunk in prefetch(text_chunks(path, chunk_bytes, lo, hi)):
+            for chunk in prefetch(text_chunks(path, chunk_bytes, lo, hi, reuse=True)):      # (buffers go round inside the walk; none is handed on)
                 eng.submit_fastq(chunk, paired=False)
 
 
@@ -208,7 +208,7 @@ def deal_samples(sizes: list[int], world: int) -> list[int]:
 
 
 def type_many_samples(engines, idx, database, targs, samples: list[list[str]], rank: int, world: int, out_dir: str, log: bool,
-                      chunk_bytes: int, printer=None) -> int:
+                      chunk_bytes: int, printer=None, timing: dict | None = None) -> int:
     """Multi-sample mode (BASELINE configs[3]: "RCCL gather of per-species ST tables"; the reference's real use is many
     samples into one folder, one metamlst.py run each, metamlst-merge.py:93-107 reads the folder).  Whole samples are
     dealt to the ranks -- no collective on the data path --, every rank sends its samples through the pipelined typing
@@ -217,9 +217,13 @@ def type_many_samples(engines, idx, database, targs, samples: list[list[str]], r
     rank 0 gathers the .nfo lines (and --log tables) and writes them, sample by sample in the order given: byte for
     byte what one run per sample writes."""
     import time
-    from .cli import submit_sample_files
+    from .cli import open_sample_reader, submit_sample_files
     from .pipeline import TypingPipeline
     from .typing import log_table, sample_name, type_sample
+    t_begin = time.perf_counter()
+    from . import fastq as _fq
+    from .engine import pinned_array
+    _fq.set_buffer_allocator(pinned_array)      # file chunks are read into page-locked buffers (one DMA transfer each)
     sizes = [sum(os.path.getsize(f) for f in files) for files in samples]
     owner = deal_samples(sizes, world)
     jobs = [(i, files) for i, files in enumerate(samples) if owner[i] == rank]
@@ -229,17 +233,40 @@ def type_many_samples(engines, idx, database, targs, samples: list[list[str]], r
         pipe.place(parts)
         pipe.stagger_s = 0.75e-3
 
+    # the reader thread of the sample after the one being fed is started first: its file is read while this one crosses the link
+    readers: dict = {}
+    order = [j[0] for j in jobs]
+    nxt_of = {a: b for a, b in zip(order[:-1], order[1:])}
+    files_of = dict(jobs)
+
     def feed(e, job):
-        submit_sample_files(e, job[1], False, chunk_bytes)
+        i = job[0]
+        mine_r = readers.pop(i, None) or open_sample_reader(job[1], False, chunk_bytes)
+        if i in nxt_of:
+            readers[nxt_of[i]] = open_sample_reader(files_of[nxt_of[i]], False, chunk_bytes)
+        submit_sample_files(e, job[1], False, chunk_bytes, first_reader=mine_r)
+
+    # The per-allele table (metamlst.py:133-151 over every allele with a hit: `cel`) is display -- the closest-allele listing of
+    # metamlst.py:213-230 and the --log table; the .nfo line needs the device's choice and consensus only.  A quiet run
+    # without --log skips it, and with it the 12 bytes per allele of every sample's fetch (cfg3: 0.3 s of Python and 4 MB per
+    # sample against ~7 ms for a sample of a million reads otherwise).
+    from . import db as mdb
+    show = printer is not None
+    cache = mdb.DbCache(database.conn)
 
     def tail(job, st, chosen, letters):
         i, files = job
         name = sample_name(files[0])
-        res = type_sample(idx, st, None, database, name, targs, out_dir=None, typed=(chosen, letters))
+        res = type_sample(idx, st, None, database, name, targs, out_dir=None, fast=not show, cache=cache, typed=(chosen, letters))
         return {"i": i, "name": name, "nfo": [r.nfo_line for r in res if r.written],
-                "log": log_table(idx, st, targs, files[0]) if log else None, "results": res if printer else None}
+                "log": log_table(idx, st, targs, files[0]) if log else None, "results": res if show else None}
 
-    mine = pipe.run(jobs, feed, tail, per_allele=True)
+    t_run = time.perf_counter()
+    mine = pipe.run(jobs, feed, tail, per_allele=show or log)
+    if timing is not None:      # (what a run pays once -- database look-up tables, CU shares -- and what it pays per sample)
+        timing["prologue_s"] = t_run - t_begin
+        timing["samples_s"] = time.perf_counter() - t_run
+        timing["host_ms"] = dict(pipe.host_ms)
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world if rank == 0 else None

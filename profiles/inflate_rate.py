@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of the device inflate kernel alone (HIP events around k_inflate): bgzip'd FASTQ of N reads, level 1 and 6."""
+"""Throughput of the device inflate kernel alone (HIP events around k_inflate): bgzip'd FASTQ of N reads, level 1 and 6.
+    python profiles/inflate_rate.py [reads] [levels, e.g. 6 or 1,6]"""
 import os, struct, sys, time, zlib
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
@@ -22,7 +23,7 @@ quals = np.full((n, L), 73, np.uint8); err = rng.random((n, L)) < 0.01; quals[er
 recs = [b"@r%d x\n" % k + bases[k].tobytes() + b"\n+\n" + quals[k].tobytes() + b"\n" for k in range(n)]
 text = b"".join(recs)
 eng = Engine(0)
-for level in (1, 6):
+for level in [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,6").split(",")]:
     with ThreadPoolExecutor(16) as ex:
         blocks = list(ex.map(block, [(text[i:i + 65280], level) for i in range(0, len(text), 65280)]))
     comp = b"".join(blocks)
