@@ -255,8 +255,11 @@ def open_sample_reader(paths, paired: bool, chunk_bytes: int):
 def submit_sample_files(eng, paths, paired: bool, chunk_bytes: int, first_reader=None) -> None:
     """All reads of one sample's FASTQ file(s) into one engine (first_reader: open_sample_reader(paths, ...), if opened ahead)."""
     if paired:
-        for c1, c2 in prefetch(pair_chunks(paths[0], paths[1], chunk_bytes // 2)):
+        from .fastq import release_buffers
+        ring: list = []
+        for c1, c2 in prefetch(pair_chunks(paths[0], paths[1], chunk_bytes // 2, reuse=True, ring=ring)):
             eng.submit_fastq_pair(c1, c2)
+        release_buffers(ring)
         return
     for k, path in enumerate(paths):
         if is_bgzf(path):      # bgzip'd FASTQ: the compressed blocks go to the GPU and are inflated there

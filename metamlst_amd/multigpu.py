@@ -146,7 +146,7 @@ def submit_fastq_shard(eng, paths: list[str], rank: int, world: int, chunk_bytes
                 eng.set_read_index_base(k << 36)
                 eng.submit_fastq_pair(c1, c2)
             return
-        for k, (c1, c2) in enumerate(prefetch(pair_chunks(paths[0], paths[1], chunk_bytes // 2))):
+        for k, (c1, c2) in enumerate(prefetch(pair_chunks(paths[0], paths[1], chunk_bytes // 2, reuse=True))):
             if k % world == rank:
                 eng.set_read_index_base(k << 36)
                 eng.submit_fastq_pair(c1, c2)

@@ -193,10 +193,33 @@ def test_pair_cuts_are_the_chunks_pair_chunks_yields(tmp_path):
         f.seek(-1, 2)
         f.truncate()                                     # no newline behind the last quality line
     for chunk in (2048, 5000, 1 << 20):
-        want = list(fastq.pair_chunks(a, b, chunk))
+        want = [(bytes(x), bytes(y)) for x, y in fastq.pair_chunks(a, b, chunk)]
         cuts = fastq.pair_cuts(a, b, chunk)
         assert [fastq.read_pair_cut(a, b, c) for c in cuts] == want
         assert sum(c[1] for c in cuts) == os.path.getsize(a) and sum(c[3] for c in cuts) == os.path.getsize(b)
+        assert all(x.count(b"\n") == y.count(b"\n") and x.count(b"\n") % 4 == 0 for x, y in want)
+        assert b"".join(x for x, _ in want) == open(a, "rb").read() and b"".join(y for _, y in want) == open(b, "rb").read() + b"\n"
+    # the threaded walk of plain files cuts where the one-thread walk (kept for gzip) cuts
+    import gzip
+    for src in (a, b):
+        with open(src, "rb") as f, gzip.open(src + ".gz", "wb") as g:
+            g.write(f.read())
+    for chunk in (2048, 5000):
+        p, q = [(bytes(x), bytes(y)) for x, y in fastq.pair_chunks(a, b, chunk)], list(fastq.pair_chunks(a + ".gz", b + ".gz", chunk))
+        # (the one-thread walk learns of a file's end one read later and hands the last record over in a chunk of its own)
+        assert p[:-1] == q[:len(p) - 1] and b"".join(x for x, _ in p) == b"".join(x for x, _ in q) and b"".join(y for _, y in p) == b"".join(y for _, y in q)
+    # buffers that go round behind a reader thread; files with different numbers of records are refused
+    ring = []
+    got = [(bytes(x), bytes(y)) for x, y in fastq.prefetch(fastq.pair_chunks(a, b, 3000, reuse=True, ring=ring))]
+    fastq.release_buffers(ring)
+    assert got == [(bytes(x), bytes(y)) for x, y in fastq.pair_chunks(a, b, 3000)]
+    with open(b, "ab") as f:
+        f.write(b"\n@extra\nAC\n+\nII\n")
+    try:
+        list(fastq.pair_chunks(a, b, 4096))
+        raise AssertionError("different record counts went unnoticed")
+    except ValueError:
+        pass
 
 
 def test_plain_file_chunks_partition_the_file_at_any_cut_and_buffers_go_round_safely(tmp_path):
