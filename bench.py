@@ -633,12 +633,14 @@ def end_to_end(w, args, torch, device):
     out["fastq_text_packed_on_host_to_st"] = {"Mreads_per_s": round(n / t_q / 1e6, 1), "seconds": round(t_q, 4), "species_called": len(calls_q)}
     out["bgzip_to_st"] = {"reads": nz, "Mreads_per_s": round(nz / min(ts) / 1e6, 1), "compressed_bytes": int(comp.size), "zlib_level": 6, "seconds": round(min(ts), 4),
                           "species_called": len(calls)}
-    del raw, parts
+    del raw
     out["cli_folder_to_nfo"] = folder_leg(w, text_host, n, rec)
+    out["cli_folder_bgzip_to_nfo"] = folder_leg(w, text_host, n, rec, bgzf_parts=parts, eof_block=bgzf_block(b""))
+    del parts
     return out
 
 
-def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=1 << 20):
+def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=1 << 20, bgzf_parts=None, eof_block=b""):
     """The product command on a folder of samples (`cli type folder/` = multigpu.type_many_samples: files -> reader thread -> GPU
     parser -> the pipelined loop of metamlst_amd/pipeline.py on the workload's engines -> one .nfo file per sample;
     /root/reference/metamlst-merge.py:93-107 reads that folder).  FASTQ text files in memory-backed storage, so what is
@@ -647,14 +649,24 @@ def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=1 << 20):
     from metamlst_amd.multigpu import type_many_samples
     from metamlst_amd.typing import TypingArgs
     per = min(reads_per_file, n // n_files)
+    if bgzf_parts is not None:      # whole BGZF blocks of 65,280 bytes of text: a sample = a run of them (its last record may be cut: the parser drops nothing, the reader completes it from the next block -- so samples are cut at block AND record boundaries: 65,280 x k bytes with k a multiple of rec / gcd)
+        import math
+        unit = rec // math.gcd(rec, 65280)                   # blocks per boundary that is also a record boundary
+        blocks_per = (per * rec // 65280) // unit * unit
+        per = blocks_per * 65280 // rec
     if per < 1000:
         return {"skipped": "slice too small"}
     root = tempfile.mkdtemp(prefix="mlst_folder_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         files = []
         for k in range(n_files):
-            f = os.path.join(root, "s%02d.fastq" % k)
-            text_host[k * per * rec:(k + 1) * per * rec].tofile(f)
+            if bgzf_parts is None:
+                f = os.path.join(root, "s%02d.fastq" % k)
+                text_host[k * per * rec:(k + 1) * per * rec].tofile(f)
+            else:
+                f = os.path.join(root, "s%02d.fastq.gz" % k)
+                with open(f, "wb") as fh:
+                    fh.write(b"".join(bgzf_parts[k * blocks_per:(k + 1) * blocks_per]) + eof_block)
             files.append([f])
         ts = []
         for r in range(3):
@@ -680,7 +692,7 @@ def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=1 << 20):
             e.synchronize()
             e.set_cu_partition(0, 1)
     t, tm = min(ts, key=lambda x: x[0])
-    return {"samples": n_files, "reads_per_sample": per, "engines": len(w.engines), "seconds": round(t, 4),
+    return {"samples": n_files, "reads_per_sample": per, "input": "FASTQ text" if bgzf_parts is None else "bgzip (level 6), inflated on the GPU", "engines": len(w.engines), "seconds": round(t, 4),
             "prologue_s": round(tm["prologue_s"], 4), "samples_s": round(tm["samples_s"], 4), "ms_per_sample": round(tm["samples_s"] / n_files * 1e3, 3),
             "Mreads_per_s": round(n_files * per / tm["samples_s"] / 1e6, 1), "Mreads_per_s_with_prologue": round(n_files * per / t / 1e6, 1),
             "nfo_files": len(written), "species_lines": lines,

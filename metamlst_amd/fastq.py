@@ -176,6 +176,36 @@ def _pread_into(fd: int, buf: np.ndarray, lo: int, hi: int) -> None:
         list(_reader_pool().map(piece, starts))
 
 
+def raw_chunks(path: str, chunk_bytes: int = 256 << 20, lo: int = 0, hi: int | None = None, margin: int = 1 << 17,
+               reuse: bool = False, ring: list | None = None):
+    """Bytes [lo, hi) of a file in pieces of chunk_bytes, cut anywhere: yields (buf, n) with the piece at buf[margin:margin + n]
+    and `margin` free bytes in front of it -- room for what the consumer carries over from the piece before (the cut-off BGZF
+    block of Engine.submit_fastq_bgzf_file).  Positional reads by a few threads; reuse / ring as in text_chunks."""
+    size = os.path.getsize(path)
+    hi = size if hi is None else min(hi, size)
+    if ring is None:
+        ring = []
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        at = lo
+        while at < hi:
+            n = min(chunk_bytes, hi - at)
+            if reuse and len(ring) >= 4:
+                buf = ring.pop(0)
+                if buf.size < margin + n:
+                    _give_buffer(buf)
+                    buf = _take_buffer(margin + n)
+            else:
+                buf = _take_buffer(margin + n) if reuse else np.empty(margin + n, np.uint8)
+            if reuse:
+                ring.append(buf)
+            _pread_into(fd, buf[margin:], at, at + n)
+            at += n
+            yield buf, n
+    finally:
+        os.close(fd)
+
+
 def release_buffers(ring: list) -> None:
     """The consumer is done with every chunk of a text_chunks(reuse=True, ring=ring) walk: its buffers may serve the next file."""
     while ring:

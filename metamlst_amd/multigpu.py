@@ -217,7 +217,7 @@ def type_many_samples(engines, idx, database, targs, samples: list[list[str]], r
     rank 0 gathers the .nfo lines (and --log tables) and writes them, sample by sample in the order given: byte for
     byte what one run per sample writes."""
     import time
-    from .cli import open_sample_reader, submit_sample_files
+    from .cli import submit_sample_files
     from .pipeline import TypingPipeline
     from .typing import log_table, sample_name, type_sample
     t_begin = time.perf_counter()
@@ -227,24 +227,16 @@ def type_many_samples(engines, idx, database, targs, samples: list[list[str]], r
     sizes = [sum(os.path.getsize(f) for f in files) for files in samples]
     owner = deal_samples(sizes, world)
     jobs = [(i, files) for i, files in enumerate(samples) if owner[i] == rank]
-    pipe = TypingPipeline(engines if isinstance(engines, (list, tuple)) else [engines], penalty=targs.penalty)
+    pipe = TypingPipeline(engines if isinstance(engines, (list, tuple)) else [engines], penalty=targs.penalty, feed_threads=True)
     parts = int(os.environ.get("MLST_CU_PARTITIONS", "0")) or TypingPipeline.default_partitions(pipe.depth)
     if parts > 1:
         pipe.place(parts)
         pipe.stagger_s = 0.75e-3
 
-    # the reader thread of the sample after the one being fed is started first: its file is read while this one crosses the link
-    readers: dict = {}
-    order = [j[0] for j in jobs]
-    nxt_of = {a: b for a, b in zip(order[:-1], order[1:])}
-    files_of = dict(jobs)
-
+    # every engine is fed by a thread of its own (pipeline.feed_threads): the file reads, the copies and -- for bgzip'd files --
+    # the inflate the library waits for overlap across the engines instead of holding up the loop one after the other
     def feed(e, job):
-        i = job[0]
-        mine_r = readers.pop(i, None) or open_sample_reader(job[1], False, chunk_bytes)
-        if i in nxt_of:
-            readers[nxt_of[i]] = open_sample_reader(files_of[nxt_of[i]], False, chunk_bytes)
-        submit_sample_files(e, job[1], False, chunk_bytes, first_reader=mine_r)
+        submit_sample_files(e, job[1], False, chunk_bytes)
 
     # The per-allele table (metamlst.py:133-151 over every allele with a hit: `cel`) is display -- the closest-allele listing of
     # metamlst.py:213-230 and the --log table; the .nfo line needs the device's choice and consensus only.  A quiet run
@@ -263,6 +255,7 @@ def type_many_samples(engines, idx, database, targs, samples: list[list[str]], r
 
     t_run = time.perf_counter()
     mine = pipe.run(jobs, feed, tail, per_allele=show or log)
+    pipe.stop_feeders()
     if timing is not None:      # (what a run pays once -- database look-up tables, CU shares -- and what it pays per sample)
         timing["prologue_s"] = t_run - t_begin
         timing["samples_s"] = time.perf_counter() - t_run

@@ -35,10 +35,14 @@ class TypingPipeline:
     stagger_s   -- the first submissions go out this far apart when the engines have their own CU shares: started in the
                    same instant the launch sequences stay in step for a round or two (all in k_route, then all in
                    k_route_probe ...); 0.5-1 ms apart they mix from the start.
+    feed_threads-- feed(engine, job) + typing_enqueue of every engine run on a thread of their own (one per engine).  For
+                   feeds that BLOCK -- file reads, host-to-device copies that wait, the inflate of a bgzip'd file, which the
+                   library waits for -- so that the engines' inputs overlap; resident batches (bench.py) are queued in
+                   ~40 us and stay on the caller's thread.  Ignored with `shards` (collectives are issued in one order).
     """
 
     def __init__(self, engines: list, penalty: int = 100, mincov: int = 1, none_char: str = "N", shards: list | None = None,
-                 stagger_s: float = 0.0):
+                 stagger_s: float = 0.0, feed_threads: bool = False):
         if not engines:
             raise ValueError("a pipeline needs at least one engine")
         self.engines = list(engines)
@@ -46,6 +50,9 @@ class TypingPipeline:
         self.penalty, self.mincov, self.none_char = penalty, mincov, none_char
         self.shards = shards
         self.stagger_s = stagger_s
+        self.feed_threads = bool(feed_threads) and shards is None
+        self._pool = None
+        self._pending: dict = {}
         self.partitions = 1
         self.host_ms = {"submit": 0.0, "wait_device": 0.0, "tail": 0.0}
 
@@ -69,10 +76,24 @@ class TypingPipeline:
         e = self.engines[k % self.depth]
         if self.shards is not None:
             self.shards[k % self.depth].enqueue(lambda: self._pass1(e, job, feed), penalty=self.penalty)
+        elif self.feed_threads:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(self.depth, thread_name_prefix="feed")
+            self._pending[k % self.depth] = self._pool.submit(self._feed_and_enqueue, e, job, feed)
         else:
-            self._pass1(e, job, feed)
-            e.typing_enqueue(penalty=self.penalty, mincov=self.mincov, none_char=self.none_char)
+            self._feed_and_enqueue(e, job, feed)
         self.host_ms["submit"] += (time.perf_counter() - t0) * 1e3
+
+    def _feed_and_enqueue(self, e, job, feed: Callable) -> None:
+        self._pass1(e, job, feed)
+        e.typing_enqueue(penalty=self.penalty, mincov=self.mincov, none_char=self.none_char)
+
+    def _fed(self, slot: int) -> None:
+        """the engine of this slot has its sample queued (a feeder thread's exception surfaces here)"""
+        fut = self._pending.pop(slot, None)
+        if fut is not None:
+            fut.result()
 
     @staticmethod
     def _pass1(e, job, feed: Callable) -> None:
@@ -112,6 +133,7 @@ class TypingPipeline:
             else:
                 # wait, queue the engine's next sample, THEN copy the finished one's results out of their pinned slot: on its
                 # own share of the CUs an engine idles from the end of a sample to the submission of the next
+                self._fed(kk % self.depth)
                 e.typing_wait()
                 self.host_ms["wait_device"] += (time.perf_counter() - t0) * 1e3
                 nxt = next(it, _END)
@@ -126,10 +148,19 @@ class TypingPipeline:
         return results
 
     def synchronize(self) -> None:
+        for slot in list(self._pending):
+            self._fed(slot)
         for e in self.engines:
             e.synchronize()
 
+    def stop_feeders(self) -> None:
+        """end the feeder threads (the engines stay as they are)"""
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
     def close(self) -> None:
+        self.stop_feeders()
         for e in self.engines:
             e.close()
 

@@ -80,5 +80,17 @@ def test_eight_samples_through_the_pipeline_equal_eight_serial_runs():
         # fewer samples than engines, and none
         assert len(pipe.run(range(2), feed, tail)) == 2
         assert pipe.run([], feed, tail) == []
+        # every engine fed by a thread of its own (what the folder mode does: feeds that block overlap): the same lines, and a
+        # feeder's exception surfaces in the loop
+        pipe.feed_threads = True
+        got = pipe.run(range(len(samples)), feed, tail, per_allele=True)
+        assert [(g[1], g[2]) for g in got] == want
+
+        def bad_feed(e, job):
+            if job == 3:
+                raise ValueError("sample 3 cannot be read")
+            feed(e, job)
+        with pytest.raises(ValueError, match="sample 3"):
+            pipe.run(range(len(samples)), bad_feed, tail)
         pipe.close()
         database.closeConnection()
