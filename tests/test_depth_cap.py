@@ -165,3 +165,60 @@ def test_capped_typing_tail_on_the_device():
         for a in ch:
             assert letters[a].decode() == "".join(consensus_from_counts(want[a])), (cap, a)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_cli_depth_cap_writes_the_nfo_line_of_the_capped_oracle_pileup(tmp_path):
+    """`cli type SAMPLE --depth-cap N` (one sample, and a folder of two through the pipelined loop): the .nfo line is the one
+    the host statement of metamlst.py:133-289 writes over the ORACLE's capped pile-up; without the switch, over the plain one;
+    and the two differ on this sample (the cap drops mismatching late reads from deep columns)."""
+    import subprocess
+    import sys
+    from metamlst_amd import db as mdb
+    from metamlst_amd.typing import TypingArgs, type_sample
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    db, idx = fx.ecoli_small(40)
+    # a novel allele: SNPs planted in the genome at columns the reads cover deeply; half of the reads of the sample come first
+    # WITHOUT them (another isolate's reads), so what the first N records of a column say differs from what all of them say
+    g0, starts = synth.make_genome(db, "ecoli", db.profiles["ecoli"][2], size=90_000)
+    gene = db.loci["ecoli"][0][0]
+    seq = synth.allele_sequence(db.path, "ecoli", gene, int(db.profiles["ecoli"][2][0]))
+    muts = [(p, "A" if seq[p] != "A" else "C") for p in (60, 200, 333)]
+    g1, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][2], size=90_000, mutate={gene: muts})
+    b0, q0 = synth.sample_reads(g0, 1500, seed=5, err_rate=0.0)      # 2.5x: the first records of every column
+    b1, q1 = synth.sample_reads(g1, 9000, seed=6, err_rate=0.0)      # 15x: the majority
+    bases, quals = np.concatenate([b0, b1]), np.concatenate([q0, q1])
+    fq = tmp_path / "s.fastq"
+    with open(fq, "wb") as f:
+        for k in range(len(bases)):
+            f.write(b"@r%d\n" % k + bases[k].tobytes() + b"\n+\n" + quals[k].tobytes() + b"\n")
+    fb, fq_q, off = synth.flatten_reads(bases, quals)
+    orc = oracle_lib.Oracle(idx)
+    orc.submit_reads(fb, fq_q, off)
+    database = mdb.metaMLST_db(db.path)
+    want = {}
+    for cap in (0, 2):
+        res = type_sample(idx, orc.stats(), lambda ch, cap=cap: orc.pileup(ch, depth_cap=cap), database, "s", TypingArgs(), out_dir=None)
+        want[cap] = "".join(r.nfo_line for r in res if r.written)
+        assert want[cap].count("\r\n") == 1
+    assert want[0] != want[2]
+    env = dict(os.environ)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+
+    def cli(args):
+        r = subprocess.run([sys.executable, "-m", "metamlst_amd.cli"] + args, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+    for cap in (0, 2):
+        out = tmp_path / ("out%d" % cap)
+        cli(["type", str(fq), "-d", db.path, "-o", str(out), "--quiet"] + (["--depth-cap", str(cap)] if cap else []))
+        assert open(out / "s.nfo", newline="").read() == want[cap], cap
+    folder = tmp_path / "reads"
+    folder.mkdir()
+    for name in ("a", "b"):
+        (folder / (name + ".fastq")).write_bytes(fq.read_bytes())
+    out = tmp_path / "outf"
+    cli(["type", str(folder), "-d", db.path, "-o", str(out), "--quiet", "--depth-cap", "2"])
+    for name in ("a", "b"):
+        assert open(out / (name + ".nfo"), newline="").read() == want[2].replace("\ts\t", "\t%s\t" % name)
+    database.closeConnection()

@@ -278,3 +278,19 @@ def test_read_ahead_of_the_next_sample_never_writes_into_chunks_still_in_the_con
             got.append(bytes(view))
         mine.close()
         assert b"".join(got) == open(path, "rb").read(), k
+
+
+def test_raw_chunks_leave_a_margin_in_front_of_every_piece(tmp_path):
+    """fastq.raw_chunks (the reader of bgzip'd files): pieces cut anywhere, each behind `margin` free bytes of its buffer."""
+    from metamlst_amd import fastq
+    p = tmp_path / "x.bin"
+    data = np.random.default_rng(3).integers(0, 256, 300_001, dtype=np.uint8).tobytes()
+    p.write_bytes(data)
+    for lo, hi in ((0, None), (1234, 250_000), (299_990, None), (5, 5)):
+        got, ring = [], []
+        for buf, n in fastq.prefetch(fastq.raw_chunks(str(p), 70_000, lo, hi, margin=4096, reuse=True, ring=ring)):
+            assert buf.size >= 4096 + n and 0 < n <= 70_000
+            buf[4096 - 7:4096] = 1                                           # the consumer writes its carry in front: that is what the margin is for
+            got.append(bytes(buf[4096:4096 + n]))
+        fastq.release_buffers(ring)
+        assert b"".join(got) == data[lo:hi]
