@@ -23,6 +23,14 @@ enum { OK = 0, E_INPUT = -1, E_BLOCKTYPE = -2, E_STORED = -3, E_LENGTHS = -4, E_
 struct Bits {
     const uint8_t* in; uint64_t n, pos;
     uint64_t buf; int cnt;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one lane per stream (inflate_lane.h): a 256-byte window of the stream in LDS, refilled 256 bytes at a time by sixteen
+    // independent 16-byte loads (one memory round trip per ~100 symbols instead of one per three)
+    __attribute__((address_space(3))) uint64_t* win;      // (an LDS pointer by type: a generic one makes every read a FLAT load, which waits for the lane's outstanding global stores)
+                                 // element j of this lane's window at win[j * 64] (lane-interleaved); nullptr: no window
+    const uint8_t* win_at;       // the 16-byte aligned address the window starts at
+    const uint8_t* buf_end;      // end of the (padded) compressed buffer: no load reaches beyond it
+#endif
 };
 // n <= 16 bits, least significant bit first.  Refills take eight bytes with one batch of independent loads (a thread of
 // k_inflate waits a full memory latency for every dependent load): the bytes are ORed in above the cnt valid bits, the
@@ -31,7 +39,44 @@ struct Bits {
 MLST_HD inline void refill(Bits& b) {
     if (b.pos + 8 <= b.n) {
         uint64_t w = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (device: eight byte loads per lane are 512 requests per wave; the eight bytes as two aligned 8-byte words and a funnel
+        // shift.  The second word may lie up to 7 bytes behind the stream: the engine's compressed buffers end with 16 bytes of
+        // padding.)
+        const uint8_t* p = b.in + b.pos;
+        uint64_t w0, w1; unsigned sh;
+        if (b.win) {
+            const bool need = p + 16 > b.win_at + 256 || p < b.win_at;
+            if (__ballot(need)) {                      // every lane that is here moves its window up: the waits coincide
+                const uint8_t* a0 = p - ((uintptr_t)p & 15u);
+                typedef unsigned int v4 __attribute__((ext_vector_type(4)));
+                v4 v[16];
+                #pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const uint8_t* a = a0 + 16 * j;
+                    if (a + 16 > b.buf_end) a = b.buf_end - 16;      // (behind the buffer: bytes no code of the stream reaches)
+                    v[j] = *reinterpret_cast<const v4*>(a);
+                }
+                #pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    b.win[(2 * j) * 64] = (uint64_t)v[j].x | ((uint64_t)v[j].y << 32);
+                    b.win[(2 * j + 1) * 64] = (uint64_t)v[j].z | ((uint64_t)v[j].w << 32);
+                }
+                b.win_at = a0;
+            }
+            const unsigned o = (unsigned)(p - b.win_at);
+            w0 = b.win[(o >> 3) * 64]; w1 = b.win[((o >> 3) + 1) * 64];
+            sh = (o & 7u) * 8u;
+        } else {
+            const uint64_t a = (uint64_t)(uintptr_t)p;
+            const uint64_t* p8 = reinterpret_cast<const uint64_t*>(p - (a & 7u));
+            sh = (unsigned)(a & 7u) * 8u;
+            w0 = p8[0]; w1 = p8[1];
+        }
+        w = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+#else
         for (int k = 0; k < 8; k++) w |= (uint64_t)b.in[b.pos + k] << (8 * k);
+#endif
         b.buf |= w << b.cnt;
         b.pos += (uint64_t)((63 - b.cnt) >> 3);
         b.cnt |= 56;
@@ -147,9 +192,16 @@ MLST_HD inline int codes(Bits& b, const Huff& lc, const HuffD& dc, Out& o, uint6
 
 // one raw deflate stream -> at most cap bytes through o (o.op = bytes written, also after an error).  Whether the stream
 // filled what the caller expected is the caller's check (ISIZE of the BGZF block).
-template <typename Out>
-MLST_HD inline int inflate_stream(const uint8_t* in, uint64_t n_in, Out& o, uint64_t cap, Tables* tb) {
+// OWN_CODES: the output policy brings its own symbol loop (Out::codes, same contract as codes() above) -- inflate_lane.h's
+// loop for one lane per stream, laid out so that the lanes of a wave walk few different paths
+template <typename Out, bool OWN_CODES = false>
+MLST_HD inline int inflate_stream(const uint8_t* in, uint64_t n_in, Out& o, uint64_t cap, Tables* tb, uint64_t* dev_win = nullptr, const uint8_t* dev_buf_end = nullptr) {
     Bits b; b.in = in; b.n = n_in; b.pos = 0; b.buf = 0; b.cnt = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b.win = (__attribute__((address_space(3))) uint64_t*)dev_win; b.win_at = nullptr; b.buf_end = dev_buf_end;
+#else
+    (void)dev_win; (void)dev_buf_end;
+#endif
     uint64_t& op = o.op;
     Huff& lc = tb->lc; HuffD& dc = tb->dc;
     uint16_t lengths[320];
@@ -174,7 +226,7 @@ MLST_HD inline int inflate_stream(const uint8_t* in, uint64_t n_in, Out& o, uint
             build(lc, lengths, 288);
             for (int s = 0; s < 30; s++) lengths[s] = 5;
             build(dc, lengths, 30);
-            rc = codes(b, lc, dc, o, cap);
+            if constexpr (OWN_CODES) rc = Out::codes(b, lc, dc, o, cap); else rc = codes(b, lc, dc, o, cap);
             if (rc != OK) return rc;
         } else if (type == 2) {
             const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -208,7 +260,7 @@ MLST_HD inline int inflate_stream(const uint8_t* in, uint64_t n_in, Out& o, uint
             if (e < 0 || (e > 0 && nlen != (uint32_t)(lc.count[0] + lc.count[1]))) return E_LENGTHS;
             e = build(dc, lengths + nlen, (int)ndist);
             if (e < 0 || (e > 0 && ndist != (uint32_t)(dc.count[0] + dc.count[1]))) return E_LENGTHS;
-            rc = codes(b, lc, dc, o, cap);
+            if constexpr (OWN_CODES) rc = Out::codes(b, lc, dc, o, cap); else rc = codes(b, lc, dc, o, cap);
             if (rc != OK) return rc;
         } else return E_BLOCKTYPE;
         if (last) break;

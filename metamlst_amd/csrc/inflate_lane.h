@@ -1,0 +1,281 @@
+// inflate_lane.h -- DEFLATE on the GPU in two kernels (device code only; round 4).
+//
+// inflate_wave.h decodes ONE stream per wave: 134 instructions per Huffman symbol of which 63 of 64 lanes repeat the first
+// lane's arithmetic, and the kernel is bound by instruction issue (profiles/round4/inflate.md: 85 cycles per symbol and CU).
+// The chain of a deflate stream is in its BITS -- where a code starts depends on every code before it -- not in its
+// bytes: what a match copies does not decide where the next code starts.  So the two are taken apart:
+//
+//   phase 1  k_inflate_tok   one LANE per BGZF block: the serial decoder of inflate_dev.h (the one the host tests run
+//            against zlib), its tables in LDS (1.3 KB per lane), emits one 32-bit TOKEN per symbol -- a literal, a match
+//            (length, distance) or a stored run -- and copies nothing.  Every vector instruction advances 64 streams.
+//   phase 2  k_inflate_ptr   one 1,024-thread workgroup per block: the tokens' output offsets by a prefix sum, then every
+//            byte of the block gets a 16-bit POINTER in LDS (128 KB): a literal points at itself, byte k of a match at the
+//            byte `distance` before it.  Pointer jumping (ptr[p] = ptr[ptr[p]], in place, until nothing moves: the
+//            depth of the longest chain halves per round) turns every pointer into the position of the literal the byte
+//            comes from, and one gather writes the block.  No byte waits for another one's store; nothing leaves the LDS
+//            between the fill and the gather.
+//
+// A block whose tokens do not fit its share of the token buffer (more than TOK_CAP symbols: data that hardly compresses) is
+// flagged and left to inflate_wave.h's kernel.  Errors: the codes of inflate_dev.h; every loop is bounded as there.
+#pragma once
+#include "inflate_dev.h"
+
+namespace inflate_lane {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+struct Blk { u64 in_off, out_off; u32 in_len, out_len; };      // one BGZF block: its deflate stream in the compressed buffer, its text in the output
+enum : u32 { TAG_LIT = 0u, TAG_RAW = 1u, TAG_MATCH = 2u, TAG_OPERAND = 3u, TOK_OVERFLOW = 0xFFFFFFFFu };
+// token (tag in bits 30-31): literal = the byte; match = (length - 3) << 16 | (distance - 1); stored run = its length (16 bits),
+// followed by an OPERAND word: where the run starts, in bytes from the start of the block's deflate stream
+
+#if defined(__HIP_DEVICE_COMPILE__)
+struct OutTok;
+__device__ inline int codes_simt(mlst_inflate::Bits& b, const mlst_inflate::Huff& lc, const mlst_inflate::HuffD& dc, OutTok& o, uint64_t cap);
+struct OutTok {
+    u32* tok; u32 nt, cap; uint64_t op; const u8* in_base; bool over;
+    __device__ static int codes(mlst_inflate::Bits& b, const mlst_inflate::Huff& lc, const mlst_inflate::HuffD& dc, OutTok& o, uint64_t cap) { return codes_simt(b, lc, dc, o, cap); }
+    __device__ __attribute__((always_inline)) void emit(u32 t) { if (nt < cap) tok[nt] = t; else over = true; nt++; }
+    __device__ __attribute__((always_inline)) void put(u8 c) { emit((u32)c); op++; }
+    __device__ __attribute__((always_inline)) void copy(u32 dist, u32 len) { emit((TAG_MATCH << 30) | ((len - 3u) << 16) | (dist - 1u)); op += len; }
+    __device__ __attribute__((always_inline)) void raw(const u8* src, u32 len) {
+        if (len == 0) return;
+        emit((TAG_RAW << 30) | len); emit((TAG_OPERAND << 30) | (u32)(src - in_base)); op += len;      // (len <= 65535: LEN is a 16-bit field)
+    }
+};
+
+// The symbol loop for one lane per stream.  inflate_dev.h's codes() is written for one thread: a literal, a match, a long code,
+// a refill are branches, and 64 lanes that each take their own walk all of them one after the other (measured: 1,057
+// instructions per step of the wave, 4.6 cycles each with one wave per SIMD).  Here a step is one straight line that every
+// lane walks: refill when fewer than 48 bits are left (a symbol takes at most 15 + 5 + 15 + 13), look the literal / length code
+// up, and -- only the lanes whose code is longer than the table's 8 bits -- find it by the canonical walk over lengths 9..15
+// on the bit-reversed window (no bit-by-bit loop); a literal's token leaves, the match lanes go on through length extra bits,
+// distance code and distance extra bits, all cut from the same 64-bit buffer without another refill.
+// (Branches cost a wave twice: the lanes that do not take one wait, and every divergent `if` is a saved and restored execution
+// mask -- the first version of this loop, with the serial decoder's early returns, spent 290 scalar instructions per step on
+// them.  So: errors are a sticky per-lane code looked at once per step, the canonical walk has a fixed trip count and selects
+// its hit, and what is left are four `if`s: refill, long literal / length code, match, long distance code.)
+template <int FROM>
+__device__ __attribute__((always_inline)) inline int long_code(const uint16_t* count, const uint16_t* symbol, u32 first, u32 index, u32 rev15, int& len_out) {
+    // rev15: the next 15 stream bits, first bit most significant (canonical codes are sent most significant bit first)
+    int found_l = 0; u32 found = 0;
+    #pragma unroll
+    for (int l = FROM; l <= 15; l++) {
+        const u32 code = rev15 >> (15 - l), c = count[l];
+        const bool hit = found_l == 0 && code - first < c;
+        found = hit ? index + (code - first) : found; found_l = hit ? l : found_l;
+        index += c; first = (first + c) << 1;
+    }
+    len_out = found_l;
+    return found_l ? (int)symbol[found] : (int)mlst_inflate::E_SYMBOL;
+}
+__device__ inline int codes_simt(mlst_inflate::Bits& b, const mlst_inflate::Huff& lc, const mlst_inflate::HuffD& dc, OutTok& o, uint64_t cap) {
+    using namespace mlst_inflate;
+    // where the canonical walks start behind the tables' bits: first code and symbol index of length LB + 1
+    u32 lf = 0, li = 0, df = 0, di = 0;
+    for (int l = 1; l <= Huff::LB; l++) { const u32 c = lc.count[l]; li += c; lf = (lf + c) << 1; }
+    for (int l = 1; l <= HuffD::LB; l++) { const u32 c = dc.count[l]; di += c; df = (df + c) << 1; }
+    u32 op = (u32)o.op; const u32 cap32 = (u32)cap;          // (a block holds at most 65,536 bytes: 32-bit arithmetic on the path)
+    int err = OK;
+    for (;;) {
+        if (b.cnt < 48) refill(b);
+        const u32 lo = (u32)b.buf;
+        const u32 e = lc.lut[lo & ((1u << Huff::LB) - 1u)];
+        int sym = (int)(e >> Huff::SH), l = (int)(e & ((1u << Huff::SH) - 1u));
+        if (e == 0) {
+            sym = long_code<Huff::LB + 1>(lc.count, lc.symbol, lf, li, __brev(lo) >> 17, l);
+            err = sym < 0 ? sym : err; sym = sym < 0 ? 256 : sym;
+        }
+        err = l > b.cnt ? (int)E_INPUT : err;
+        b.buf >>= l; b.cnt -= l;
+        u32 token = (u32)sym, n_out = 1;
+        if (sym > 256) {
+            int ls = sym - 257;
+            err = ls >= 29 ? (int)E_SYMBOL : err; ls = ls >= 29 ? 0 : ls;
+            const int le = ls < 8 || ls == 28 ? 0 : (ls - 4) >> 2;
+            const u32 lb = ls < 8 ? 3u + (u32)ls : (ls == 28 ? 258u : ((4u + ((u32)ls & 3u)) << le) + 3u);
+            const u32 len = lb + ((u32)b.buf & ((1u << le) - 1u));
+            b.buf >>= le; b.cnt -= le;
+            const u32 lo2 = (u32)b.buf;
+            const u32 ed = dc.lut[lo2 & ((1u << HuffD::LB) - 1u)];
+            int ds = (int)(ed >> HuffD::SH), dl = (int)(ed & ((1u << HuffD::SH) - 1u));
+            if (ed == 0) {
+                ds = long_code<HuffD::LB + 1>(dc.count, dc.symbol, df, di, __brev(lo2) >> 17, dl);
+                err = ds < 0 ? ds : err; ds = ds < 0 ? 0 : ds;
+            }
+            b.buf >>= dl; b.cnt -= dl;
+            err = ds >= 30 ? (int)E_SYMBOL : err; ds = ds >= 30 ? 0 : ds;
+            const int de = ds < 4 ? 0 : (ds - 2) >> 1;
+            const u32 db = ds < 4 ? 1u + (u32)ds : ((2u + ((u32)ds & 1u)) << de) + 1u;
+            const u32 dist = db + ((u32)b.buf & ((1u << de) - 1u));
+            b.buf >>= de; b.cnt -= de;
+            err = b.cnt < 0 ? (int)E_INPUT : err;                       // (the three fields were cut without a look at the count)
+            err = dist > op ? (int)E_DISTANCE : err;
+            token = (TAG_MATCH << 30) | ((len - 3u) << 16) | (dist - 1u); n_out = len;
+        }
+        if (sym == 256 || err != OK) break;
+        if (op + n_out > cap32) { err = E_OUTPUT; break; }
+        o.emit(token); op += n_out;
+    }
+    o.op = op;
+    return err;
+}
+
+// ---- phase 1: lane = block
+__device__ __attribute__((always_inline)) inline void tok_body(const u8* comp, const u8* comp_end, const Blk* blk, u32 n_blk, u32 err_base,
+                                                               u32* tok, u32 tok_cap, u32* n_tok, u32* err, mlst_inflate::Tables* tabs, unsigned long* win) {
+    const u32 lane = threadIdx.x & 63u;
+    for (u32 i0 = blockIdx.x * 64u; i0 < n_blk; i0 += gridDim.x * 64u) {
+        const u32 i = i0 + lane;
+        if (i >= n_blk) continue;
+        const Blk B = blk[i];
+        const u32 want = B.out_len;
+        OutTok o; o.tok = tok + (u64)i * tok_cap; o.nt = 0; o.cap = tok_cap; o.op = 0; o.in_base = comp + B.in_off; o.over = false;
+        int rc = mlst_inflate::inflate_stream<OutTok, true>(comp + B.in_off, (u64)B.in_len, o, (u64)want, &tabs[lane], win + lane, comp_end);
+        if (rc == mlst_inflate::OK && o.op != (u64)want) rc = mlst_inflate::E_SHORT;
+        if (rc != mlst_inflate::OK) { if (atomicCAS(&err[0], 0u, err_base + i + 1u) == 0u) err[1] = (u32)(-rc); n_tok[i] = 0; }
+        else n_tok[i] = o.over ? (u32)TOK_OVERFLOW : o.nt;
+    }
+}
+
+// ---- phase 2: workgroup = block.  LDS: ptr[65536] (128 KB) + the scan's partial sums.
+__device__ __attribute__((always_inline)) inline u32 wave_incl_scan(u32 v) {
+    #pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 y = (u32)__shfl_up((int)v, o); if ((int)(threadIdx.x & 63u) >= o) v += y; }
+    return v;
+}
+template <int NT>      // NT = threads per workgroup (a multiple of 64, at most 1024)
+__device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, const Blk* blk, u32 n_blk, u32 err_base,
+                                                               const u32* tok, u32 tok_cap, const u32* n_tok, u8* out, u32* err,
+                                                               u16* ptr, u32* s_part, u32* s_flag) {
+    constexpr int NW = NT / 64;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (u32 b = blockIdx.x; b < n_blk; b += gridDim.x) {
+        const u32 nt = n_tok[b];
+        if (nt == (u32)TOK_OVERFLOW || nt == 0) continue;              // block-uniform (left to the other kernel / failed in phase 1)
+        const u32* T = tok + (u64)b * tok_cap;
+        const Blk B = blk[b];
+        u8* O = out + B.out_off;
+        const u8* I = comp + B.in_off;
+        const u32 total = B.out_len;
+#if defined(MLST_PTR_TRACE)      // profiling builds: cycles per phase, summed over the blocks, in err[2..5] (fill, jumping, gather, rounds)
+        const unsigned long long tr0 = __builtin_readcyclecounter();
+#endif
+        // ---- fill: tiles of NT tokens, their output offsets by a scan, pointers (and literal bytes) written per token
+        u32 base = 0;
+        u32 t_next = tid < nt ? T[tid] : 0u;                             // (the next tile's tokens are on their way while this one is worked on)
+        for (u32 t0 = 0; t0 < nt; t0 += NT) {
+            const u32 ti = t0 + tid;
+            u32 t = 0, len = 0, tag = TAG_OPERAND;
+            const u32 t_cur = t_next;
+            t_next = ti + NT < nt ? T[ti + NT] : 0u;
+            if (ti < nt) {
+                t = t_cur; tag = t >> 30;
+                len = tag == TAG_MATCH ? ((t >> 16) & 0xFFu) + 3u : (tag == TAG_RAW ? (t & 0xFFFFu) : (tag == TAG_LIT ? 1u : 0u));
+            }
+            const u32 inc = wave_incl_scan(len);
+            if (lane == 63) s_part[wave] = inc;
+            __syncthreads();
+            u32 before = base;
+            for (u32 w = 0; w < wave; w++) before += s_part[w];
+            u32 tile_total = 0;
+            for (u32 w = 0; w < (u32)NW; w++) tile_total += s_part[w];
+            const u32 dst = before + inc - len;
+            // per token: the first bytes by its own lane, the rest of a long one by the whole wave
+            u32 done = 0;
+            if (len && dst + len <= total) {
+                if (tag == TAG_MATCH) {
+                    const u32 dist = (t & 0x7FFFu) + 1u;
+                    const u32 n0 = len < 32u ? len : 32u;      // (longer ones -- quality runs -- are finished by the whole wave below)
+                    if (dist > dst) { done = len; if (atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_DISTANCE); }
+                    else { for (u32 k = 0; k < n0; k++) ptr[dst + k] = (u16)(dst + k - dist); done = n0; }
+                } else if (tag == TAG_LIT) { ptr[dst] = (u16)dst; O[dst] = (u8)t; done = 1; }
+            } else if (len) { done = len; if (atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_OUTPUT); }
+            const u32 nxt = (tag == TAG_RAW && ti + 1 < nt) ? T[ti + 1] : 0u;      // (the operand of a stored run)
+            u64 todo = __ballot(done < len);
+            while (todo) {
+                const int k = __ffsll((long long)todo) - 1; todo &= todo - 1;
+                const u32 tt = (u32)__shfl((int)t, k), tl = (u32)__shfl((int)len, k), td = (u32)__shfl((int)dst, k), t_done = (u32)__shfl((int)done, k);
+                const u32 t_nxt = (u32)__shfl((int)nxt, k);
+                if ((tt >> 30) == TAG_MATCH) {
+                    const u32 dist = (tt & 0x7FFFu) + 1u;
+                    for (u32 j = t_done + lane; j < tl; j += 64) ptr[td + j] = (u16)(td + j - dist);
+                } else {      // stored run: its bytes straight from the compressed buffer
+                    const u32 src = t_nxt & 0x3FFFFFFFu;
+                    if ((t_nxt >> 30) == TAG_OPERAND && (u64)src + tl <= (u64)B.in_len)
+                        for (u32 j = lane; j < tl; j += 64) { ptr[td + j] = (u16)(td + j); O[td + j] = I[src + j]; }
+                    else if (lane == 0 && atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_STORED);
+                }
+            }
+            base += tile_total;
+            __syncthreads();
+        }
+        if (base != total) { if (tid == 0 && atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_SHORT); __syncthreads(); continue; }
+        // ---- pointer jumping: every pointer ends at a literal (a byte that points at itself).  Thread t owns the byte PAIRS
+        // 2 (t + NT j) (one 32-bit read and write for two pointers; only their targets are read one by one); `live` has a bit per
+        // j whose pointers are not both known to rest on a literal yet: a pair drops out as soon as they do.  (The quality lines of a
+        // FASTQ block copy each other record after record: half the bytes of a block sit ~200 links deep and stay for 8-9 rounds.)
+#if defined(MLST_PTR_TRACE)
+        const unsigned long long tr1 = __builtin_readcyclecounter(); int tr_rounds = 0;
+#endif
+        u32* const ptr2 = reinterpret_cast<u32*>(ptr);
+        const u32 n_pairs = (total + 1u) >> 1;
+        if ((total & 1u) && tid == 0) ptr[total] = (u16)total;          // (the odd block's last pair: its second half points at itself)
+        __syncthreads();
+        u32 live = 0;
+        for (u32 j = 0; tid + j * NT < n_pairs; j++) live |= 1u << j;
+        for (int round = 0; round < 17; round++) {
+            u32 next = 0;
+            for (u32 m = live; __ballot(m != 0); ) {                    // (every lane walks its own set bits, four pairs at a time: their LDS reads are independent)
+                u32 pj[4], w[4], r0[4], r1[4]; bool on[4];
+                #pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    on[k] = m != 0;
+                    pj[k] = on[k] ? (u32)__ffs((int)m) - 1u : 0u;
+                    m &= m - 1;
+                }
+                #pragma unroll
+                for (int k = 0; k < 4; k++) w[k] = on[k] ? ptr2[tid + pj[k] * NT] : 0u;
+                #pragma unroll
+                for (int k = 0; k < 4; k++) { r0[k] = ptr[w[k] & 0xFFFFu]; r1[k] = ptr[w[k] >> 16]; }
+                #pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const u32 q0 = w[k] & 0xFFFFu, q1 = w[k] >> 16;
+                    // (a pointer whose target is a literal -- or that is one -- has arrived: r == q)
+                    if (on[k] && (r0[k] != q0 || r1[k] != q1)) { ptr2[tid + pj[k] * NT] = r0[k] | (r1[k] << 16); next |= 1u << pj[k]; }
+                }
+            }
+            live = next;
+            const int any = __syncthreads_or(live != 0);
+#if defined(MLST_PTR_TRACE)
+            tr_rounds++;
+#endif
+            if (!any) break;
+        }
+#if defined(MLST_PTR_TRACE)
+        const unsigned long long tr2 = __builtin_readcyclecounter();
+#endif
+        // ---- gather (the literal bytes were stored in the fill phase: visible to the workgroup behind the barriers above),
+        // eight independent loads in flight per thread
+        for (u32 j0 = 0; tid + j0 * NT < total; j0 += 8) {
+            u32 q[8]; u8 v[8];
+            #pragma unroll
+            for (int k = 0; k < 8; k++) { const u32 p = tid + (j0 + k) * NT; q[k] = p < total ? ptr[p] : 0u; }
+            #pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = O[q[k]];
+            #pragma unroll
+            for (int k = 0; k < 8; k++) { const u32 p = tid + (j0 + k) * NT; if (p < total && q[k] != p) O[p] = v[k]; }
+        }
+        __syncthreads();
+#if defined(MLST_PTR_TRACE)
+        if (tid == 0) { const unsigned long long tr3 = __builtin_readcyclecounter();
+                        atomicAdd(&err[2], (u32)((tr1 - tr0) >> 6)); atomicAdd(&err[3], (u32)((tr2 - tr1) >> 6)); atomicAdd(&err[4], (u32)((tr3 - tr2) >> 6)); atomicAdd(&err[5], (u32)tr_rounds); }
+#endif
+    }
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+}  // namespace inflate_lane

@@ -30,6 +30,7 @@
 #include "mlst_debug.h"
 #include "inflate_dev.h"
 #include "inflate_wave.h"
+#include "inflate_lane.h"
 #include "mlst_policy.h"
 
 typedef unsigned long long u64;
@@ -1139,19 +1140,22 @@ __global__ __launch_bounds__(1024) void k_flag_compact(u32* __restrict__ flags, 
 }
 
 // ------------------------------------------------------------------ BGZF -> text (one wave per <= 64 KiB deflate block)
-struct BgzfBlk { u64 in_off, out_off; u32 in_len, out_len; };
+typedef inflate_lane::Blk BgzfBlk;      // { u64 in_off, out_off; u32 in_len, out_len; }
 #if !defined(MLST_INFLATE_GROUP)
 #define MLST_INFLATE_GROUP 64
 #endif
 #define INFLATE_NG (64 / MLST_INFLATE_GROUP)      /* streams per wave (csrc/inflate_wave.h) */
 // one wave per block (csrc/inflate_wave.h); comp_bytes = size of the compressed buffer (the input windows stop there)
 __global__ __launch_bounds__(64) void k_inflate(const u8* __restrict__ comp, u64 comp_bytes, const BgzfBlk* __restrict__ blk, u32 n_blk, u8* __restrict__ out,
-                                                u32* __restrict__ err /* [0] = 1 + first bad block, [1] = its code */, unsigned long long* __restrict__ stats /* optional: 12 sums */) {
+                                                u32* __restrict__ err /* [0] = 1 + first bad block, [1] = its code */, unsigned long long* __restrict__ stats /* optional: 12 sums */,
+                                                const u32* __restrict__ only /* optional: decode block i only where only[i] == TOK_OVERFLOW (what the two-kernel path left over) */,
+                                                u32 err_base /* number of blk[0] in the caller's list (for err[0]) */) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int GS = inflate_wave::GS, NG = 64 / GS;      // lanes per stream, streams per wave
     __shared__ inflate_wave::Tabs s_tb[NG];        // Huffman tables, output ring and match queue of every stream
     const int lane = (int)threadIdx.x % GS, grp = (int)threadIdx.x / GS, gbase = grp * GS;
     for (u32 i = blockIdx.x * NG + (u32)grp; i < n_blk; i += gridDim.x * NG) {     // the same for the lanes of a group
+        if (only && only[i] != (u32)inflate_lane::TOK_OVERFLOW) continue;
         const BgzfBlk B = blk[i];
         u32 produced = 0;
         inflate_wave::Stats st;
@@ -1163,9 +1167,27 @@ __global__ __launch_bounds__(64) void k_inflate(const u8* __restrict__ comp, u64
         }
 #endif
         if (rc == mlst_inflate::OK && produced != B.out_len) rc = mlst_inflate::E_SHORT;
-        if (rc != mlst_inflate::OK && lane == 0 && atomicCAS(&err[0], 0u, i + 1u) == 0u) err[1] = (u32)(-rc);
+        if (rc != mlst_inflate::OK && lane == 0 && atomicCAS(&err[0], 0u, err_base + i + 1u) == 0u) err[1] = (u32)(-rc);
         inflate_wave::wave_sync();                // the tables are rebuilt for the next stream
     }
+#endif
+}
+// the two-kernel inflate (csrc/inflate_lane.h): lane = block -> tokens; workgroup = block -> bytes by pointer jumping in LDS
+#define INFL_TOK_CAP 24576u          /* tokens a block may have (96 KB of the token buffer per block); more: left to k_inflate */
+__global__ __launch_bounds__(64) void k_inflate_tok(const u8* __restrict__ comp, u64 comp_bytes, const BgzfBlk* __restrict__ blk, u32 n_blk, u32 err_base, u32* __restrict__ tok,
+                                                    u32* __restrict__ n_tok, u32* __restrict__ err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ mlst_inflate::Tables s_tb[64];
+    __shared__ unsigned long s_win[32 * 64];       // 256 bytes of every lane's stream, lane-interleaved 8-byte words (inflate_dev.h: Bits::win)
+    inflate_lane::tok_body(comp, comp + comp_bytes, blk, n_blk, err_base, tok, INFL_TOK_CAP, n_tok, err, s_tb, s_win);
+#endif
+}
+__global__ __launch_bounds__(1024) void k_inflate_ptr(const u8* __restrict__ comp, const BgzfBlk* __restrict__ blk, u32 n_blk, u32 err_base, const u32* __restrict__ tok,
+                                                      const u32* __restrict__ n_tok, u8* __restrict__ out, u32* __restrict__ err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) u16 s_ptr[65536];
+    __shared__ u32 s_part[16]; __shared__ u32 s_flag;
+    inflate_lane::ptr_body<1024>(comp, blk, n_blk, err_base, tok, INFL_TOK_CAP, n_tok, out, err, s_ptr, s_part, &s_flag);
 #endif
 }
 // ------------------------------------------------------------------ FASTQ text -> packed reads (GPU parser)
@@ -3315,6 +3337,7 @@ struct mlst_handle {
     u64* d_fq_lines = nullptr; u64 cap_fq_lines = 0; u64* d_fq_soff = nullptr; u64* d_fq_qoff = nullptr; u64 cap_fq_reads = 0; u64* d_fq_meta = nullptr;
     // pileup scratch
     int* d_locus_chosen = nullptr; u64* d_locus_colbase = nullptr; u64* d_pl_list = nullptr; u8* d_tb = nullptr;
+    u32* d_itok = nullptr; u32* d_intok = nullptr; u64 cap_itok_blocks = 0; int inflate_mode = 0;      // two-kernel inflate: token buffer (INFL_TOK_CAP words per block of a pass), tokens per block
     u32 depth_cap = 0; u64* d_capbuf = nullptr; u64 cap_capcols = 0;      // depth-capped pile-up (mlst_set_depth_cap): lo, hi, thr (u64 each) and cnt (u32) per column
     u32* d_counts = nullptr; u64 cap_counts = 0;
     // device-side typing (mlst_typing_enqueue / mlst_typing_fetch): fixed column layout, one slot of loc_maxlen columns per locus
@@ -3486,6 +3509,7 @@ static void free_state(mlst_handle* h) {
     hipFree(h->d_qc); h->d_qc = nullptr; h->cap_qc = 0; if (h->h_qc) { hipHostFree(h->h_qc); h->h_qc = nullptr; h->cap_hostq = 0; }
     hipFree(h->d_locus_chosen); hipFree(h->d_locus_colbase); hipFree(h->d_pl_list); hipFree(h->d_tb);
     hipFree(h->d_capbuf); h->d_capbuf = nullptr; h->cap_capcols = 0;
+    hipFree(h->d_itok); hipFree(h->d_intok); h->d_itok = nullptr; h->d_intok = nullptr; h->cap_itok_blocks = 0;
     E.sum_score = nullptr; E.n_hits = nullptr; E.locus_len = E.locus_first = nullptr; E.ctr = nullptr; E.ret_bases = nullptr; E.ret_quals = nullptr;
     E.ret_len = nullptr; E.ret_ridx = nullptr; E.ret_nrec = nullptr; E.items = nullptr; E.item_state = nullptr; E.res = nullptr; E.dp_list = nullptr;
     h->d_locus_chosen = nullptr; h->d_locus_colbase = nullptr; h->d_pl_list = nullptr; h->d_tb = nullptr;
@@ -4437,6 +4461,34 @@ extern "C" int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, c
     return submit_impl(h, h->d_packed, h->d_qc, h->d_lens, n_reads, wpr, qstride, paired, 2);
 }
 
+// BGZF blocks -> text.  Two ways (MLST_INFLATE_MODE): 2 = the two-kernel path of csrc/inflate_lane.h (one lane per block decodes
+// the Huffman codes into tokens, one workgroup per block turns tokens into bytes by pointer jumping in LDS), in passes of at
+// most INFL_PASS blocks (the token buffer holds 96 KB per block of a pass), with the blocks whose tokens did not fit left to
+// 1 = the one-wave-per-block kernel of csrc/inflate_wave.h.
+#define INFL_PASS 16384u
+static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padded, const BgzfBlk* d_blk, u32 n_blk, u8* d_out, u32* d_err, unsigned long long* d_st) {
+    if (n_blk == 0) return MLST_OK;
+    if (!h->inflate_mode) { const char* e = getenv("MLST_INFLATE_MODE"); h->inflate_mode = e ? atoi(e) : 2; if (h->inflate_mode != 1 && h->inflate_mode != 2) h->inflate_mode = 2; }
+    if (h->inflate_mode == 1 || d_st) {
+        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n_blk + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, h->stream, d_comp, comp_bytes_padded, d_blk, n_blk, d_out, d_err, d_st, (const u32*)nullptr, 0u);
+        return MLST_OK;
+    }
+    const u32 pass = std::min(n_blk, INFL_PASS);
+    if (h->cap_itok_blocks < pass) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        hipFree(h->d_itok); hipFree(h->d_intok); h->d_itok = nullptr; h->d_intok = nullptr; h->cap_itok_blocks = 0;
+        HIPCHK(h, dmalloc(&h->d_itok, (u64)pass * INFL_TOK_CAP)); HIPCHK(h, dmalloc(&h->d_intok, (u64)pass));
+        h->cap_itok_blocks = pass;
+    }
+    for (u32 at = 0; at < n_blk; at += pass) {
+        const u32 n = std::min(pass, n_blk - at);
+        hipLaunchKernelGGL(k_inflate_tok, dim3((n + 63) / 64), dim3(64), 0, h->stream, d_comp, comp_bytes_padded, d_blk + at, n, at, h->d_itok, h->d_intok, d_err);
+        hipLaunchKernelGGL(k_inflate_ptr, dim3(std::min(n, 4096u)), dim3(1024), 0, h->stream, d_comp, d_blk + at, n, at, (const u32*)h->d_itok, (const u32*)h->d_intok, d_out, d_err);
+        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, h->stream, d_comp, comp_bytes_padded, d_blk + at, n, d_out, d_err, (unsigned long long*)nullptr, (const u32*)h->d_intok, at);
+    }
+    return MLST_OK;
+}
+
 // Page-locked host memory for a caller's input buffers (FASTQ text read from files): a copy from such a buffer is one DMA
 // transfer at the link's rate; from ordinary memory the runtime first copies through its own staging buffers on a host
 // thread.  Process-wide (no engine needed); released by mlst_free_host.
@@ -4556,7 +4608,7 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
         HIPCHK(h, hipMemcpyAsync(h->d_bgzf_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->stream));
         u32* d_err = reinterpret_cast<u32*>(h->d_fq_meta + 2);
         HIPCHK(h, hipMemsetAsync(d_err, 0, 8, h->stream));
-        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>((blks.size() + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, h->stream, h->d_bgzf, (u64)h->cap_bgzf + 16, (const BgzfBlk*)h->d_bgzf_blk, (u32)blks.size(), h->d_fq_text, d_err, (unsigned long long*)nullptr);
+        { int rc = launch_inflate(h, h->d_bgzf, (u64)h->cap_bgzf + 16, (const BgzfBlk*)h->d_bgzf_blk, (u32)blks.size(), h->d_fq_text, d_err, nullptr); if (rc) return rc; }
         u32 err[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));      // also: blks / data may be released by the caller after this
@@ -4591,14 +4643,14 @@ extern "C" int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data,
     const bool want_stats = false;
 #endif
     if (want_stats && (dmalloc(&d_st, (u64)16) != hipSuccess || hipMemset(d_st, 0, 128) != hipSuccess)) d_st = nullptr;
-    if (dmalloc(&d_in, n_bytes + 16) != hipSuccess || dmalloc(&d_out, text_bytes + 16) != hipSuccess || dmalloc(&d_blk, (u64)blks.size()) != hipSuccess || dmalloc(&d_err, (u64)2) != hipSuccess)
+    if (dmalloc(&d_in, n_bytes + 16) != hipSuccess || dmalloc(&d_out, text_bytes + 16) != hipSuccess || dmalloc(&d_blk, (u64)blks.size()) != hipSuccess || dmalloc(&d_err, (u64)8) != hipSuccess)
         rc = fail(h, MLST_E_HIP, "device allocation failed");
     if (!rc && (hipMemcpy(d_in, data, n_bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice) != hipSuccess
-                || hipMemset(d_err, 0, 8) != hipSuccess || hipMemset(d_out, 0xEE, text_bytes) != hipSuccess)) rc = fail(h, MLST_E_HIP, "copy to the device failed");
+                || hipMemset(d_err, 0, 32) != hipSuccess || hipMemset(d_out, 0xEE, text_bytes) != hipSuccess)) rc = fail(h, MLST_E_HIP, "copy to the device failed");
     if (!rc) {
         hipEvent_t e0 = ev_get(h), e1 = ev_get(h);
         hipEventRecord(e0, h->stream);
-        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>((blks.size() + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, h->stream, d_in, (u64)n_bytes + 16, (const BgzfBlk*)d_blk, (u32)blks.size(), d_out, d_err, d_st);
+        rc = launch_inflate(h, d_in, (u64)n_bytes + 16, (const BgzfBlk*)d_blk, (u32)blks.size(), d_out, d_err, d_st);
         hipEventRecord(e1, h->stream);
         hipError_t se = hipStreamSynchronize(h->stream);
         float ms = 0; if (se == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
@@ -4607,6 +4659,10 @@ extern "C" int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data,
         if (se != hipSuccess || hipMemcpy(err, d_err, 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(out, d_out, text_bytes, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(h, MLST_E_HIP, "k_inflate failed: %s", hipGetErrorString(hipGetLastError()));
         else if (err[0]) rc = fail(h, MLST_E_INVALID, "corrupt deflate data in BGZF block %u (code %u)", err[0] - 1, err[1]);
+#if defined(MLST_PTR_TRACE)
+        { u32 tr[8] = {0}; if (hipMemcpy(tr, d_err, 32, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "k_inflate_ptr phases over %zu blocks (units of 64 cycles): fill %u, pointer jumping %u (%u rounds), gather %u\n", blks.size(), tr[2], tr[3], tr[5], tr[4]); }
+#endif
     }
     if (d_st && !rc) {
         unsigned long long v[10] = {0};
