@@ -92,9 +92,12 @@ MLST_HD inline int take(Bits& b, int n, uint32_t& out) {
 
 // A code = (count per length, symbols in code order) + a look-up table over the next LB input bits for the codes of at
 // most LB bits: entry = (symbol << SH) | length, 0 = longer code (decoded bit by bit).
-struct Huff  { enum { LB = 8, SH = 4 }; uint16_t count[16]; uint16_t symbol[288]; uint16_t lut[1 << LB]; };   // literal / length code (also the code-length code)
-struct HuffD { enum { LB = 6, SH = 3 }; uint16_t count[16]; uint16_t symbol[30]; uint8_t lut[1 << LB]; };     // distance code
-struct Tables { Huff lc; HuffD dc; };                           // 1.3 KB per stream: LDS in k_inflate, the stack on the host
+// (table bits: with one lane per stream -- inflate_lane.h -- a code longer than the table sends its lane through the canonical walk
+// while the other 63 wait, and with 64 streams some lane meets one in nearly every step at 8 / 6 bits: 9 / 8 bits are what 160 KB
+// of LDS hold for 64 lanes beside the input windows)
+struct Huff  { enum { LB = 9, SH = 4 }; uint16_t count[16]; uint16_t symbol[288]; uint16_t lut[1 << LB]; };   // literal / length code (also the code-length code)
+struct HuffD { enum { LB = 8, SH = 4 }; uint16_t count[16]; uint16_t symbol[30]; uint16_t lut[1 << LB]; };    // distance code
+struct Tables { Huff lc; HuffD dc; };                           // 2.2 KB per stream: LDS in k_inflate_tok, the stack on the host
 
 // canonical code from code lengths; returns 0 for a complete code, > 0 for an incomplete one, < 0 for an over-subscribed one
 template <typename H>
