@@ -87,12 +87,16 @@ def _bgzf_raw(raw: bytes, data: bytes) -> bytes:
 
 
 @pytest.mark.gpu
-def test_device_decoder_equals_zlib_on_every_block_kind():
-    """The wave decoder of csrc/inflate_wave.h (register windows, scalar state, tables built by ballot) on the GPU: every
+@pytest.mark.parametrize("mode", ["2", "1"])
+def test_device_decoder_equals_zlib_on_every_block_kind(mode, monkeypatch):
+    """The device decoders on the GPU -- mode 2: the two kernels of csrc/inflate_lane.h (one lane per block -> tokens, one
+    workgroup per block -> bytes by pointer jumping; blocks of more than 24,576 symbols, here the Huffman-only ones, fall to the
+    other kernel); mode 1: the one-wave-per-block decoder of csrc/inflate_wave.h for every block -- on every
     payload x level x strategy in ONE buffer of BGZF blocks (one launch), blocks at odd byte offsets, compared with the
     bytes that went in.  Includes stored blocks (level 0 and incompressible data), fixed codes, long codes (Huffman
-    only), overlapping matches (runs), matches 32 K back, empty blocks."""
+    only), overlapping matches (runs), matches 32 K back, empty blocks, blocks of odd and of full (65,536 bytes) length."""
     from metamlst_amd.engine import Engine, MlstError
+    monkeypatch.setenv("MLST_INFLATE_MODE", mode)      # (read when an engine inflates for the first time)
     rng = np.random.default_rng(5)
     far = bytes(rng.integers(0, 256, 300, dtype=np.uint8))
     extra = [far + bytes(rng.integers(65, 70, 32300, dtype=np.uint8)) + far,        # a match at the far end of the window
@@ -105,6 +109,10 @@ def test_device_decoder_equals_zlib_on_every_block_kind():
             data = data[:65280]
             blocks.append(_bgzf_raw(deflate(data, level, strategy), data))
             want.append(data)
+    full = (payloads()[4] * 2)[:65536]                                            # the format's largest block; and an odd length
+    for data in (full, full[:65535], full[:1], full[:2], full[:3]):
+        blocks.append(_bgzf_raw(deflate(data, 6), data))
+        want.append(data)
     eng = Engine(0)
     got = eng.inflate_bgzf(b"".join(blocks))
     assert got == b"".join(want)
