@@ -594,10 +594,17 @@ def end_to_end(w, args, torch, device):
     with ThreadPoolExecutor(max(1, min(64, os.cpu_count() or 1))) as ex:      # zlib releases the GIL
         parts = list(ex.map(bgzf_block, [raw[at:at + 65280] for at in range(0, len(raw), 65280)]))
     comp = np.frombuffer(b"".join(parts) + bgzf_block(b""), np.uint8)
+    # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks, here 16,384 of them = one pass of the inflate
+    # kernels, ~190 MB compressed): the copy of piece k + 1 crosses the link while piece k's text is parsed
+    per_piece = 16384
+    cuts = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
+    pieces = [comp[int(cuts[a]):int(cuts[min(a + per_piece, len(parts))])] for a in range(0, len(parts), per_piece)]
+    pieces[-1] = comp[int(cuts[(len(pieces) - 1) * per_piece]):]            # (with the end-of-file block)
 
     def run_bgzf():
         eng.reset_sample()
-        eng.submit_fastq_bgzf(comp, final=True)
+        for k, pc in enumerate(pieces):
+            eng.submit_fastq_bgzf(pc, final=(k == len(pieces) - 1))
         eng.typing_enqueue(penalty=100)
         return tail()
 
