@@ -326,3 +326,42 @@ def test_packed_host_submit_equals_the_text_path():
         assert np.array_equal(fx2.sorted_items(eng.items(1 << 16)), want_items)
         assert got_ch == want_ch and {a: bytes(v) for a, v in got_let.items()} == {a: bytes(v) for a, v in want_let.items()}
     eng.close()
+
+
+@pytest.mark.gpu
+def test_page_locked_buffers_feed_the_parser_like_ordinary_memory(tmp_path):
+    """engine.pinned_array (mlst_alloc_host): FASTQ text submitted from page-locked memory -- whole, and as the pooled chunks
+    fastq.text_chunks(reuse=True) hands out once the allocator is set, the way `cli type` reads files -- gives the statistics of the
+    same text from ordinary memory; the memory goes back when the arrays are collected."""
+    import gc
+    from metamlst_amd import fastq
+    from metamlst_amd.engine import Engine, pinned_array
+    import fixtures as fx2
+    db, idx = fx2.ecoli_small(40)
+    g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][1], size=50_000)
+    b, q = synth.sample_reads(g, 4000, seed=9)
+    text = b"".join(b"@r%d\n" % k + b[k].tobytes() + b"\n+\n" + q[k].tobytes() + b"\n" for k in range(len(b)))
+    eng = Engine(0)
+    eng.load_reference(idx)
+    assert eng.submit_fastq(text) == len(b)
+    want = eng.stats()
+    pin = pinned_array(len(text) + 1000)
+    pin[:len(text)] = np.frombuffer(text, np.uint8)
+    eng.reset_sample()
+    assert eng.submit_fastq(pin[:len(text)]) == len(b)
+    fx2.assert_stats_equal(eng.stats(), want)
+    path = tmp_path / "p.fastq"
+    path.write_bytes(text)
+    fastq.set_buffer_allocator(pinned_array)
+    try:
+        ring = []
+        eng.reset_sample()
+        n = sum(eng.submit_fastq(c) for c in fastq.prefetch(fastq.text_chunks(str(path), 300_000, reuse=True, ring=ring)))
+        fastq.release_buffers(ring)
+        assert n == len(b)
+        fx2.assert_stats_equal(eng.stats(), want)
+    finally:
+        fastq.set_buffer_allocator(None)
+    del pin, ring
+    gc.collect()
+    eng.close()
