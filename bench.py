@@ -641,13 +641,16 @@ def end_to_end(w, args, torch, device):
     out["bgzip_to_st"] = {"reads": nz, "Mreads_per_s": round(nz / min(ts) / 1e6, 1), "compressed_bytes": int(comp.size), "zlib_level": 6, "seconds": round(min(ts), 4),
                           "species_called": len(calls)}
     del raw
-    out["cli_folder_to_nfo"] = folder_leg(w, text_host, n, rec)
-    out["cli_folder_bgzip_to_nfo"] = folder_leg(w, text_host, n, rec, bgzf_parts=parts, eof_block=bgzf_block(b""))
+    for key, kw in (("cli_folder_to_nfo", {}), ("cli_folder_bgzip_to_nfo", {"bgzf_parts": parts, "eof_block": bgzf_block(b"")})):
+        try:
+            out[key] = folder_leg(w, text_host, n, rec, **kw)
+        except (OSError, MemoryError) as e:      # (no room for the sample files: the leg is skipped, the line stands)
+            out[key] = {"skipped": "%s: %s" % (type(e).__name__, e)}
     del parts
     return out
 
 
-def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=1 << 20, bgzf_parts=None, eof_block=b""):
+def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=2 << 20, bgzf_parts=None, eof_block=b""):
     """The product command on a folder of samples (`cli type folder/` = multigpu.type_many_samples: files -> reader thread -> GPU
     parser -> the pipelined loop of metamlst_amd/pipeline.py on the workload's engines -> one .nfo file per sample;
     /root/reference/metamlst-merge.py:93-107 reads that folder).  FASTQ text files in memory-backed storage, so what is
@@ -655,6 +658,7 @@ def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=1 << 20, bgzf_par
     import shutil
     from metamlst_amd.multigpu import type_many_samples
     from metamlst_amd.typing import TypingArgs
+    reads_per_file = int(os.environ.get("MLST_FOLDER_READS", reads_per_file))      # (ad-hoc runs: larger samples)
     per = min(reads_per_file, n // n_files)
     if bgzf_parts is not None:      # whole BGZF blocks of 65,280 bytes of text: a sample = a run of them (its last record may be cut: the parser drops nothing, the reader completes it from the next block -- so samples are cut at block AND record boundaries: 65,280 x k bytes with k a multiple of rec / gcd)
         import math
@@ -663,7 +667,14 @@ def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=1 << 20, bgzf_par
         per = blocks_per * 65280 // rec
     if per < 1000:
         return {"skipped": "slice too small"}
-    root = tempfile.mkdtemp(prefix="mlst_folder_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    need = n_files * per * rec * (1.3 if bgzf_parts is None else 0.4)
+    shm_ok = False
+    try:
+        st = os.statvfs("/dev/shm")
+        shm_ok = st.f_bavail * st.f_frsize > need
+    except OSError:
+        pass
+    root = tempfile.mkdtemp(prefix="mlst_folder_", dir="/dev/shm" if shm_ok else None)
     try:
         files = []
         for k in range(n_files):

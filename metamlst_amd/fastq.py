@@ -106,7 +106,8 @@ def last_record_start(buf, window: int = 1 << 16) -> int:
 _READ_PIECE = 4 << 20
 _pool_lock = threading.Lock()
 _pool_bufs: list = []          # idle buffers (uint8 arrays), at most _POOL_MAX of them
-_POOL_MAX = 6
+_POOL_MAX = int(os.environ.get("MLST_READ_POOL", "20"))      # (four feeder threads keep four buffers each in flight: a pool that holds fewer
+                                                             # frees and allocates page-locked memory between samples -- ~50 ms per 256 MB buffer)
 _readers = None
 
 
