@@ -1192,11 +1192,30 @@ __global__ __launch_bounds__(1024) void k_inflate_ptr(const u8* __restrict__ com
 }
 // ------------------------------------------------------------------ FASTQ text -> packed reads (GPU parser)
 #define FQ_BLOCK 4096        // bytes of text per workgroup
+// newline flags of 16 bytes of text at byte p (a multiple of 16; the text buffer is 256-byte aligned): bit k = byte p + k is '\n'.
+// One 16-byte load per thread instead of sixteen byte loads (the passes over the text were bound by their load instructions:
+// 330-540 GB/s; the parse of a bgzip'd piece took 7 ms beside 9.5 ms of inflate).
+__device__ inline u32 fq_nl16(const u8* __restrict__ text, u64 p, u64 n_bytes) {
+    u32 m = 0;
+    if (p + 16 <= n_bytes) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + p);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+        #pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const u32 y = w[d] ^ 0x0A0A0A0Au;                                                  // zero bytes where the text holds '\n'
+            const u32 t = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);              // 0x80 in exactly those bytes
+            m |= (((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u)) << (4 * d);
+        }
+    } else {
+        for (u32 k = 0; k < 16 && p + k < n_bytes; k++) if (text[p + k] == '\n') m |= 1u << k;
+    }
+    return m;
+}
 // pass A: newlines per FQ_BLOCK bytes
 __global__ __launch_bounds__(256) void k_fq_count(const u8* __restrict__ text, u64 n_bytes, u32* __restrict__ blk_count) {
     __shared__ u32 s_c[4];
-    u64 base = (u64)blockIdx.x * FQ_BLOCK; u32 c = 0;
-    for (u32 i = threadIdx.x; i < FQ_BLOCK; i += 256) { u64 p = base + i; if (p < n_bytes && text[p] == '\n') c++; }
+    const u64 p = (u64)blockIdx.x * FQ_BLOCK + (u64)threadIdx.x * 16;
+    u32 c = p < n_bytes ? (u32)__popc(fq_nl16(text, p, n_bytes)) : 0u;
     c = wave_sum_u32(c);
     if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -1216,21 +1235,20 @@ __global__ __launch_bounds__(1024) void k_fq_scan(u32* __restrict__ blk_count, u
     u64 run = s_part[threadIdx.x];
     for (u32 i = lo; i < hi; i++) { u32 t = blk_count[i]; blk_count[i] = (u32)run; run += t; }     // < 2^32 lines per chunk (checked on the host)
 }
-// pass C: start offset of every line: line 0 starts at 0, line k+1 starts after the k-th newline
+// pass C: start offset of every line: line 0 starts at 0, line k+1 starts after the k-th newline.  A thread takes 16 bytes
+// (FQ_BLOCK = 256 threads x 16), the newline counts are scanned over the workgroup once.
 __global__ __launch_bounds__(256) void k_fq_lines(const u8* __restrict__ text, u64 n_bytes, const u32* __restrict__ blk_excl, u64* __restrict__ line_start) {
     __shared__ u32 s_w[4];
-    u64 base = (u64)blockIdx.x * FQ_BLOCK; u32 run = blk_excl[blockIdx.x];
+    const u64 p = (u64)blockIdx.x * FQ_BLOCK + (u64)threadIdx.x * 16;
+    const int wv = threadIdx.x >> 6;
     if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0;
-    for (u32 i0 = 0; i0 < FQ_BLOCK; i0 += 256) {
-        u64 p = base + i0 + threadIdx.x; bool nl = p < n_bytes && text[p] == '\n';
-        u64 m = __ballot(nl); int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (lane == 0) s_w[wv] = (u32)__popcll(m);
-        __syncthreads();
-        u32 before = 0; for (int w = 0; w < wv; w++) before += s_w[w];
-        if (nl) line_start[(u64)run + before + __popcll(m & ((1ull << lane) - 1)) + 1] = p + 1;
-        run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        __syncthreads();
-    }
+    u32 m = p < n_bytes ? fq_nl16(text, p, n_bytes) : 0u;
+    const u32 cnt = (u32)__popc(m), inc = wave_incl_scan_dpp(cnt);
+    if ((threadIdx.x & 63) == 63) s_w[wv] = inc;
+    __syncthreads();
+    u64 line = (u64)blk_excl[blockIdx.x] + (inc - cnt) + 1;
+    for (int w = 0; w < wv; w++) line += s_w[w];
+    while (m) { const int k = __ffs((int)m) - 1; m &= m - 1; line_start[line++] = p + (u64)k + 1; }
 }
 // pass D: per record the byte ranges of the sequence line (4r+1) and the quality line (4r+3); CR stripped
 // pair_k != 0: the text is two files of mates one after the other, pair_k records each; record j of the first becomes read
