@@ -24,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="0,1")
     ap.add_argument("--chunk", type=int, default=4_000_000)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "skewed"])
     ap.add_argument("--engine-only", action="store_true", help="skip the oracle (diagnostics of the engine-side sequence)")
     a = ap.parse_args()
     import __graft_entry__ as ge
