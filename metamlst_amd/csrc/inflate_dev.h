@@ -45,7 +45,8 @@ MLST_HD inline void refill(Bits& b) {
         // padding.)
         const uint8_t* p = b.in + b.pos;
         uint64_t w0, w1; unsigned sh;
-        if (b.win) {
+        {   // (device code always brings a window -- inflate_lane.h is its only user; a second path that loads from global memory
+            // here made the compiler wait at the join for EVERYTHING the lane had in flight, its token stores included)
             const bool need = p + 16 > b.win_at + 256 || p < b.win_at;
             if (__ballot(need)) {                      // every lane that is here moves its window up: the waits coincide
                 const uint8_t* a0 = p - ((uintptr_t)p & 15u);
@@ -67,11 +68,6 @@ MLST_HD inline void refill(Bits& b) {
             const unsigned o = (unsigned)(p - b.win_at);
             w0 = b.win[(o >> 3) * 64]; w1 = b.win[((o >> 3) + 1) * 64];
             sh = (o & 7u) * 8u;
-        } else {
-            const uint64_t a = (uint64_t)(uintptr_t)p;
-            const uint64_t* p8 = reinterpret_cast<const uint64_t*>(p - (a & 7u));
-            sh = (unsigned)(a & 7u) * 8u;
-            w0 = p8[0]; w1 = p8[1];
         }
         w = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
 #else
