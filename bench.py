@@ -784,6 +784,7 @@ def summarize(w, res, eng, world, depth):
 
 
 def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's driver shares device memory between processes by dmabuf only: RCCL needs it)
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))

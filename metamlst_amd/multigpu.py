@@ -39,6 +39,7 @@ def spawn_ranks(n_gpus: int, cmd: list[str], attempts: int = 3) -> int:
         try:
             for r in range(n_gpus):
                 env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                           HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                            MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
                 procs.append(subprocess.Popen(cmd, env=env))
             live = list(procs)
