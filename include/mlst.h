@@ -124,7 +124,8 @@ int mlst_submit_fastq_stream(mlst_handle* h, const uint8_t* text, uint64_t n_byt
 int mlst_submit_fastq_pair(mlst_handle* h, const uint8_t* text1, uint64_t n1, const uint8_t* text2, uint64_t n2, uint64_t* n_reads_out);
 
 /* The same from BGZF-compressed FASTQ (bgzip; a series of independent <= 64 KiB deflate blocks): the COMPRESSED bytes
- * cross PCIe, every block is inflated by one GPU wave (csrc/inflate_wave.h), the text is parsed as above.  A chunk is
+ * cross PCIe, the blocks are inflated on the GPU (csrc/inflate_lane.h: one lane per block decodes the codes into tokens,
+ * one workgroup per block turns tokens into bytes; csrc/inflate_wave.h for oversized blocks), the text is parsed as above.  A chunk is
  * a run of whole BGZF blocks cut anywhere between blocks; a record that straddles two chunks is completed by the next
  * call; the last chunk of a file is passed with final_chunk != 0 and must end with a whole record.  Block CRCs are
  * not verified (the inflated size is).  With n_consumed_out != NULL a non-final buffer may also end inside a block:
