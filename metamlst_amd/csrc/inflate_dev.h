@@ -93,20 +93,29 @@ MLST_HD inline int take(Bits& b, int n, uint32_t& out) {
 // of LDS hold for 64 lanes beside the input windows)
 struct Huff  { enum { LB = 9, SH = 4 }; uint16_t count[16]; uint16_t symbol[288]; uint16_t lut[1 << LB]; };   // literal / length code (also the code-length code)
 struct HuffD { enum { LB = 8, SH = 4 }; uint16_t count[16]; uint16_t symbol[30]; uint16_t lut[1 << LB]; };    // distance code
-struct Tables { Huff lc; HuffD dc; };                           // 2.2 KB per stream: LDS in k_inflate_tok, the stack on the host
+struct Tables { Huff lc; HuffD dc; uint16_t offs[16]; };        // 2.2 KB per stream: LDS in k_inflate_tok, the stack on the host
+// No array of the decoder lives on a thread's stack (round 5; k_inflate_tok had 656 bytes of scratch per lane): the code
+// lengths of a block are kept in lc.lut until the literal / length code is built from them (build() reads every length before it
+// writes the first table entry), the code-length code is decoded with dc's tables (19 symbols of at most 7 bits fit HuffD), and
+// build()'s running offsets sit in Tables::offs.
 
 // canonical code from code lengths; returns 0 for a complete code, > 0 for an incomplete one, < 0 for an over-subscribed one
+// (length may be h.lut itself: every length is read before the first table entry is written)
 template <typename H>
-MLST_HD inline int build(H& h, const uint16_t* length, int n) {
+MLST_HD inline int build(H& h, const uint16_t* length, int n, uint16_t* offs) {
     for (int l = 0; l <= 15; l++) h.count[l] = 0;
-    for (int i = 0; i < (1 << H::LB); i++) h.lut[i] = 0;
     for (int s = 0; s < n; s++) h.count[length[s]]++;
-    if (h.count[0] == n) return 0;                 // no codes: complete, but decoding anything with it fails
     int left = 1;
-    for (int l = 1; l <= 15; l++) { left <<= 1; left -= h.count[l]; if (left < 0) return left; }
-    uint16_t offs[16]; offs[1] = 0;
+    if (h.count[0] != n) for (int l = 1; l <= 15; l++) { left <<= 1; left -= h.count[l]; if (left < 0) break; }
+    if (h.count[0] == n || left < 0) {             // no codes (complete, but decoding anything with it fails) or an over-subscribed set
+        const int none = h.count[0] == n;
+        for (int i = 0; i < (1 << H::LB); i++) h.lut[i] = 0;
+        return none ? 0 : left;
+    }
+    offs[1] = 0;
     for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + h.count[l]);
     for (int s = 0; s < n; s++) if (length[s] != 0) h.symbol[offs[length[s]]++] = (uint16_t)s;
+    for (int i = 0; i < (1 << H::LB); i++) h.lut[i] = 0;
     // look-up table: the canonical code of the j-th symbol of length l is first(l) + j, sent most significant bit first
     int code = 0, idx = 0;
     for (int l = 1; l <= H::LB; l++) {
@@ -203,7 +212,8 @@ MLST_HD inline int inflate_stream(const uint8_t* in, uint64_t n_in, Out& o, uint
 #endif
     uint64_t& op = o.op;
     Huff& lc = tb->lc; HuffD& dc = tb->dc;
-    uint16_t lengths[320];
+    uint16_t* const lengths = lc.lut;                  // 512 entries; at most 320 lengths (see Tables)
+    uint16_t* const offs = tb->offs;
     for (;;) {
         uint32_t last, type; int rc;
         if ((rc = take(b, 1, last)) != OK || (rc = take(b, 2, type)) != OK) return rc;
@@ -218,27 +228,27 @@ MLST_HD inline int inflate_stream(const uint8_t* in, uint64_t n_in, Out& o, uint
             if (op + len > cap) return E_OUTPUT;
             o.raw(b.in + b.pos, len); b.pos += len;
         } else if (type == 1) {
+            for (int s = 0; s < 30; s++) lengths[s] = 5;
+            build(dc, lengths, 30, offs);
             for (int s = 0; s < 144; s++) lengths[s] = 8;
             for (int s = 144; s < 256; s++) lengths[s] = 9;
             for (int s = 256; s < 280; s++) lengths[s] = 7;
             for (int s = 280; s < 288; s++) lengths[s] = 8;
-            build(lc, lengths, 288);
-            for (int s = 0; s < 30; s++) lengths[s] = 5;
-            build(dc, lengths, 30);
+            build(lc, lengths, 288, offs);
             if constexpr (OWN_CODES) rc = Out::codes(b, lc, dc, o, cap); else rc = codes(b, lc, dc, o, cap);
             if (rc != OK) return rc;
         } else if (type == 2) {
-            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             uint32_t nlen, ndist, ncode;
             if ((rc = take(b, 5, nlen)) != OK || (rc = take(b, 5, ndist)) != OK || (rc = take(b, 4, ncode)) != OK) return rc;
             nlen += 257; ndist += 1; ncode += 4;
             if (nlen > 286 || ndist > 30) return E_LENGTHS;
             for (int i = 0; i < 19; i++) lengths[i] = 0;
             for (uint32_t i = 0; i < ncode; i++) { uint32_t x; if ((rc = take(b, 3, x)) != OK) return rc; lengths[order[i]] = (uint16_t)x; }
-            if (build(lc, lengths, 19) != 0) return E_LENGTHS;      // the code-length code must be complete
+            if (build(dc, lengths, 19, offs) != 0) return E_LENGTHS;      // the code-length code (in dc's tables) must be complete
             uint32_t idx = 0;
             while (idx < nlen + ndist) {
-                int sym = decode(b, lc);
+                int sym = decode(b, dc);
                 if (sym < 0) return sym;
                 if (sym < 16) lengths[idx++] = (uint16_t)sym;
                 else {
@@ -255,10 +265,10 @@ MLST_HD inline int inflate_stream(const uint8_t* in, uint64_t n_in, Out& o, uint
                 }
             }
             if (lengths[256] == 0) return E_LENGTHS;                 // no end-of-block code
-            int e = build(lc, lengths, (int)nlen);
-            if (e < 0 || (e > 0 && nlen != (uint32_t)(lc.count[0] + lc.count[1]))) return E_LENGTHS;
-            e = build(dc, lengths + nlen, (int)ndist);
+            int e = build(dc, lengths + nlen, (int)ndist, offs);      // (the distance code first: building lc overwrites the lengths)
             if (e < 0 || (e > 0 && ndist != (uint32_t)(dc.count[0] + dc.count[1]))) return E_LENGTHS;
+            e = build(lc, lengths, (int)nlen, offs);
+            if (e < 0 || (e > 0 && nlen != (uint32_t)(lc.count[0] + lc.count[1]))) return E_LENGTHS;
             if constexpr (OWN_CODES) rc = Out::codes(b, lc, dc, o, cap); else rc = codes(b, lc, dc, o, cap);
             if (rc != OK) return rc;
         } else return E_BLOCKTYPE;

@@ -1237,11 +1237,12 @@ __global__ __launch_bounds__(1024) void k_fq_scan(u32* __restrict__ blk_count, u
 }
 // pass C: start offset of every line: line 0 starts at 0, line k+1 starts after the k-th newline.  A thread takes 16 bytes
 // (FQ_BLOCK = 256 threads x 16), the newline counts are scanned over the workgroup once.
-__global__ __launch_bounds__(256) void k_fq_lines(const u8* __restrict__ text, u64 n_bytes, const u32* __restrict__ blk_excl, u64* __restrict__ line_start) {
+// first: where line 0 starts (the bytes in front of it are filler without a newline: a chunk whose text was placed behind a partial record of unknown length)
+__global__ __launch_bounds__(256) void k_fq_lines(const u8* __restrict__ text, u64 n_bytes, const u32* __restrict__ blk_excl, u64* __restrict__ line_start, u64 first) {
     __shared__ u32 s_w[4];
     const u64 p = (u64)blockIdx.x * FQ_BLOCK + (u64)threadIdx.x * 16;
     const int wv = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = first;
     u32 m = p < n_bytes ? fq_nl16(text, p, n_bytes) : 0u;
     const u32 cnt = (u32)__popc(m), inc = wave_incl_scan_dpp(cnt);
     if ((threadIdx.x & 63) == 63) s_w[wv] = inc;
@@ -3356,6 +3357,13 @@ struct mlst_handle {
     // pileup scratch
     int* d_locus_chosen = nullptr; u64* d_locus_colbase = nullptr; u64* d_pl_list = nullptr; u8* d_tb = nullptr;
     u32* d_itok = nullptr; u32* d_intok = nullptr; u64 cap_itok_blocks = 0; int inflate_mode = 0;      // two-kernel inflate: token buffer (INFL_TOK_CAP words per block of a pass), tokens per block
+    // BGZF input in three stages on three streams (mlst_submit_fastq_bgzf, round 5): the copy of piece k (copy_stream), the inflate
+    // of piece k (infl_stream) and the parse + pass 1 of piece k - 1 (the engine's stream) run side by side.  Two slots of
+    // compressed bytes / block descriptors / error words used in turn; `bz_pend` is the piece whose text is being inflated
+    // (or has been) and has not been parsed yet.
+    struct BzSlot { u8* d_comp = nullptr; u64 cap_comp = 0; void* d_blk = nullptr; u64 cap_blk = 0; hipEvent_t ev_copied = nullptr, ev_inflated = nullptr; u32* d_err = nullptr; u32* h_err = nullptr; };
+    BzSlot bz[2]; int bz_slot = 0, bz_mode = -1; hipStream_t infl_stream = nullptr;
+    struct { bool on = false; int slot = 0, tslot = 0, paired = 0; u64 text_bytes = 0; } bz_pend;
     u32 depth_cap = 0; u64* d_capbuf = nullptr; u64 cap_capcols = 0;      // depth-capped pile-up (mlst_set_depth_cap): lo, hi, thr (u64 each) and cnt (u32) per column
     u32* d_counts = nullptr; u64 cap_counts = 0;
     // device-side typing (mlst_typing_enqueue / mlst_typing_fetch): fixed column layout, one slot of loc_maxlen columns per locus
@@ -3398,6 +3406,8 @@ static int fail(mlst_handle* h, int code, const char* fmt, ...) {
 }
 #define HIPCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, MLST_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
+static int bz_flush(mlst_handle* h);      // BGZF input: the piece still being inflated is parsed and submitted (defined with mlst_submit_fastq_bgzf)
+static void bz_free(mlst_handle* h);
 template <typename T> static hipError_t dmalloc(T** p, u64 n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
 template <typename T> static hipError_t dmalloc(GP<T>* p, u64 n) { return hipMalloc((void**)&p->p, (n ? n : 1) * sizeof(T)); }
 
@@ -3538,6 +3548,7 @@ extern "C" void mlst_destroy(mlst_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    bz_free(h);
     for (auto& e : h->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) hipEventDestroy(e);
     free_ref(h); free_state(h);
@@ -4039,6 +4050,7 @@ extern "C" int mlst_reset_sample(mlst_handle* h) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
     hipSetDevice(h->device);
     drain_events(h);
+    if (h->bz_pend.on) { if (h->infl_stream) hipStreamSynchronize(h->infl_stream); h->bz_pend.on = false; }      // a BGZF piece still open belongs to the sample that is dropped
     return reset_sample_state(h);
 }
 
@@ -4251,6 +4263,7 @@ static int h2d_overlapped(mlst_handle* h, void* d_dst, const void* src, u64 n, h
 extern "C" int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, const uint8_t* d_quals, const uint64_t* d_off,
                                         uint64_t n_reads, uint32_t max_len, int paired) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     hipSetDevice(h->device);
     if (n_reads == 0) return MLST_OK;
     if (max_len > MLST_MAX_READ_LEN) return fail(h, MLST_E_LIMIT, "read longer than %d bases", MLST_MAX_READ_LEN);
@@ -4264,6 +4277,7 @@ extern "C" int mlst_submit_reads_device(mlst_handle* h, const uint8_t* d_bases, 
 extern "C" int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uint8_t* quals, const uint64_t* off,
                                  uint64_t n_reads, int paired) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     if (n_reads == 0) return MLST_OK;
     if (!bases || !quals || !off) return fail(h, MLST_E_INVALID, "NULL argument");
     hipSetDevice(h->device);
@@ -4300,7 +4314,9 @@ static int next_text_slot(mlst_handle* h, u64 bytes) {
 // the partial record at its end is kept (h->d_fq_carry) for the next chunk.
 // pair_boundary != 0 (whole text only): the text is two mate files back to back, the second starting at that byte; both
 // must hold the same number of records, which are then interleaved (k_fq_records) and submitted as pairs.
-static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, uint64_t* n_reads_out, u64 pair_boundary = 0) {
+// tslot: the text slot the chunk sits in (-1: the current one); skip: bytes of filler in front of the first line (see k_fq_lines).
+static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, uint64_t* n_reads_out, u64 pair_boundary = 0, int tslot = -1, u64 skip = 0) {
+    if (tslot < 0) tslot = h->fq_slot;
     const u64 n_blocks = (n_bytes + FQ_BLOCK - 1) / FQ_BLOCK;
     if (h->cap_fq_blk < n_blocks) { hipFree(h->d_fq_blk); h->d_fq_blk = nullptr; HIPCHK(h, dmalloc(&h->d_fq_blk, n_blocks + 1)); h->cap_fq_blk = n_blocks; }
     HIPCHK(h, hipMemsetAsync(h->d_fq_meta, 0, 16, h->stream));
@@ -4314,7 +4330,7 @@ static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, u
     if (whole && n_lines % 4 != 0) return fail(h, MLST_E_INVALID, "FASTQ chunk holds %llu lines: not a whole number of 4-line records", (unsigned long long)n_lines);
     const u64 n_reads = n_lines / 4;
     if (h->cap_fq_lines < n_lines + 2) { hipFree(h->d_fq_lines); h->d_fq_lines = nullptr; HIPCHK(h, dmalloc(&h->d_fq_lines, n_lines + 2)); h->cap_fq_lines = n_lines + 2; }
-    hipLaunchKernelGGL(k_fq_lines, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_blk, h->d_fq_lines);
+    hipLaunchKernelGGL(k_fq_lines, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_blk, h->d_fq_lines, skip);
     h->fq_carry_len = 0;
     if (!whole) {      // text behind the last whole record waits for the next chunk
         u64 end_off = 0;
@@ -4329,7 +4345,7 @@ static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, u
         }
         n_bytes = end_off; n_lines = 4 * n_reads;
     }
-    if (n_reads == 0) { HIPCHK(h, hipEventRecord(h->ev_packed[h->fq_slot], h->stream)); return MLST_OK; }
+    if (n_reads == 0) { HIPCHK(h, hipEventRecord(h->ev_packed[tslot], h->stream)); return MLST_OK; }
     u64 pair_k = 0;
     if (pair_boundary) {
         if (n_reads & 1) return fail(h, MLST_E_INVALID, "mate files hold different numbers of records (%llu records in all)", (unsigned long long)n_reads);
@@ -4366,7 +4382,7 @@ static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, u
     hipLaunchKernelGGL(k_pack_text, dim3(grid_for((n_reads + 63) / 64, 1, 8192)), dim3(256), 0, h->stream, h->d_fq_text, h->d_fq_soff, h->d_fq_qoff,
                        h->d_lens, n_reads, h->d_packed, h->d_qrows, wpr, qstride);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev_packed[h->fq_slot], h->stream));      // the text buffer may be overwritten from here on
+    HIPCHK(h, hipEventRecord(h->ev_packed[tslot], h->stream));      // the text buffer may be overwritten from here on
     if (n_reads_out) *n_reads_out = n_reads;
     return mlst_submit_packed_device(h, h->d_packed, h->d_qrows, h->d_lens, n_reads, wpr, qstride, paired);
 }
@@ -4446,6 +4462,7 @@ extern "C" int mlst_pack_fastq_host(const uint8_t* text, uint64_t n_bytes, uint3
 extern "C" int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, const uint8_t* qrows, const uint16_t* lens, uint64_t n_reads,
                                        uint32_t wpr, uint32_t qstride, int paired) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     if (!packed || !qrows || !lens) return fail(h, MLST_E_INVALID, "NULL argument");
     hipSetDevice(h->device);
     if (wpr == 0 || wpr > RW || (wpr & 1)) return fail(h, MLST_E_INVALID, "words_per_read must be even and in 2..%d", RW);
@@ -4484,25 +4501,26 @@ extern "C" int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, c
 // most INFL_PASS blocks (the token buffer holds 96 KB per block of a pass), with the blocks whose tokens did not fit left to
 // 1 = the one-wave-per-block kernel of csrc/inflate_wave.h.
 #define INFL_PASS 16384u
-static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padded, const BgzfBlk* d_blk, u32 n_blk, u8* d_out, u32* d_err, unsigned long long* d_st) {
+static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padded, const BgzfBlk* d_blk, u32 n_blk, u8* d_out, u32* d_err, unsigned long long* d_st, hipStream_t st = nullptr) {
     if (n_blk == 0) return MLST_OK;
+    if (!st) st = h->stream;
     if (!h->inflate_mode) { const char* e = getenv("MLST_INFLATE_MODE"); h->inflate_mode = e ? atoi(e) : 2; if (h->inflate_mode != 1 && h->inflate_mode != 2) h->inflate_mode = 2; }
     if (h->inflate_mode == 1 || d_st) {
-        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n_blk + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, h->stream, d_comp, comp_bytes_padded, d_blk, n_blk, d_out, d_err, d_st, (const u32*)nullptr, 0u);
+        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n_blk + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk, n_blk, d_out, d_err, d_st, (const u32*)nullptr, 0u);
         return MLST_OK;
     }
     const u32 pass = std::min(n_blk, INFL_PASS);
     if (h->cap_itok_blocks < pass) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipStreamSynchronize(st)); HIPCHK(h, hipStreamSynchronize(h->stream));
         hipFree(h->d_itok); hipFree(h->d_intok); h->d_itok = nullptr; h->d_intok = nullptr; h->cap_itok_blocks = 0;
         HIPCHK(h, dmalloc(&h->d_itok, (u64)pass * INFL_TOK_CAP)); HIPCHK(h, dmalloc(&h->d_intok, (u64)pass));
         h->cap_itok_blocks = pass;
     }
     for (u32 at = 0; at < n_blk; at += pass) {
         const u32 n = std::min(pass, n_blk - at);
-        hipLaunchKernelGGL(k_inflate_tok, dim3((n + 63) / 64), dim3(64), 0, h->stream, d_comp, comp_bytes_padded, d_blk + at, n, at, h->d_itok, h->d_intok, d_err);
-        hipLaunchKernelGGL(k_inflate_ptr, dim3(std::min(n, 4096u)), dim3(1024), 0, h->stream, d_comp, d_blk + at, n, at, (const u32*)h->d_itok, (const u32*)h->d_intok, d_out, d_err);
-        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, h->stream, d_comp, comp_bytes_padded, d_blk + at, n, d_out, d_err, (unsigned long long*)nullptr, (const u32*)h->d_intok, at);
+        hipLaunchKernelGGL(k_inflate_tok, dim3((n + 63) / 64), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk + at, n, at, h->d_itok, h->d_intok, d_err);
+        hipLaunchKernelGGL(k_inflate_ptr, dim3(std::min(n, 4096u)), dim3(1024), 0, st, d_comp, d_blk + at, n, at, (const u32*)h->d_itok, (const u32*)h->d_intok, d_out, d_err);
+        hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk + at, n, d_out, d_err, (unsigned long long*)nullptr, (const u32*)h->d_intok, at);
     }
     return MLST_OK;
 }
@@ -4526,6 +4544,7 @@ extern "C" int mlst_free_host(void* p) {
 
 extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int paired, uint64_t* n_reads_out) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     if (n_reads_out) *n_reads_out = 0;
     if (n_bytes == 0) return MLST_OK;
     if (!text) return fail(h, MLST_E_INVALID, "NULL argument");
@@ -4541,6 +4560,7 @@ extern "C" int mlst_submit_fastq(mlst_handle* h, const uint8_t* text, uint64_t n
 
 extern "C" int mlst_submit_fastq_stream(mlst_handle* h, const uint8_t* text, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     if (n_reads_out) *n_reads_out = 0;
     if (n_bytes && !text) return fail(h, MLST_E_INVALID, "NULL argument");
     const u64 total = h->fq_carry_len + n_bytes;
@@ -4557,6 +4577,7 @@ extern "C" int mlst_submit_fastq_stream(mlst_handle* h, const uint8_t* text, uin
 
 extern "C" int mlst_submit_fastq_pair(mlst_handle* h, const uint8_t* text1, uint64_t n1, const uint8_t* text2, uint64_t n2, uint64_t* n_reads_out) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     if (n_reads_out) *n_reads_out = 0;
     if (n1 == 0 && n2 == 0) return MLST_OK;
     if (!text1 || !text2 || n1 == 0 || n2 == 0) return fail(h, MLST_E_INVALID, "mate files hold different numbers of records (one chunk is empty)");
@@ -4591,6 +4612,62 @@ static bool bgzf_block(const u8* p, u64 left, u64& total, u64& cdata_off, u64& c
     return true;
 }
 
+// ---- BGZF input, three stages on three streams (round 5).  Until round 4 a piece went copy -> inflate -> parse -> pass 1 on ONE
+// stream with four host synchronisations on the way: 3.8 + 9.5 + 4 ms per 1.07 GB of text one after the other.  Now call k
+//   (1) queues the copy of piece k on the copy stream and its inflate on the inflate stream (into a text slot, FQ_HEAD bytes
+//       from its start: the partial record the piece before leaves is not known yet and goes in front of it later),
+//   (2) finishes piece k - 1: waits for ITS inflate, parses it and queues its pass 1 on the engine's stream -- the host
+//       synchronisations of the parser wait for the parser's kernels only, while the inflate of piece k runs beside them,
+//   (3) waits for the copy of piece k (the caller owns `data` again on return).
+// The last call (final_chunk) finishes its own piece as well; every other entry that looks at the sample's state finishes a
+// piece that is still open first (bz_flush).  n_reads_out counts the records completed by the call (those of piece k - 1).
+#define FQ_HEAD (1ull << 20)      /* room in front of an inflated piece for the partial record of the piece before it */
+static int bz_mode(mlst_handle* h) {
+    if (h->bz_mode < 0) { const char* e = getenv("MLST_BGZF_PIPE"); h->bz_mode = (e && e[0] == '0') ? 0 : 1; }
+    return h->bz_mode;
+}
+// parse + pass 1 of the piece whose inflate was queued last; whole: no text follows it
+static int bz_finish(mlst_handle* h, bool whole, uint64_t* n_reads_out) {
+    if (n_reads_out) *n_reads_out = 0;
+    if (!h->bz_pend.on) return MLST_OK;
+    h->bz_pend.on = false;
+    mlst_handle::BzSlot& B = h->bz[h->bz_pend.slot];
+    HIPCHK(h, hipEventSynchronize(B.ev_inflated));
+    if (B.h_err[0]) { h->fq_carry_len = 0; return fail(h, MLST_E_INVALID, "corrupt deflate data in BGZF block %u of the chunk (code %u)", B.h_err[0] - 1, B.h_err[1]); }
+    const u64 carry = h->fq_carry_len;
+    if (carry + 256 > FQ_HEAD) { h->fq_carry_len = 0; return fail(h, MLST_E_LIMIT, "a FASTQ record of more than %llu bytes", (unsigned long long)(FQ_HEAD - 256)); }
+    u8* slot = h->d_fq_slot[h->bz_pend.tslot];
+    const u64 s0 = FQ_HEAD - carry, base = s0 & ~255ull, skip = s0 - base;      // the parser's 16-byte loads want an aligned start: filler up to the carry
+    if (carry) HIPCHK(h, hipMemcpyAsync(slot + s0, h->d_fq_carry, carry, hipMemcpyDeviceToDevice, h->stream));
+    if (skip) HIPCHK(h, hipMemsetAsync(slot + base, 'X', skip, h->stream));
+    h->d_fq_text = slot + base;
+    return fastq_pipeline(h, skip + carry + h->bz_pend.text_bytes, h->bz_pend.paired, whole, n_reads_out, 0, h->bz_pend.tslot, skip);
+}
+// a piece that is still open is finished (its trailing partial record stays in the carry, as after any non-final chunk)
+static int bz_flush(mlst_handle* h) { return h->bz_pend.on ? bz_finish(h, false, nullptr) : MLST_OK; }
+static void bz_free(mlst_handle* h) {
+    if (h->infl_stream) hipStreamSynchronize(h->infl_stream);
+    for (auto& B : h->bz) {
+        hipFree(B.d_comp); hipFree(B.d_blk); hipFree(B.d_err); if (B.h_err) hipHostFree(B.h_err);
+        if (B.ev_copied) hipEventDestroy(B.ev_copied); if (B.ev_inflated) hipEventDestroy(B.ev_inflated);
+        B = mlst_handle::BzSlot();
+    }
+    if (h->infl_stream) { hipStreamDestroy(h->infl_stream); h->infl_stream = nullptr; }
+    h->bz_pend.on = false;
+}
+// the inflate stream runs where the engine's own stream runs (mlst_set_cu_partition)
+static int bz_stream(mlst_handle* h) {
+    if (h->infl_stream) return MLST_OK;
+    if (h->cu_split <= 1) { HIPCHK(h, hipStreamCreateWithFlags(&h->infl_stream, hipStreamNonBlocking)); return MLST_OK; }
+    hipDeviceProp_t prop; HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+    const u32 n_cu = (u32)prop.multiProcessorCount;
+    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+    const u32 lo = (u32)((u64)n_cu * h->cu_part / h->cu_split), hi = (u32)((u64)n_cu * (h->cu_part + 1) / h->cu_split);
+    for (u32 c = lo; c < hi; c++) mask[c >> 5] |= 1u << (c & 31);
+    HIPCHK(h, hipExtStreamCreateWithCUMask(&h->infl_stream, (uint32_t)mask.size(), mask.data()));
+    return MLST_OK;
+}
+
 extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out,
                                       uint64_t* n_consumed_out) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
@@ -4599,8 +4676,10 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
     if (n_bytes && !data) return fail(h, MLST_E_INVALID, "NULL argument");
     if (n_bytes >= (1ull << 36)) return fail(h, MLST_E_LIMIT, "BGZF chunk too large");
     hipSetDevice(h->device);
+    const bool piped = bz_mode(h) != 0;
     std::vector<BgzfBlk> blks;
-    u64 text_bytes = h->fq_carry_len;
+    const u64 text_at = piped ? FQ_HEAD : h->fq_carry_len;      // where the first block's text goes in its slot
+    u64 text_bytes = text_at;
     for (u64 off = 0; off < n_bytes; ) {
         u64 total, coff, clen; u32 isize;
         if (!bgzf_block(data + off, n_bytes - off, total, coff, clen, isize)) {
@@ -4615,9 +4694,53 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
     }
     if (text_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
     if (n_consumed_out) *n_consumed_out = n_bytes;
+    if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
+    if (piped) {
+        uint64_t done = 0, n1 = 0;
+        if (blks.empty()) {      // nothing new: the open piece (if any) is finished; a last call also types what the carry holds
+            if (h->bz_pend.on) { int rc = bz_finish(h, final_chunk != 0, &n1); if (rc) return rc; done += n1; }
+            else if (final_chunk && h->fq_carry_len) {
+                { int rc = next_text_slot(h, h->fq_carry_len); if (rc) return rc; }
+                const u64 carry = h->fq_carry_len;
+                HIPCHK(h, hipMemcpyAsync(h->d_fq_text, h->d_fq_carry, carry, hipMemcpyDeviceToDevice, h->stream));
+                int rc = fastq_pipeline(h, carry, paired, true, &n1); if (rc) return rc; done += n1;
+            }
+            if (n_reads_out) *n_reads_out = done;
+            return MLST_OK;
+        }
+        { int rc = bz_stream(h); if (rc) return rc; }
+        if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        const int sl = h->bz_slot ^= 1;
+        mlst_handle::BzSlot& B = h->bz[sl];
+        if (!B.ev_copied) { HIPCHK(h, hipEventCreateWithFlags(&B.ev_copied, hipEventDisableTiming)); HIPCHK(h, hipEventCreateWithFlags(&B.ev_inflated, hipEventDisableTiming));
+                            HIPCHK(h, dmalloc(&B.d_err, (u64)16)); HIPCHK(h, hipHostMalloc((void**)&B.h_err, 64, hipHostMallocDefault)); }
+        // (the slot's last user, piece k - 2, has been finished: its inflate is over)
+        if (B.cap_comp < n_bytes) { hipFree(B.d_comp); B.d_comp = nullptr; HIPCHK(h, dmalloc(&B.d_comp, n_bytes + n_bytes / 8 + 16)); B.cap_comp = n_bytes + n_bytes / 8; }
+        if (B.cap_blk < blks.size()) { hipFree(B.d_blk); B.d_blk = nullptr; BgzfBlk* pb = nullptr; HIPCHK(h, dmalloc(&pb, (u64)blks.size() + blks.size() / 8)); B.d_blk = pb; B.cap_blk = blks.size() + blks.size() / 8; }
+        { int rc = next_text_slot(h, text_bytes + text_bytes / 16); if (rc) return rc; }
+        const int tslot = h->fq_slot;
+        HIPCHK(h, hipMemcpyAsync(B.d_comp, data, n_bytes, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(h, hipMemcpyAsync(B.d_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(h, hipEventRecord(B.ev_copied, h->copy_stream));
+        HIPCHK(h, hipStreamWaitEvent(h->infl_stream, B.ev_copied, 0));
+        HIPCHK(h, hipStreamWaitEvent(h->infl_stream, h->ev_packed[tslot], 0));      // the text slot's last reader (an event never recorded counts as complete)
+        HIPCHK(h, hipMemsetAsync(B.d_err, 0, 64, h->infl_stream));
+        { int rc = launch_inflate(h, B.d_comp, (u64)B.cap_comp + 16, (const BgzfBlk*)B.d_blk, (u32)blks.size(), h->d_fq_slot[tslot], B.d_err, nullptr, h->infl_stream); if (rc) return rc; }
+        HIPCHK(h, hipMemcpyAsync(B.h_err, B.d_err, 8, hipMemcpyDeviceToHost, h->infl_stream));
+        HIPCHK(h, hipEventRecord(B.ev_inflated, h->infl_stream));
+        // piece k - 1 while the GPU inflates piece k
+        int rc = MLST_OK;
+        if (h->bz_pend.on) { rc = bz_finish(h, false, &n1); done += n1; }
+        h->bz_pend.on = true; h->bz_pend.slot = sl; h->bz_pend.tslot = tslot; h->bz_pend.paired = paired; h->bz_pend.text_bytes = text_bytes - text_at;
+        if (!rc && final_chunk) { rc = bz_finish(h, true, &n1); done += n1; }
+        const hipError_t ce = hipStreamSynchronize(h->copy_stream);      // blks / data may be released by the caller after this
+        if (rc) { if (h->infl_stream) hipStreamSynchronize(h->infl_stream); h->bz_pend.on = false; return rc; }
+        HIPCHK(h, ce);
+        if (n_reads_out) *n_reads_out = done;
+        return MLST_OK;
+    }
     if (text_bytes == 0) return MLST_OK;
     { int rc = next_text_slot(h, text_bytes); if (rc) return rc; }      // (the inflate kernel writes it on the engine's stream: ordered behind its last reader)
-    if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
     if (h->fq_carry_len) HIPCHK(h, hipMemcpyAsync(h->d_fq_text, h->d_fq_carry, h->fq_carry_len, hipMemcpyDeviceToDevice, h->stream));
     if (!blks.empty()) {
         if (h->cap_bgzf < n_bytes) { hipFree(h->d_bgzf); h->d_bgzf = nullptr; HIPCHK(h, dmalloc(&h->d_bgzf, n_bytes + 16)); h->cap_bgzf = n_bytes; }
@@ -4642,6 +4765,7 @@ extern "C" int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data,
     if (produced) *produced = 0;
     if (!data || !out) return fail(h, MLST_E_INVALID, "NULL argument");
     hipSetDevice(h->device);
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     std::vector<BgzfBlk> blks; u64 text_bytes = 0;
     for (u64 off = 0; off < n_bytes; ) {
         u64 total, coff, clen; u32 isize;
@@ -4722,6 +4846,7 @@ static void note_sieve_window(mlst_handle* h, const Counters* c) {
 extern "C" int mlst_get_allele_stats(mlst_handle* h, int64_t* sum_score, uint32_t* n_hits, uint64_t* locus_len,
                                      uint64_t* locus_first, uint64_t* counters) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     hipSetDevice(h->device);
     Counters* c = nullptr;
     int rc = fetch_stats(h, &c); if (rc) return rc;
@@ -4742,6 +4867,7 @@ extern "C" int mlst_stats_flat_sizes(mlst_handle* h, uint64_t* n_sum, uint64_t* 
 }
 extern "C" int mlst_export_stats_device(mlst_handle* h, int64_t* d_sum, int64_t* d_min) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     hipSetDevice(h->device);
     int rc = check_overflow(h); if (rc) return rc;
     hipLaunchKernelGGL(k_export, dim3(256), dim3(256), 0, h->stream, h->d_E, (long long*)d_sum, (long long*)d_min);
@@ -4843,6 +4969,7 @@ static int pileup_launch(mlst_handle* h, const uint32_t* chosen, uint32_t n, uin
 
 extern "C" int mlst_pileup_device(mlst_handle* h, const uint32_t* chosen, uint32_t n, uint32_t* d_counts, uint64_t* n_cols_out) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     hipSetDevice(h->device);
     int rc = pileup_launch(h, chosen, n, d_counts, 0, n_cols_out); if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -4851,6 +4978,7 @@ extern "C" int mlst_pileup_device(mlst_handle* h, const uint32_t* chosen, uint32
 
 extern "C" int mlst_pileup(mlst_handle* h, const uint32_t* chosen, uint32_t n, uint32_t* counts) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     hipSetDevice(h->device);
     u64 ncols = 0;
     for (u32 k = 0; k < n; k++) { if (chosen[k] >= h->n_alleles) return fail(h, MLST_E_INVALID, "chosen allele out of range"); ncols += h->aoff[chosen[k] + 1] - h->aoff[chosen[k]]; }
@@ -4866,6 +4994,7 @@ extern "C" int mlst_pileup(mlst_handle* h, const uint32_t* chosen, uint32_t n, u
 extern "C" int mlst_consensus(mlst_handle* h, const uint32_t* chosen, uint32_t n, uint32_t mincov, char none_char,
                               uint8_t* out_seq, uint32_t* counts) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     if (!out_seq) return fail(h, MLST_E_INVALID, "out_seq is NULL");
     hipSetDevice(h->device);
     u64 ncols = 0;
@@ -4958,6 +5087,7 @@ extern "C" int mlst_typing_layout(mlst_handle* h, uint64_t* colbase, uint64_t* t
 // copies of statistics, choice and consensus into pinned memory.
 extern "C" int mlst_typing_choose_pileup(mlst_handle* h, int32_t penalty, uint32_t* d_counts) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     hipSetDevice(h->device);
     const u64 nl = h->n_loci, ncols = h->fixed_cols;
     u32* cnt = d_counts ? d_counts : h->d_auto_counts;
@@ -4997,6 +5127,7 @@ extern "C" int mlst_typing_finish(mlst_handle* h, uint32_t mincov, char none_cha
 // again with a buffer of at least that many columns (statistics and choice are not touched by the repeat).
 extern "C" int mlst_typing_choose_pileup_compact(mlst_handle* h, int32_t penalty, uint32_t* d_counts, uint64_t cap_cols) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     if (!d_counts || cap_cols == 0) return fail(h, MLST_E_INVALID, "mlst_typing_choose_pileup_compact needs a counts buffer");
     hipSetDevice(h->device);
     const u64 nl = h->n_loci;
@@ -5030,6 +5161,7 @@ extern "C" int mlst_typing_compact_info(mlst_handle* h, uint64_t* need_cols, uin
 }
 extern "C" int mlst_typing_enqueue(mlst_handle* h, int32_t penalty, uint32_t mincov, char none_char) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     hipSetDevice(h->device);
     // (the depth-capped pile-up may size its buffers on the way and is not a fast path: launched directly)
     const int gs = h->depth_cap ? 0 : graph_enter(h, h->g_typing, {(u64)(u32)penalty, (u64)mincov, (u64)(u8)none_char, (u64)(h->max_wpr <= 10)});
@@ -5053,8 +5185,10 @@ extern "C" int mlst_set_cu_partition(mlst_handle* h, uint32_t part, uint32_t n_p
     if (n_parts == 0 || part >= n_parts) return fail(h, MLST_E_INVALID, "CU partition %u of %u", part, n_parts);
     if (n_parts == 1 && h->cu_split == 1) return MLST_OK;      // the whole device already: keep the stream (a fresh one may share a hardware queue with another engine's)
     hipSetDevice(h->device);
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     drain_events(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->infl_stream) { hipStreamSynchronize(h->infl_stream); hipStreamDestroy(h->infl_stream); h->infl_stream = nullptr; }      // (re-created on the new share by the next BGZF piece)
     hipDeviceProp_t prop; HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
     const u32 n_cu = (u32)prop.multiProcessorCount;
     if (n_parts > n_cu) return fail(h, MLST_E_INVALID, "more CU partitions (%u) than CUs (%u)", n_parts, n_cu);
@@ -5098,6 +5232,7 @@ extern "C" int mlst_busy(mlst_handle* h) {
 extern "C" int mlst_set_stream(mlst_handle* h, void* stream) {
     if (!h) return MLST_E_INVALID;
     hipSetDevice(h->device);
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     drain_events(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->stream = stream ? (hipStream_t)stream : h->own_stream;
@@ -5107,6 +5242,7 @@ extern "C" int mlst_set_stream(mlst_handle* h, void* stream) {
 // mlst_typing_fetch / mlst_get_allele_stats)
 extern "C" int mlst_export_stats_device_async(mlst_handle* h, int64_t* d_sum, int64_t* d_min) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
+    { int rc_ = bz_flush(h); if (rc_) return rc_; }
     hipSetDevice(h->device);
     hipLaunchKernelGGL(k_export, dim3(256), dim3(256), 0, h->stream, h->d_E, (long long*)d_sum, (long long*)d_min);
     HIPCHK(h, hipGetLastError());
@@ -5265,4 +5401,4 @@ extern "C" int mlst_debug_route_realloc(mlst_handle* h, uint64_t pad_bytes) {
     if (pad_bytes && pad_bytes != ~0ull) { void* q = nullptr; HIPCHK(h, hipMalloc(&q, pad_bytes)); h->dbg_pads.push_back(q); }
     return MLST_OK;
 }
-extern "C" int mlst_synchronize(mlst_handle* h) { if (!h) return MLST_E_INVALID; hipSetDevice(h->device); HIPCHK(h, hipStreamSynchronize(h->stream)); return MLST_OK; }
+extern "C" int mlst_synchronize(mlst_handle* h) { if (!h) return MLST_E_INVALID; hipSetDevice(h->device); { int rc_ = bz_flush(h); if (rc_) return rc_; } HIPCHK(h, hipStreamSynchronize(h->stream)); return MLST_OK; }
