@@ -24,8 +24,11 @@ struct Bits {
     const uint8_t* in; uint64_t n, pos;
     uint64_t buf; int cnt;
 #if defined(__HIP_DEVICE_COMPILE__)
-    // one lane per stream (inflate_lane.h): a 256-byte window of the stream in LDS, refilled 256 bytes at a time by sixteen
-    // independent 16-byte loads (one memory round trip per ~100 symbols instead of one per three)
+    // one lane per stream (inflate_lane.h): a window of WIN bytes of the stream in LDS, refilled WIN bytes at a time by WIN / 16
+    // independent 16-byte loads (one memory round trip per ~50 symbols instead of one per three).  128 bytes since round 5
+    // (256 before): k_inflate_tok then leaves 10 KB of a CU's LDS to the kernels that run beside it (with 2 KB left the
+    // parser's workgroups, 16 bytes of LDS each, found room for two per CU and took 2.0 ms instead of 0.3).
+    enum { WIN = 128 };
     __attribute__((address_space(3))) uint64_t* win;      // (an LDS pointer by type: a generic one makes every read a FLAT load, which waits for the lane's outstanding global stores)
                                  // element j of this lane's window at win[j * 64] (lane-interleaved); nullptr: no window
     const uint8_t* win_at;       // the 16-byte aligned address the window starts at
@@ -47,19 +50,19 @@ MLST_HD inline void refill(Bits& b) {
         uint64_t w0, w1; unsigned sh;
         {   // (device code always brings a window -- inflate_lane.h is its only user; a second path that loads from global memory
             // here made the compiler wait at the join for EVERYTHING the lane had in flight, its token stores included)
-            const bool need = p + 16 > b.win_at + 256 || p < b.win_at;
+            const bool need = p + 16 > b.win_at + Bits::WIN || p < b.win_at;
             if (__ballot(need)) {                      // every lane that is here moves its window up: the waits coincide
                 const uint8_t* a0 = p - ((uintptr_t)p & 15u);
                 typedef unsigned int v4 __attribute__((ext_vector_type(4)));
-                v4 v[16];
+                v4 v[Bits::WIN / 16];
                 #pragma unroll
-                for (int j = 0; j < 16; j++) {
+                for (int j = 0; j < Bits::WIN / 16; j++) {
                     const uint8_t* a = a0 + 16 * j;
                     if (a + 16 > b.buf_end) a = b.buf_end - 16;      // (behind the buffer: bytes no code of the stream reaches)
                     v[j] = *reinterpret_cast<const v4*>(a);
                 }
                 #pragma unroll
-                for (int j = 0; j < 16; j++) {
+                for (int j = 0; j < Bits::WIN / 16; j++) {
                     b.win[(2 * j) * 64] = (uint64_t)v[j].x | ((uint64_t)v[j].y << 32);
                     b.win[(2 * j + 1) * 64] = (uint64_t)v[j].z | ((uint64_t)v[j].w << 32);
                 }

@@ -29,6 +29,7 @@ typedef unsigned char u8;
 
 struct Blk { u64 in_off, out_off; u32 in_len, out_len; };      // one BGZF block: its deflate stream in the compressed buffer, its text in the output
 enum : u32 { TAG_LIT = 0u, TAG_RAW = 1u, TAG_MATCH = 2u, TAG_OPERAND = 3u, TOK_OVERFLOW = 0xFFFFFFFFu };
+enum : u32 { LIT_BASE = 0xFF00u };      // phase 2: a 16-bit pointer >= LIT_BASE is a literal, its byte in the low 8 bits
 // token (tag in bits 30-31): literal = the byte; match = (length - 3) << 16 | (distance - 1); stored run = its length (16 bits),
 // followed by an OPERAND word: where the run starts, in bytes from the start of the block's deflate stream
 
@@ -133,6 +134,7 @@ __device__ __attribute__((always_inline)) inline void tok_body(const u8* comp, c
         if (i >= n_blk) continue;
         const Blk B = blk[i];
         const u32 want = B.out_len;
+        if (want > LIT_BASE) { n_tok[i] = (u32)TOK_OVERFLOW; continue; }      // (phase 2 keeps literals in the pointers' top 256 values; bgzip's blocks hold 65,280 bytes)
         OutTok o; o.tok = tok + (u64)i * tok_cap; o.nt = 0; o.cap = tok_cap; o.op = 0; o.in_base = comp + B.in_off; o.over = false;
         int rc = mlst_inflate::inflate_stream<OutTok, true>(comp + B.in_off, (u64)B.in_len, o, (u64)want, &tabs[lane], win + lane, comp_end);
         if (rc == mlst_inflate::OK && o.op != (u64)want) rc = mlst_inflate::E_SHORT;
@@ -142,15 +144,23 @@ __device__ __attribute__((always_inline)) inline void tok_body(const u8* comp, c
 }
 
 // ---- phase 2: workgroup = block.  LDS: ptr[65536] (128 KB) + the scan's partial sums.
+// Round 5: a literal is kept IN its pointer (LIT_BASE | byte: the top 256 pointer values, free because a block that takes
+// this path holds at most LIT_BASE bytes), so a pointer that reaches a literal takes the byte with it and is final at once;
+// nothing is stored to or gathered from global memory before the end, where the text leaves the LDS in 16-byte stores, and
+// the newlines of every 2^nl_shift-byte cell of the text buffer are counted on the way (the FASTQ parser's first pass).
 __device__ __attribute__((always_inline)) inline u32 wave_incl_scan(u32 v) {
     #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const u32 y = (u32)__shfl_up((int)v, o); if ((int)(threadIdx.x & 63u) >= o) v += y; }
     return v;
 }
+__device__ __attribute__((always_inline)) inline u32 nl_count4(u32 w) {      // newlines among the four bytes of w
+    const u32 y = w ^ 0x0A0A0A0Au;
+    return (u32)__popc(~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu));
+}
 template <int NT>      // NT = threads per workgroup (a multiple of 64, at most 1024)
 __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, const Blk* blk, u32 n_blk, u32 err_base,
                                                                const u32* tok, u32 tok_cap, const u32* n_tok, u8* out, u32* err,
-                                                               u16* ptr, u32* s_part, u32* s_flag) {
+                                                               u16* ptr, u32* s_part, u32* s_nl /* 20 */, u32* nl, u32 nl_shift) {
     constexpr int NW = NT / 64;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (u32 b = blockIdx.x; b < n_blk; b += gridDim.x) {
@@ -161,11 +171,12 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
         u8* O = out + B.out_off;
         const u8* I = comp + B.in_off;
         const u32 total = B.out_len;
-#if defined(MLST_PTR_TRACE)      // profiling builds: cycles per phase, summed over the blocks, in err[2..5] (fill, jumping, gather, rounds)
+#if defined(MLST_PTR_TRACE)      // profiling builds: cycles per phase, summed over the blocks, in err[2..5] (fill, jumping, write-out, rounds)
         const unsigned long long tr0 = __builtin_readcyclecounter();
 #endif
-        // ---- fill: tiles of NT tokens, their output offsets by a scan, pointers (and literal bytes) written per token
-        u32 base = 0;
+        if (tid < 20) s_nl[tid] = 0;
+        // ---- fill: tiles of NT tokens, their output offsets by a scan, pointers (or literal bytes) written per token
+        u32 base = 0; bool bad = false;
         u32 t_next = tid < nt ? T[tid] : 0u;                             // (the next tile's tokens are on their way while this one is worked on)
         for (u32 t0 = 0; t0 < nt; t0 += NT) {
             const u32 ti = t0 + tid;
@@ -190,10 +201,10 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
                 if (tag == TAG_MATCH) {
                     const u32 dist = (t & 0x7FFFu) + 1u;
                     const u32 n0 = len < 32u ? len : 32u;      // (longer ones -- quality runs -- are finished by the whole wave below)
-                    if (dist > dst) { done = len; if (atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_DISTANCE); }
+                    if (dist > dst) { done = len; bad = true; if (atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_DISTANCE); }
                     else { for (u32 k = 0; k < n0; k++) ptr[dst + k] = (u16)(dst + k - dist); done = n0; }
-                } else if (tag == TAG_LIT) { ptr[dst] = (u16)dst; O[dst] = (u8)t; done = 1; }
-            } else if (len) { done = len; if (atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_OUTPUT); }
+                } else if (tag == TAG_LIT) { ptr[dst] = (u16)(LIT_BASE | (t & 0xFFu)); done = 1; }
+            } else if (len) { done = len; bad = true; if (atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_OUTPUT); }
             const u32 nxt = (tag == TAG_RAW && ti + 1 < nt) ? T[ti + 1] : 0u;      // (the operand of a stored run)
             u64 todo = __ballot(done < len);
             while (todo) {
@@ -206,28 +217,33 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
                 } else {      // stored run: its bytes straight from the compressed buffer
                     const u32 src = t_nxt & 0x3FFFFFFFu;
                     if ((t_nxt >> 30) == TAG_OPERAND && (u64)src + tl <= (u64)B.in_len)
-                        for (u32 j = lane; j < tl; j += 64) { ptr[td + j] = (u16)(td + j); O[td + j] = I[src + j]; }
-                    else if (lane == 0 && atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_STORED);
+                        for (u32 j = lane; j < tl; j += 64) ptr[td + j] = (u16)(LIT_BASE | I[src + j]);
+                    else { bad = true; if (lane == 0 && atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_STORED); }
                 }
             }
             base += tile_total;
             __syncthreads();
         }
-        if (base != total) { if (tid == 0 && atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_SHORT); __syncthreads(); continue; }
-        // ---- pointer jumping: every pointer ends at a literal (a byte that points at itself).  Thread t owns the byte PAIRS
-        // 2 (t + NT j) (one 32-bit read and write for two pointers; only their targets are read one by one); `live` has a bit per
-        // j whose pointers are not both known to rest on a literal yet: a pair drops out as soon as they do.  (The quality lines of a
-        // FASTQ block copy each other record after record: half the bytes of a block sit ~200 links deep and stay for 8-9 rounds.)
+        if (base != total) bad = true;
+        // a block with an inconsistent token (flagged above) is not jumped or written out: its pointers may be stale
+        if (__syncthreads_or(bad)) { if (tid == 0 && atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_SHORT); continue; }
+        // ---- pointer jumping: every pointer ends as a literal.  Thread t owns the byte PAIRS 2 (t + NT j) (one 32-bit read and
+        // write for two pointers; only their targets are read one by one); `live` has a bit per j whose pair still holds a
+        // pointer.  (The quality lines of a FASTQ block copy each other record after record: half the bytes of a block sit
+        // ~200 links deep and stay for 8-9 rounds.)
 #if defined(MLST_PTR_TRACE)
         const unsigned long long tr1 = __builtin_readcyclecounter(); int tr_rounds = 0;
 #endif
         u32* const ptr2 = reinterpret_cast<u32*>(ptr);
         const u32 n_pairs = (total + 1u) >> 1;
-        if ((total & 1u) && tid == 0) ptr[total] = (u16)total;          // (the odd block's last pair: its second half points at itself)
+        if (tid == 0) { ptr[total] = (u16)LIT_BASE; ptr[total + 1] = (u16)LIT_BASE; }      // (the odd block's last pair: its second half is no pointer; total <= LIT_BASE)
         __syncthreads();
         u32 live = 0;
-        for (u32 j = 0; tid + j * NT < n_pairs; j++) live |= 1u << j;
-        for (int round = 0; round < 17; round++) {
+        for (u32 j = 0; tid + j * NT < n_pairs; j++) {
+            const u32 w = ptr2[tid + j * NT];
+            if ((w & 0xFFFFu) < LIT_BASE || (w >> 16) < LIT_BASE) live |= 1u << j;
+        }
+        for (int round = 0; round < 18; round++) {
             u32 next = 0;
             for (u32 m = live; __ballot(m != 0); ) {                    // (every lane walks its own set bits, four pairs at a time: their LDS reads are independent)
                 u32 pj[4], w[4], r0[4], r1[4]; bool on[4];
@@ -238,14 +254,20 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
                     m &= m - 1;
                 }
                 #pragma unroll
-                for (int k = 0; k < 4; k++) w[k] = on[k] ? ptr2[tid + pj[k] * NT] : 0u;
+                for (int k = 0; k < 4; k++) w[k] = on[k] ? ptr2[tid + pj[k] * NT] : (LIT_BASE | (LIT_BASE << 16));
                 #pragma unroll
-                for (int k = 0; k < 4; k++) { r0[k] = ptr[w[k] & 0xFFFFu]; r1[k] = ptr[w[k] >> 16]; }
+                for (int k = 0; k < 4; k++) {      // (a half that is a literal already reads slot 0 and keeps its value)
+                    const u32 q0 = w[k] & 0xFFFFu, q1 = w[k] >> 16;
+                    r0[k] = ptr[q0 < LIT_BASE ? q0 : 0u]; r1[k] = ptr[q1 < LIT_BASE ? q1 : 0u];
+                }
                 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const u32 q0 = w[k] & 0xFFFFu, q1 = w[k] >> 16;
-                    // (a pointer whose target is a literal -- or that is one -- has arrived: r == q)
-                    if (on[k] && (r0[k] != q0 || r1[k] != q1)) { ptr2[tid + pj[k] * NT] = r0[k] | (r1[k] << 16); next |= 1u << pj[k]; }
+                    const u32 n0 = q0 < LIT_BASE ? r0[k] : q0, n1 = q1 < LIT_BASE ? r1[k] : q1;
+                    if (on[k]) {
+                        ptr2[tid + pj[k] * NT] = n0 | (n1 << 16);
+                        if (n0 < LIT_BASE || n1 < LIT_BASE) next |= 1u << pj[k];
+                    }
                 }
             }
             live = next;
@@ -258,17 +280,32 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
 #if defined(MLST_PTR_TRACE)
         const unsigned long long tr2 = __builtin_readcyclecounter();
 #endif
-        // ---- gather (the literal bytes were stored in the fill phase: visible to the workgroup behind the barriers above),
-        // eight independent loads in flight per thread
-        for (u32 j0 = 0; tid + j0 * NT < total; j0 += 8) {
-            u32 q[8]; u8 v[8];
-            #pragma unroll
-            for (int k = 0; k < 8; k++) { const u32 p = tid + (j0 + k) * NT; q[k] = p < total ? ptr[p] : 0u; }
-            #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = O[q[k]];
-            #pragma unroll
-            for (int k = 0; k < 8; k++) { const u32 p = tid + (j0 + k) * NT; if (p < total && q[k] != p) O[p] = v[k]; }
+        // ---- write-out: sixteen bytes per thread and turn (two 16-byte LDS reads, one 16-byte store) where the block's text starts
+        // on a 16-byte boundary (every block of a bgzip'd file does), byte by byte otherwise; newlines counted per cell
+        typedef unsigned int v4 __attribute__((ext_vector_type(4)));
+        const u64 cell0 = B.out_off >> nl_shift;
+        u32 n16 = 0;
+        if ((((uintptr_t)O) & 15u) == 0) {
+            n16 = total >> 4;
+            const v4* p4 = reinterpret_cast<const v4*>(ptr);
+            for (u32 c = tid; c < n16; c += NT) {
+                const v4 a = p4[2 * c], e = p4[2 * c + 1];
+                v4 q;
+                q.x = __builtin_amdgcn_perm(a.y, a.x, 0x06040200u); q.y = __builtin_amdgcn_perm(a.w, a.z, 0x06040200u);
+                q.z = __builtin_amdgcn_perm(e.y, e.x, 0x06040200u); q.w = __builtin_amdgcn_perm(e.w, e.z, 0x06040200u);
+                __builtin_nontemporal_store(q, reinterpret_cast<v4*>(O + 16 * c));
+                if (nl) {
+                    const u32 cnt = nl_count4(q.x) + nl_count4(q.y) + nl_count4(q.z) + nl_count4(q.w);
+                    if (cnt) atomicAdd(&s_nl[(u32)(((B.out_off + 16ull * c) >> nl_shift) - cell0)], cnt);
+                }
+            }
         }
+        for (u32 p = n16 * 16 + tid; p < total; p += NT) {
+            const u8 c = (u8)ptr[p]; O[p] = c;
+            if (nl && c == (u8)'\n') atomicAdd(&s_nl[(u32)(((B.out_off + p) >> nl_shift) - cell0)], 1u);
+        }
+        __syncthreads();
+        if (nl && tid < 20 && s_nl[tid]) atomicAdd(&nl[cell0 + tid], s_nl[tid]);
         __syncthreads();
 #if defined(MLST_PTR_TRACE)
         if (tid == 0) { const unsigned long long tr3 = __builtin_readcyclecounter();

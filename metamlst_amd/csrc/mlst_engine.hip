@@ -1178,16 +1178,17 @@ __global__ __launch_bounds__(64) void k_inflate_tok(const u8* __restrict__ comp,
                                                     u32* __restrict__ n_tok, u32* __restrict__ err) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ mlst_inflate::Tables s_tb[64];
-    __shared__ unsigned long s_win[32 * 64];       // 256 bytes of every lane's stream, lane-interleaved 8-byte words (inflate_dev.h: Bits::win)
+    __shared__ unsigned long s_win[(mlst_inflate::Bits::WIN / 8) * 64];       // WIN bytes of every lane's stream, lane-interleaved 8-byte words (inflate_dev.h: Bits::win)
     inflate_lane::tok_body(comp, comp + comp_bytes, blk, n_blk, err_base, tok, INFL_TOK_CAP, n_tok, err, s_tb, s_win);
 #endif
 }
+// nl (optional): newlines per 2^nl_shift bytes of the text buffer (cell = offset in `out` >> nl_shift; nl_shift >= 12), added up as the text is written
 __global__ __launch_bounds__(1024) void k_inflate_ptr(const u8* __restrict__ comp, const BgzfBlk* __restrict__ blk, u32 n_blk, u32 err_base, const u32* __restrict__ tok,
-                                                      const u32* __restrict__ n_tok, u8* __restrict__ out, u32* __restrict__ err) {
+                                                      const u32* __restrict__ n_tok, u8* __restrict__ out, u32* __restrict__ err, u32* __restrict__ nl, u32 nl_shift) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) u16 s_ptr[65536];
-    __shared__ u32 s_part[16]; __shared__ u32 s_flag;
-    inflate_lane::ptr_body<1024>(comp, blk, n_blk, err_base, tok, INFL_TOK_CAP, n_tok, out, err, s_ptr, s_part, &s_flag);
+    __shared__ u32 s_part[16]; __shared__ u32 s_nl[20];
+    inflate_lane::ptr_body<1024>(comp, blk, n_blk, err_base, tok, INFL_TOK_CAP, n_tok, out, err, s_ptr, s_part, s_nl, nl, nl_shift);
 #endif
 }
 // ------------------------------------------------------------------ FASTQ text -> packed reads (GPU parser)
@@ -1221,19 +1222,41 @@ __global__ __launch_bounds__(256) void k_fq_count(const u8* __restrict__ text, u
     __syncthreads();
     if (threadIdx.x == 0) blk_count[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
 }
-// pass B: exclusive scan of the block counts (one workgroup; n_blocks is small: 4 GB of text = 1 M blocks)
+// pass B: exclusive scan of the block counts, in place (one workgroup; 4 GB of text = 1 M blocks).  4,096 counts per turn:
+// four per thread, a wave scan, the waves' totals through LDS.  (Until round 5 every thread walked a range of its own:
+// 64 cache lines per load instruction, 2.1 ms for the 262 k blocks of a 1 GB piece.)
 __global__ __launch_bounds__(1024) void k_fq_scan(u32* __restrict__ blk_count, u32 n_blocks, u64* __restrict__ n_lines_out, u64 n_bytes, const u8* __restrict__ text, int count_partial) {
-    __shared__ u64 s_part[1024];
-    u32 per = (n_blocks + 1023) / 1024; u32 lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
-    u64 sum = 0; for (u32 i = lo; i < hi; i++) sum += blk_count[i];
-    s_part[threadIdx.x] = sum;
+    __shared__ u32 s_w[16]; __shared__ u64 s_carry;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    if (threadIdx.x == 0) { u64 run = 0; for (int i = 0; i < 1024; i++) { u64 t = s_part[i]; s_part[i] = run; run += t; }
-                            // a last line without a trailing newline still counts as a line (unless more text follows in the next chunk)
-                            *n_lines_out = run + ((count_partial && n_bytes > 0 && text[n_bytes - 1] != '\n') ? 1 : 0); }
-    __syncthreads();
-    u64 run = s_part[threadIdx.x];
-    for (u32 i = lo; i < hi; i++) { u32 t = blk_count[i]; blk_count[i] = (u32)run; run += t; }     // < 2^32 lines per chunk (checked on the host)
+    for (u32 i0 = 0; i0 < n_blocks; i0 += 4096) {
+        const u32 i = i0 + tid * 4;
+        u32 v[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i + (u32)k < n_blocks ? blk_count[i + k] : 0u;
+        const u32 sum = v[0] + v[1] + v[2] + v[3], inc = wave_incl_scan_dpp(sum);
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        u32 before = 0, tile = 0;
+        for (u32 w = 0; w < 16; w++) { const u32 x = s_w[w]; if (w < wv) before += x; tile += x; }
+        u64 run = s_carry + before + inc - sum;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { if (i + (u32)k < n_blocks) blk_count[i + k] = (u32)run; run += v[k]; }      // < 2^32 lines per chunk (checked on the host)
+        __syncthreads();
+        if (tid == 0) s_carry += tile;
+        __syncthreads();
+    }
+    // a last line without a trailing newline still counts as a line (unless more text follows in the next chunk)
+    if (tid == 0) *n_lines_out = s_carry + ((count_partial && n_bytes > 0 && text[n_bytes - 1] != '\n') ? 1 : 0);
+}
+// newlines of the blocks the two-kernel inflate left to k_inflate (only[b] == TOK_OVERFLOW), added to the cells k_inflate_ptr counts into
+__global__ __launch_bounds__(256) void k_nl_blocks(const BgzfBlk* __restrict__ blk, u32 n_blk, const u32* __restrict__ only, const u8* __restrict__ out, u32* __restrict__ nl, u32 nl_shift) {
+    for (u32 b = blockIdx.x; b < n_blk; b += gridDim.x) {
+        if (only[b] != (u32)inflate_lane::TOK_OVERFLOW) continue;
+        const BgzfBlk B = blk[b];
+        for (u32 p = threadIdx.x; p < B.out_len; p += 256) if (out[B.out_off + p] == (u8)'\n') atomicAdd(&nl[(B.out_off + p) >> nl_shift], 1u);
+    }
 }
 // pass C: start offset of every line: line 0 starts at 0, line k+1 starts after the k-th newline.  A thread takes 16 bytes
 // (FQ_BLOCK = 256 threads x 16), the newline counts are scanned over the workgroup once.
@@ -3363,7 +3386,7 @@ struct mlst_handle {
     // (or has been) and has not been parsed yet.
     struct BzSlot { u8* d_comp = nullptr; u64 cap_comp = 0; void* d_blk = nullptr; u64 cap_blk = 0; hipEvent_t ev_copied = nullptr, ev_inflated = nullptr; u32* d_err = nullptr; u32* h_err = nullptr; };
     BzSlot bz[2]; int bz_slot = 0, bz_mode = -1; hipStream_t infl_stream = nullptr;
-    struct { bool on = false; int slot = 0, tslot = 0, paired = 0; u64 text_bytes = 0; } bz_pend;
+    struct { bool on = false, counted = false; int slot = 0, tslot = 0, paired = 0; u64 text_bytes = 0; } bz_pend;
     u32 depth_cap = 0; u64* d_capbuf = nullptr; u64 cap_capcols = 0;      // depth-capped pile-up (mlst_set_depth_cap): lo, hi, thr (u64 each) and cnt (u32) per column
     u32* d_counts = nullptr; u64 cap_counts = 0;
     // device-side typing (mlst_typing_enqueue / mlst_typing_fetch): fixed column layout, one slot of loc_maxlen columns per locus
@@ -3378,6 +3401,7 @@ struct mlst_handle {
     // buffer's last chunk has been packed (h2d_overlapped)
     hipStream_t copy_stream = nullptr; hipEvent_t stage_done = nullptr;
     u8* d_fq_slot[2] = {nullptr, nullptr}; u64 cap_fq_slot[2] = {0, 0}; hipEvent_t ev_packed[2] = {nullptr, nullptr}; int fq_slot = 0;
+    u32* d_fq_nl[2] = {nullptr, nullptr};      // newlines per FQ_BLOCK bytes of a text slot, counted by the inflate (k_inflate_ptr) for the parser
     int cu_split = 1, cu_part = 0;              // mlst_set_cu_partition: the engine's own stream runs on CUs [part, part + 1) * n_cu / split
     hipStream_t own_stream = nullptr;           // the stream created by mlst_create (h->stream may be a caller's stream: mlst_set_stream)
     u32* d_dist = nullptr; u8* d_query = nullptr; u64 cap_dist = 0, cap_query = 0;
@@ -3557,7 +3581,7 @@ extern "C" void mlst_destroy(mlst_handle* h) {
     if (h->stage_done) hipEventDestroy(h->stage_done);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     hipFree(h->d_cand); hipFree(h->d_in_bases); hipFree(h->d_in_quals); hipFree(h->d_in_off);
-    hipFree(h->d_fq_slot[0]); hipFree(h->d_fq_slot[1]); hipFree(h->d_fq_blk); hipFree(h->d_fq_lines); hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); hipFree(h->d_fq_meta);
+    hipFree(h->d_fq_slot[0]); hipFree(h->d_fq_slot[1]); hipFree(h->d_fq_nl[0]); hipFree(h->d_fq_nl[1]); hipFree(h->d_fq_blk); hipFree(h->d_fq_lines); hipFree(h->d_fq_soff); hipFree(h->d_fq_qoff); hipFree(h->d_fq_meta);
     hipFree(h->d_bgzf); hipFree(h->d_bgzf_blk); hipFree(h->d_fq_carry); h->d_bgzf = nullptr; h->d_bgzf_blk = nullptr; h->d_fq_carry = nullptr; h->cap_bgzf = h->cap_bgzf_blk = h->cap_fq_carry = h->fq_carry_len = 0;
     hipFree(h->d_packed); hipFree(h->d_qrows); hipFree(h->d_lens); hipFree(h->d_counts); hipFree(h->d_dist); hipFree(h->d_query);
     for (auto* g : {&h->g_submit, &h->g_typing}) if (g->exec) hipGraphExecDestroy(g->exec);
@@ -4305,6 +4329,7 @@ static int next_text_slot(mlst_handle* h, u64 bytes) {
     if (h->cap_fq_slot[slot] < bytes) {
         HIPCHK(h, hipEventSynchronize(h->ev_packed[slot]));      // (an event never recorded counts as complete)
         hipFree(h->d_fq_slot[slot]); h->d_fq_slot[slot] = nullptr; HIPCHK(h, dmalloc(&h->d_fq_slot[slot], bytes + 16)); h->cap_fq_slot[slot] = bytes;
+        hipFree(h->d_fq_nl[slot]); h->d_fq_nl[slot] = nullptr; HIPCHK(h, dmalloc(&h->d_fq_nl[slot], bytes / 4096 + 8));
     }
     h->d_fq_text = h->d_fq_slot[slot];
     return MLST_OK;
@@ -4315,14 +4340,19 @@ static int next_text_slot(mlst_handle* h, u64 bytes) {
 // pair_boundary != 0 (whole text only): the text is two mate files back to back, the second starting at that byte; both
 // must hold the same number of records, which are then interleaved (k_fq_records) and submitted as pairs.
 // tslot: the text slot the chunk sits in (-1: the current one); skip: bytes of filler in front of the first line (see k_fq_lines).
-static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, uint64_t* n_reads_out, u64 pair_boundary = 0, int tslot = -1, u64 skip = 0) {
+// ext_blk (optional): the newline counts per FQ_BLOCK bytes come with the text (the inflate counted them while writing it) except for
+// the first count_bytes bytes (a multiple of FQ_BLOCK: the filler and the partial record in front of an inflated piece).
+static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, uint64_t* n_reads_out, u64 pair_boundary = 0, int tslot = -1, u64 skip = 0,
+                          u32* ext_blk = nullptr, u64 count_bytes = 0) {
     if (tslot < 0) tslot = h->fq_slot;
     const u64 n_blocks = (n_bytes + FQ_BLOCK - 1) / FQ_BLOCK;
-    if (h->cap_fq_blk < n_blocks) { hipFree(h->d_fq_blk); h->d_fq_blk = nullptr; HIPCHK(h, dmalloc(&h->d_fq_blk, n_blocks + 1)); h->cap_fq_blk = n_blocks; }
+    if (!ext_blk && h->cap_fq_blk < n_blocks) { hipFree(h->d_fq_blk); h->d_fq_blk = nullptr; HIPCHK(h, dmalloc(&h->d_fq_blk, n_blocks + 1)); h->cap_fq_blk = n_blocks; }
+    u32* const blk = ext_blk ? ext_blk : h->d_fq_blk;
     HIPCHK(h, hipMemsetAsync(h->d_fq_meta, 0, 16, h->stream));
     Prof pf(h, 6);
-    hipLaunchKernelGGL(k_fq_count, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_blk);
-    hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, h->stream, h->d_fq_blk, (u32)n_blocks, h->d_fq_meta, (u64)n_bytes, h->d_fq_text, whole ? 1 : 0);
+    if (!ext_blk) hipLaunchKernelGGL(k_fq_count, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, blk);
+    else if (count_bytes) hipLaunchKernelGGL(k_fq_count, dim3((u32)(count_bytes / FQ_BLOCK)), dim3(256), 0, h->stream, h->d_fq_text, (u64)count_bytes, blk);
+    hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(1024), 0, h->stream, blk, (u32)n_blocks, h->d_fq_meta, (u64)n_bytes, h->d_fq_text, whole ? 1 : 0);
     u64 n_lines = 0;
     HIPCHK(h, hipMemcpyAsync(&n_lines, h->d_fq_meta, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -4330,7 +4360,7 @@ static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, u
     if (whole && n_lines % 4 != 0) return fail(h, MLST_E_INVALID, "FASTQ chunk holds %llu lines: not a whole number of 4-line records", (unsigned long long)n_lines);
     const u64 n_reads = n_lines / 4;
     if (h->cap_fq_lines < n_lines + 2) { hipFree(h->d_fq_lines); h->d_fq_lines = nullptr; HIPCHK(h, dmalloc(&h->d_fq_lines, n_lines + 2)); h->cap_fq_lines = n_lines + 2; }
-    hipLaunchKernelGGL(k_fq_lines, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, h->d_fq_blk, h->d_fq_lines, skip);
+    hipLaunchKernelGGL(k_fq_lines, dim3((u32)n_blocks), dim3(256), 0, h->stream, h->d_fq_text, (u64)n_bytes, blk, h->d_fq_lines, skip);
     h->fq_carry_len = 0;
     if (!whole) {      // text behind the last whole record waits for the next chunk
         u64 end_off = 0;
@@ -4501,11 +4531,13 @@ extern "C" int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, c
 // most INFL_PASS blocks (the token buffer holds 96 KB per block of a pass), with the blocks whose tokens did not fit left to
 // 1 = the one-wave-per-block kernel of csrc/inflate_wave.h.
 #define INFL_PASS 16384u
-static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padded, const BgzfBlk* d_blk, u32 n_blk, u8* d_out, u32* d_err, unsigned long long* d_st, hipStream_t st = nullptr) {
+// d_nl (optional; two-kernel path only): newline counts per FQ_BLOCK bytes of d_out, added up while the text is written (zeroed by the caller)
+static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padded, const BgzfBlk* d_blk, u32 n_blk, u8* d_out, u32* d_err, unsigned long long* d_st, hipStream_t st = nullptr, u32* d_nl = nullptr) {
     if (n_blk == 0) return MLST_OK;
     if (!st) st = h->stream;
     if (!h->inflate_mode) { const char* e = getenv("MLST_INFLATE_MODE"); h->inflate_mode = e ? atoi(e) : 2; if (h->inflate_mode != 1 && h->inflate_mode != 2) h->inflate_mode = 2; }
     if (h->inflate_mode == 1 || d_st) {
+        if (d_nl) return fail(h, MLST_E_INVALID, "newline counts come with the two-kernel inflate only");
         hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n_blk + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk, n_blk, d_out, d_err, d_st, (const u32*)nullptr, 0u);
         return MLST_OK;
     }
@@ -4519,8 +4551,9 @@ static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padde
     for (u32 at = 0; at < n_blk; at += pass) {
         const u32 n = std::min(pass, n_blk - at);
         hipLaunchKernelGGL(k_inflate_tok, dim3((n + 63) / 64), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk + at, n, at, h->d_itok, h->d_intok, d_err);
-        hipLaunchKernelGGL(k_inflate_ptr, dim3(std::min(n, 4096u)), dim3(1024), 0, st, d_comp, d_blk + at, n, at, (const u32*)h->d_itok, (const u32*)h->d_intok, d_out, d_err);
+        hipLaunchKernelGGL(k_inflate_ptr, dim3(std::min(n, 4096u)), dim3(1024), 0, st, d_comp, d_blk + at, n, at, (const u32*)h->d_itok, (const u32*)h->d_intok, d_out, d_err, d_nl, 12u);
         hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk + at, n, d_out, d_err, (unsigned long long*)nullptr, (const u32*)h->d_intok, at);
+        if (d_nl) hipLaunchKernelGGL(k_nl_blocks, dim3(std::min(n, 2048u)), dim3(256), 0, st, d_blk + at, n, (const u32*)h->d_intok, (const u8*)d_out, d_nl, 12u);
     }
     return MLST_OK;
 }
@@ -4637,11 +4670,13 @@ static int bz_finish(mlst_handle* h, bool whole, uint64_t* n_reads_out) {
     const u64 carry = h->fq_carry_len;
     if (carry + 256 > FQ_HEAD) { h->fq_carry_len = 0; return fail(h, MLST_E_LIMIT, "a FASTQ record of more than %llu bytes", (unsigned long long)(FQ_HEAD - 256)); }
     u8* slot = h->d_fq_slot[h->bz_pend.tslot];
-    const u64 s0 = FQ_HEAD - carry, base = s0 & ~255ull, skip = s0 - base;      // the parser's 16-byte loads want an aligned start: filler up to the carry
+    // the parser's blocks are the cells the inflate counted newlines in (FQ_BLOCK bytes from the slot's start on): filler up to the carry
+    const u64 s0 = FQ_HEAD - carry, base = s0 & ~(u64)(FQ_BLOCK - 1), skip = s0 - base;
     if (carry) HIPCHK(h, hipMemcpyAsync(slot + s0, h->d_fq_carry, carry, hipMemcpyDeviceToDevice, h->stream));
     if (skip) HIPCHK(h, hipMemsetAsync(slot + base, 'X', skip, h->stream));
     h->d_fq_text = slot + base;
-    return fastq_pipeline(h, skip + carry + h->bz_pend.text_bytes, h->bz_pend.paired, whole, n_reads_out, 0, h->bz_pend.tslot, skip);
+    u32* counts = h->bz_pend.counted ? h->d_fq_nl[h->bz_pend.tslot] + base / FQ_BLOCK : nullptr;
+    return fastq_pipeline(h, skip + carry + h->bz_pend.text_bytes, h->bz_pend.paired, whole, n_reads_out, 0, h->bz_pend.tslot, skip, counts, FQ_HEAD - base);
 }
 // a piece that is still open is finished (its trailing partial record stays in the carry, as after any non-final chunk)
 static int bz_flush(mlst_handle* h) { return h->bz_pend.on ? bz_finish(h, false, nullptr) : MLST_OK; }
@@ -4655,16 +4690,11 @@ static void bz_free(mlst_handle* h) {
     if (h->infl_stream) { hipStreamDestroy(h->infl_stream); h->infl_stream = nullptr; }
     h->bz_pend.on = false;
 }
-// the inflate stream runs where the engine's own stream runs (mlst_set_cu_partition)
+// The inflate stream is NOT tied to the engine's CU share (mlst_set_cu_partition): k_inflate_tok decodes one block per LANE and
+// is bound by the latency of one wave per CU -- on a quarter of the CUs a piece of 16,384 blocks takes four turns instead of one.
 static int bz_stream(mlst_handle* h) {
     if (h->infl_stream) return MLST_OK;
-    if (h->cu_split <= 1) { HIPCHK(h, hipStreamCreateWithFlags(&h->infl_stream, hipStreamNonBlocking)); return MLST_OK; }
-    hipDeviceProp_t prop; HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
-    const u32 n_cu = (u32)prop.multiProcessorCount;
-    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
-    const u32 lo = (u32)((u64)n_cu * h->cu_part / h->cu_split), hi = (u32)((u64)n_cu * (h->cu_part + 1) / h->cu_split);
-    for (u32 c = lo; c < hi; c++) mask[c >> 5] |= 1u << (c & 31);
-    HIPCHK(h, hipExtStreamCreateWithCUMask(&h->infl_stream, (uint32_t)mask.size(), mask.data()));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->infl_stream, hipStreamNonBlocking));
     return MLST_OK;
 }
 
@@ -4725,13 +4755,17 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
         HIPCHK(h, hipStreamWaitEvent(h->infl_stream, B.ev_copied, 0));
         HIPCHK(h, hipStreamWaitEvent(h->infl_stream, h->ev_packed[tslot], 0));      // the text slot's last reader (an event never recorded counts as complete)
         HIPCHK(h, hipMemsetAsync(B.d_err, 0, 64, h->infl_stream));
-        { int rc = launch_inflate(h, B.d_comp, (u64)B.cap_comp + 16, (const BgzfBlk*)B.d_blk, (u32)blks.size(), h->d_fq_slot[tslot], B.d_err, nullptr, h->infl_stream); if (rc) return rc; }
+        if (!h->inflate_mode) { const char* e = getenv("MLST_INFLATE_MODE"); h->inflate_mode = e ? atoi(e) : 2; if (h->inflate_mode != 1 && h->inflate_mode != 2) h->inflate_mode = 2; }
+        const bool counted = h->inflate_mode == 2 && !getenv("MLST_BGZF_NOCOUNT");      // the two-kernel inflate counts the newlines of the text it writes
+        if (counted) HIPCHK(h, hipMemsetAsync(h->d_fq_nl[tslot], 0, (text_bytes / FQ_BLOCK + 2) * 4, h->infl_stream));
+        { int rc = launch_inflate(h, B.d_comp, (u64)B.cap_comp + 16, (const BgzfBlk*)B.d_blk, (u32)blks.size(), h->d_fq_slot[tslot], B.d_err, nullptr, h->infl_stream,
+                                  counted ? h->d_fq_nl[tslot] : nullptr); if (rc) return rc; }
         HIPCHK(h, hipMemcpyAsync(B.h_err, B.d_err, 8, hipMemcpyDeviceToHost, h->infl_stream));
         HIPCHK(h, hipEventRecord(B.ev_inflated, h->infl_stream));
         // piece k - 1 while the GPU inflates piece k
         int rc = MLST_OK;
         if (h->bz_pend.on) { rc = bz_finish(h, false, &n1); done += n1; }
-        h->bz_pend.on = true; h->bz_pend.slot = sl; h->bz_pend.tslot = tslot; h->bz_pend.paired = paired; h->bz_pend.text_bytes = text_bytes - text_at;
+        h->bz_pend.on = true; h->bz_pend.counted = counted; h->bz_pend.slot = sl; h->bz_pend.tslot = tslot; h->bz_pend.paired = paired; h->bz_pend.text_bytes = text_bytes - text_at;
         if (!rc && final_chunk) { rc = bz_finish(h, true, &n1); done += n1; }
         const hipError_t ce = hipStreamSynchronize(h->copy_stream);      // blks / data may be released by the caller after this
         if (rc) { if (h->infl_stream) hipStreamSynchronize(h->infl_stream); h->bz_pend.on = false; return rc; }
@@ -5188,7 +5222,6 @@ extern "C" int mlst_set_cu_partition(mlst_handle* h, uint32_t part, uint32_t n_p
     { int rc_ = bz_flush(h); if (rc_) return rc_; }
     drain_events(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->infl_stream) { hipStreamSynchronize(h->infl_stream); hipStreamDestroy(h->infl_stream); h->infl_stream = nullptr; }      // (re-created on the new share by the next BGZF piece)
     hipDeviceProp_t prop; HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
     const u32 n_cu = (u32)prop.multiProcessorCount;
     if (n_parts > n_cu) return fail(h, MLST_E_INVALID, "more CU partitions (%u) than CUs (%u)", n_parts, n_cu);

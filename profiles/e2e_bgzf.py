@@ -63,7 +63,7 @@ pieces[-1] = comp[int(cuts[(len(pieces) - 1) * per_piece]):]
 
 out = {"reads": N, "text_bytes": len(raw), "bgzf_bytes": int(comp.size), "level": LEVEL, "pieces": len(pieces)}
 ref = None
-for mode in ("0", "1"):
+for mode in os.environ.get("MODES", "0,1").split(","):
     os.environ["MLST_BGZF_PIPE"] = mode
     eng = Engine(0)
     eng.load_reference(idx)
