@@ -76,6 +76,7 @@ class SynthDB:
     loci: dict[str, list[tuple[str, int]]]                 # species -> [(gene, length)]
     n_alleles: dict[tuple[str, str], int] = field(default_factory=dict)
     profiles: dict[str, np.ndarray] = field(default_factory=dict)   # species -> int array [n_st, n_loci] (allele numbers)
+    duplicates: dict = field(default_factory=dict)          # (species, gene) -> (species, gene) it is a near copy of (make_skewed_db)
 
 
 def make_db(path: str, species_loci: dict[str, list[tuple[str, int]]], alleles_per_locus,
@@ -159,7 +160,9 @@ def make_skewed_db(path: str, n_species: int = 6, seed: int = SEED, n_profiles: 
         g = "g%d" % int(rng.integers(0, 7))
         roots[(dst, g)] = (src, g)
         sl[dst] = [(gg, (dict(sl[src])[g] if gg == g else ln)) for gg, ln in sl[dst]]
-    return make_db(path, sl, counts, n_profiles, seed, roots=roots)
+    db = make_db(path, sl, counts, n_profiles, seed, roots=roots)
+    db.duplicates = dict(roots)
+    return db
 
 
 def allele_sequence(db_path: str, species: str, gene: str, allele: int) -> str:
