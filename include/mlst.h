@@ -85,6 +85,13 @@ int mlst_load_reference(mlst_handle* h, const uint8_t* ascii_concat, const uint6
                         const uint32_t* locus_id, const uint32_t* species_id,
                         const int32_t* allele_no, uint32_t n_alleles);
 
+/* The built host index on disk.  The reference keeps `<idx>.1.bt2` next to its FASTA dump and skips bowtie2-build when the
+ * file is there (metamlst-index.py:224-225); here mlst_load_reference reads the index it would build (2-bit arena,
+ * block-haplotype tables, seed table, sieves) from `path` when the file's header carries the key of the inputs (hashes of
+ * the allele text, offsets, locus and species ids, the sieve switches), and writes the file after a build otherwise.
+ * Process-wide; NULL or "" switches it off (the default).  A file that does not fit the inputs is ignored and replaced. */
+int mlst_set_reference_cache(const char* path);
+
 /* The host-side index built by the last mlst_load_reference of the process is kept (a second engine on the same
  * database only uploads it: 0.5 s instead of 13 s for the full database); this releases it (~0.6 GB for the full
  * database).  MLST_INDEX_CACHE=0 in the environment disables the cache. */

@@ -165,7 +165,10 @@ def run_type(a, argv=None) -> int:
         print("--depth-cap orders the records of the whole sample by read index: one sample on several GPUs cannot apply it (use --gpus 1)")
         return 1
     eng = Engine(a.device, prm)
-    eng.load_reference(idx)
+    # the built host index is kept next to the database (as the reference keeps <idx>.1.bt2: metamlst-index.py:224-225) unless a
+    # species filter made this index a one-off or MLST_INDEX_CACHE=0
+    ref_cache = (a.database + ".mlstref") if (not a.filter and os.environ.get("MLST_INDEX_CACHE", "1") != "0") else ""
+    eng.load_reference(idx, cache_path=ref_cache)
     from . import fastq as _fq
     from .engine import pinned_array
     _fq.set_buffer_allocator(pinned_array)      # file chunks are read into page-locked buffers
@@ -304,7 +307,7 @@ def run_merge(a) -> int:
     eng = Engine(a.device)
     eng.load_reference(idx)
     tables = merge_folder(a.folder, database, EngineMatcher(eng, idx), z=a.z, filter=a.filter, meta=a.meta, idField=a.idField,
-                          cache=mdb.DbCache(database.conn), outseqformat=a.outseqformat, j=a.j, jgroup=a.jgroup)
+                          cache=mdb.DbCache(database.conn, idx), outseqformat=a.outseqformat, j=a.j, jgroup=a.jgroup)
     for sp, t in tables.items():
         print("%s: %d sample(s) typed, %d new profile(s)" % (sp, len(t["isolates"]), sum(1 for v in t["encounteredProfiles"].values() if v[2] in (1, 2))))
     return 0

@@ -25,6 +25,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <unistd.h>
 
 #include "mlst.h"
 #include "mlst_debug.h"
@@ -3890,6 +3891,50 @@ static std::shared_ptr<HostIndex> build_host_index(const uint8_t* ascii, const u
 static std::mutex g_index_mu;
 static std::shared_ptr<HostIndex> g_index_last; static u64 g_index_key[5] = {0, 0, 0, 0, 0};      // hashes of the inputs + their sizes
 
+// ---- The built host index on disk (round 5; the reference keeps `<idx>.1.bt2` next to its FASTA dump and skips bowtie2-build
+// when it is there: metamlst-index.py:224-225).  mlst_set_reference_cache names a file; mlst_load_reference reads the index
+// from it when its header carries the key of the inputs (hashes of the allele text, offsets, locus and species ids + the
+// sieve switches -- the same key the in-process cache uses) and writes it after a build.  A file that does not fit is ignored.
+static std::mutex g_refcache_mu; static std::string g_refcache_path;
+extern "C" int mlst_set_reference_cache(const char* path) { std::lock_guard<std::mutex> lk(g_refcache_mu); g_refcache_path = path ? path : ""; return MLST_OK; }
+#define REFCACHE_MAGIC 0x3146455254534C4Dull      /* "MLSTREF1" */
+#define REFCACHE_VERSION 3u
+template <typename T> static bool rc_put(FILE* f, const std::vector<T>& v) { const u64 n = v.size(); return fwrite(&n, 8, 1, f) == 1 && (!n || fwrite(v.data(), sizeof(T), n, f) == n); }
+template <typename T> static bool rc_get(FILE* f, std::vector<T>& v) {
+    u64 n = 0; if (fread(&n, 8, 1, f) != 1 || n > (1ull << 36) / sizeof(T)) return false;
+    v.resize(n); return !n || fread(v.data(), sizeof(T), n, f) == n;
+}
+struct RefCacheHead { u64 magic; u32 version, sz_locus, sz_hap, pad; u64 key[5]; u32 hap_win_max[2], hap_loci, tmask, smask, sieve_chain, gbits, n_loci; int kind; u32 pad2; u64 nb, n_keys; double bitmap_fill; };
+static bool refcache_store(const std::string& path, const u64 key[5], const HostIndex& H) {
+    const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb"); if (!f) return false;
+    RefCacheHead hd; memset(&hd, 0, sizeof hd);
+    hd.magic = REFCACHE_MAGIC; hd.version = REFCACHE_VERSION; hd.sz_locus = (u32)sizeof(LocusDev); hd.sz_hap = (u32)sizeof(HapRec); memcpy(hd.key, key, sizeof hd.key);
+    hd.hap_win_max[0] = H.hap_win_max[0]; hd.hap_win_max[1] = H.hap_win_max[1]; hd.hap_loci = H.hap_loci; hd.tmask = H.tmask; hd.smask = H.smask; hd.sieve_chain = H.sieve_chain;
+    hd.gbits = H.gbits; hd.n_loci = H.n_loci; hd.kind = H.kind; hd.nb = H.nb; hd.n_keys = H.n_keys; hd.bitmap_fill = H.bitmap_fill;
+    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1 && rc_put(f, H.loci) && rc_put(f, H.alen) && rc_put(f, H.arena) && rc_put(f, H.nmask) && rc_put(f, H.planes) && rc_put(f, H.hap_rec)
+              && rc_put(f, H.hap_blk) && rc_put(f, H.hap_id) && rc_put(f, H.tkeys) && rc_put(f, H.tvals) && rc_put(f, H.posts) && rc_put(f, H.sv) && rc_put(f, H.bitmap)
+              && rc_put(f, H.gbitmap) && rc_put(f, H.rfilter);
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
+    if (!ok) remove(tmp.c_str());
+    return ok;
+}
+static std::shared_ptr<HostIndex> refcache_load(const std::string& path, const u64 key[5]) {
+    FILE* f = fopen(path.c_str(), "rb"); if (!f) return nullptr;
+    auto H = std::make_shared<HostIndex>();
+    RefCacheHead hd;
+    bool ok = fread(&hd, sizeof hd, 1, f) == 1 && hd.magic == REFCACHE_MAGIC && hd.version == REFCACHE_VERSION && hd.sz_locus == sizeof(LocusDev) && hd.sz_hap == sizeof(HapRec)
+              && memcmp(hd.key, key, sizeof hd.key) == 0;
+    ok = ok && rc_get(f, H->loci) && rc_get(f, H->alen) && rc_get(f, H->arena) && rc_get(f, H->nmask) && rc_get(f, H->planes) && rc_get(f, H->hap_rec) && rc_get(f, H->hap_blk)
+         && rc_get(f, H->hap_id) && rc_get(f, H->tkeys) && rc_get(f, H->tvals) && rc_get(f, H->posts) && rc_get(f, H->sv) && rc_get(f, H->bitmap) && rc_get(f, H->gbitmap) && rc_get(f, H->rfilter);
+    fclose(f);
+    if (!ok || H->loci.size() != hd.n_loci) return nullptr;
+    H->hap_win_max[0] = hd.hap_win_max[0]; H->hap_win_max[1] = hd.hap_win_max[1]; H->hap_loci = hd.hap_loci; H->tmask = hd.tmask; H->smask = hd.smask; H->sieve_chain = hd.sieve_chain;
+    H->gbits = hd.gbits; H->n_loci = hd.n_loci; H->kind = hd.kind; H->nb = hd.nb; H->n_keys = hd.n_keys; H->bitmap_fill = hd.bitmap_fill;
+    return H;
+}
+
 static int sieve_kind_from_env() {
     const char* s = getenv("MLST_SIEVE");
     if (!s || !s[0]) return -1;
@@ -3925,8 +3970,13 @@ extern "C" int mlst_load_reference(mlst_handle* h, const uint8_t* ascii, const u
         if (nocache && nocache[0] == '0') g_index_last.reset();
         if (g_index_last && memcmp(g_index_key, key, sizeof key) == 0) HI = g_index_last;
         else {
-            HI = build_host_index(ascii, off, locus_id, species_id, n_alleles, want_kind);
-            if (HI->err_code) return fail(h, HI->err_code, "%s", HI->err.c_str());
+            std::string rc_path; { std::lock_guard<std::mutex> lk2(g_refcache_mu); rc_path = g_refcache_path; }
+            if (!rc_path.empty()) HI = refcache_load(rc_path, key);
+            if (!HI) {
+                HI = build_host_index(ascii, off, locus_id, species_id, n_alleles, want_kind);
+                if (HI->err_code) return fail(h, HI->err_code, "%s", HI->err.c_str());
+                if (!rc_path.empty()) refcache_store(rc_path, key, *HI);      // (a directory that cannot be written: no cache, no error)
+            }
             if (!(nocache && nocache[0] == '0')) { g_index_last = HI; memcpy(g_index_key, key, sizeof key); }
         }
     }

@@ -121,24 +121,75 @@ def stringDiff(s1, s2) -> int:
 
 
 class DbCache:
-    """In-memory lookups with the same answers as the SQL helpers above, built once per database
-    connection.  The reference issues un-indexed full-table scans per locus per sample
-    (sequenceExists / sequenceLocate / defineProfile); with the alignment on the GPU those scans
-    would dominate a typing pass.  Equivalence with the SQL versions is tested in
-    tests/test_merge_host.py.  Rows are visited in rowid order, which is the order SQLite returns
-    them for these un-ordered queries, so `fetchone()` semantics (first row wins) are kept."""
+    """In-memory lookups with the same answers as the SQL helpers above.  The reference issues un-indexed full-table scans
+    per locus per sample (sequenceExists / sequenceLocate / defineProfile); with the alignment on the GPU those scans would
+    dominate a typing pass.  Equivalence with the SQL versions is tested in tests/test_golden_functions.py.  Rows are
+    visited in rowid order, which is the order SQLite returns them for these un-ordered queries, so `fetchone()` semantics
+    (first row wins) are kept.
 
-    def __init__(self, conn):
+    Nothing is built before it is asked for (round 5; until round 4 the constructor walked every allele row of the
+    database -- 0.7 s of every `cli type` command on 315 k alleles, the whole prologue of the folder mode): the sequence
+    table of ONE species when a consensus of that species is looked up (from `index`, the AlleleIndex the engine was loaded
+    from, when it holds the species: no SQL at all), the label and profile tables when an ST is first called."""
+
+    def __init__(self, conn, index=None):
         self.conn = conn
-        self.seq_first: dict = {}       # (bacterium, sequence) -> (gene, alleleVariant) of the first row
-        self.label_rec: dict = {}       # 'bacterium_gene_alleleVariant' -> recID of the first row
-        self.prof_by_allele: dict = {}  # alleleCode -> [profileCode, ...] (one per profiles row)
+        self.index = index
+        self._seq_sp: dict = {}         # bacterium -> {sequence: (gene, alleleVariant) of the first row}
+        self._seq_all = None            # {(bacterium, sequence): ...} of every row (species the index does not hold)
+        self._label_rec = None          # 'bacterium_gene_alleleVariant' -> recID of the first row
+        self._prof_by_allele = None     # alleleCode -> [profileCode, ...] (one per profiles row)
         self._genes: dict = {}          # bacterium -> [geneName, ...]
-        for row in conn.execute("SELECT recID,bacterium,gene,sequence,alleleVariant FROM alleles ORDER BY recID"):
-            self.seq_first.setdefault((row["bacterium"], row["sequence"]), (row["gene"], row["alleleVariant"]))
-            self.label_rec.setdefault("%s_%s_%s" % (row["bacterium"], row["gene"], row["alleleVariant"]), row["recID"])
-        for row in conn.execute("SELECT profileCode,alleleCode FROM profiles ORDER BY recID"):
-            self.prof_by_allele.setdefault(row["alleleCode"], []).append(row["profileCode"])
+
+    # ---- tables, built on first use
+    def _seqs_of(self, bacterium) -> dict:
+        d = self._seq_sp.get(bacterium)
+        if d is not None:
+            return d
+        idx = self.index
+        if idx is not None and bacterium in getattr(idx, "species", ()) and not getattr(idx, "filtered", False):
+            import numpy as np
+            sid = idx.species.index(bacterium)
+            al = np.nonzero(idx.species_id == sid)[0]
+            al = al[np.argsort(idx.rec_id[al], kind="stable")]          # rowid order: the first row of a sequence wins
+            d = {}
+            for a in al:
+                a = int(a)
+                d.setdefault(idx.ascii_concat[int(idx.off[a]):int(idx.off[a + 1])].tobytes().decode(), (idx.loci[int(idx.locus_id[a])][1], str(int(idx.allele_no[a]))))
+            # (rows with an empty sequence are not in the index, and alleleVariant comes back from SQLite as it is stored:
+            # both only matter for the look-ups below that fall through to SQL)
+            self._seq_sp[bacterium] = d
+            return d
+        if self._seq_all is None:
+            self._seq_all = {}
+            for row in self.conn.execute("SELECT bacterium,gene,sequence,alleleVariant FROM alleles ORDER BY recID"):
+                self._seq_all.setdefault((row["bacterium"], row["sequence"]), (row["gene"], row["alleleVariant"]))
+        d = {seq: v for (sp, seq), v in self._seq_all.items() if sp == bacterium}
+        self._seq_sp[bacterium] = d
+        return d
+
+    def _first(self, bacterium, sequence):
+        sequence = str(sequence)
+        if sequence == "":              # (the index holds no empty sequences: the reference's own query answers)
+            row = self.conn.execute("SELECT gene,alleleVariant FROM alleles WHERE bacterium = ? AND sequence = ?", (bacterium, sequence)).fetchone()
+            return (row["gene"], row["alleleVariant"]) if row else None
+        return self._seqs_of(bacterium).get(sequence)
+
+    @property
+    def label_rec(self) -> dict:
+        if self._label_rec is None:
+            self._label_rec = {}
+            for row in self.conn.execute("SELECT recID,bacterium,gene,alleleVariant FROM alleles ORDER BY recID"):
+                self._label_rec.setdefault("%s_%s_%s" % (row["bacterium"], row["gene"], row["alleleVariant"]), row["recID"])
+        return self._label_rec
+
+    @property
+    def prof_by_allele(self) -> dict:
+        if self._prof_by_allele is None:
+            self._prof_by_allele = {}
+            for row in self.conn.execute("SELECT profileCode,alleleCode FROM profiles ORDER BY recID"):
+                self._prof_by_allele.setdefault(row["alleleCode"], []).append(row["profileCode"])
+        return self._prof_by_allele
 
     def genes(self, bacterium) -> list:
         """geneName rows of `SELECT geneName FROM genes WHERE bacterium = ?` (metamlst.py:185), in rowid order."""
@@ -149,14 +200,14 @@ class DbCache:
         return g
 
     def sequenceExists(self, bacterium, sequence) -> bool:
-        return (bacterium, str(sequence)) in self.seq_first
+        return self._first(bacterium, sequence) is not None
 
     def sequenceFind(self, bacterium, sequence):
-        r = self.seq_first.get((bacterium, str(sequence)))
+        r = self._first(bacterium, sequence)
         return r[0] if r else 0
 
     def sequenceLocate(self, bacterium, sequence) -> str:
-        return str(self.seq_first[(bacterium, str(sequence))][1])
+        return str(self._first(bacterium, sequence)[1])
 
     def defineProfile(self, geneList):
         """Module-level defineProfile (metaMLST_functions.py:205-216) including Q9: the LAST label

@@ -85,6 +85,7 @@ def load_library(path: str | None = None):
         "mlst_destroy": (None, [H]),
         "mlst_last_error": (C.c_char_p, [H]),
         "mlst_load_reference": (C.c_int, [H, u8p, u64p, u32p, u32p, i32p, C.c_uint32]),
+        "mlst_set_reference_cache": (C.c_int, [C.c_char_p]),
         "mlst_submit_reads": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_int]),
         "mlst_submit_fastq": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
         "mlst_submit_fastq_bgzf": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -230,8 +231,12 @@ class Engine:
             raise MlstError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
 
     # ---- reference ----
-    def load_reference(self, index: AlleleIndex):
+    def load_reference(self, index: AlleleIndex, cache_path: str | None = None):
+        """cache_path: where the built host index is kept between runs (mlst_set_reference_cache: `<database>.mlstref` next to the
+        database, as the reference keeps `<idx>.1.bt2`, metamlst-index.py:224-225); None leaves the process-wide setting alone."""
         self.index = index
+        if cache_path is not None:
+            self.lib.mlst_set_reference_cache(cache_path.encode() if cache_path else None)
         self._check(self.lib.mlst_load_reference(self._h, _ptr(index.ascii_concat), _ptr(index.off), _ptr(index.locus_id),
                                                  _ptr(index.species_id), _ptr(index.allele_no), index.n_alleles),
                     "mlst_load_reference")

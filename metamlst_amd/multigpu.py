@@ -245,7 +245,7 @@ def type_many_samples(engines, idx, database, targs, samples: list[list[str]], r
     # sample against ~7 ms for a sample of a million reads otherwise).
     from . import db as mdb
     show = printer is not None
-    cache = mdb.DbCache(database.conn)
+    cache = mdb.DbCache(database.conn, idx)
 
     def tail(job, st, chosen, letters):
         i, files = job

@@ -47,7 +47,7 @@ def main():
     eng = w.engines[0]
     orc = oracle_lib.Oracle(w.idx, threads=os.cpu_count() or 1)
     matcher = EngineMatcher(eng, w.idx)
-    cache = mdb.DbCache(w.database.conn)
+    cache = mdb.DbCache(w.database.conn, w.idx)
     out = []
     for b in want:
         packed, qrows, lens, n_total = w.batches[b]
