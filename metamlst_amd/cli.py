@@ -64,8 +64,9 @@ def _type_parser(sub):
     p.add_argument("--max-items", default=0, type=int, metavar="ITEMS", help="capacity of the (read, locus, strand) work-item list (default 8 M)")
     p.add_argument("--max-pair-results", default=0, type=int, metavar="PAIRS", help="capacity of the (item, allele) result arena (default 256 M)")
     p.add_argument("--depth-cap", default=0, type=int, metavar="N",
-                   help="pysam's pileup(max_depth) as a switch (metaMLST_functions.py:255-259 runs with 8000): a consensus column sees the "
-                        "first N alignment records that span it, in read order; 0 (default) = all of them")
+                   help="an ORDER-FREE approximation of pysam's pileup(max_depth) (metaMLST_functions.py:255-259 runs with 8000): a consensus column "
+                        "sees the first N alignment records that span it, in read-index order.  NOT bit-identical to pysam on deep samples: htslib drops "
+                        "whole reads at their start position in the coordinate-sorted BAM (DESIGN.md section 6); 0 (default) = all records")
     return p
 
 

@@ -4985,7 +4985,8 @@ static void launch_pileup(mlst_handle* h, const int* d_chosen, const u64* d_colb
 // Ungapped + banded pile-up of every item against its locus' chosen allele into d_counts (zeroed by the caller, n_pl_dp
 // too).  With a depth cap set (mlst_set_depth_cap; default off) the pile-up is the last of 42 passes: 41 counting passes
 // of a bitwise search find, per column, the key of the cap-th record that spans it (k_cap_search), and the pile-up proper
-// is restricted to the records each column sees.  ~7 ms instead of ~0.2: a literal-parity mode, not a fast path.
+// is restricted to the records each column sees.  ~7 ms instead of ~0.2: not a fast path, and an order-free APPROXIMATION of
+// pysam's max_depth (htslib drops whole reads at their start position in coordinate-sorted order: DESIGN.md section 6), not bit-identical to it.
 static int pile_all(mlst_handle* h, const int* d_chosen, const u64* d_colbase, u32* d_counts, u64 ncols) {
     if (!h->depth_cap) {
         launch_pileup(h, d_chosen, d_colbase, d_counts);

@@ -114,8 +114,10 @@ _readers = None
 def _reader_pool():
     global _readers
     if _readers is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _readers = ThreadPoolExecutor(max(2, min(int(os.environ.get("MLST_READ_THREADS", "32")), (os.cpu_count() or 2) // 2)), thread_name_prefix="fastq-read")
+        with _pool_lock:      # (first called by four feeder threads at once: one pool, not four)
+            if _readers is None:
+                from concurrent.futures import ThreadPoolExecutor
+                _readers = ThreadPoolExecutor(max(2, min(int(os.environ.get("MLST_READ_THREADS", "32")), (os.cpu_count() or 2) // 2)), thread_name_prefix="fastq-read")
     return _readers
 
 
@@ -130,7 +132,9 @@ def set_buffer_allocator(fn) -> None:
         if fn is _alloc:
             return
         _alloc = fn
+        old = list(_pool_bufs)      # (dropped after the lock is released: freeing page-locked memory takes milliseconds per buffer)
         _pool_bufs.clear()
+    del old
 
 
 def _take_buffer(n: int) -> np.ndarray:

@@ -255,8 +255,10 @@ def type_many_samples(engines, idx, database, targs, samples: list[list[str]], r
                 "log": log_table(idx, st, targs, files[0]) if log else None, "results": res if show else None}
 
     t_run = time.perf_counter()
-    mine = pipe.run(jobs, feed, tail, per_allele=show or log)
-    pipe.stop_feeders()
+    try:
+        mine = pipe.run(jobs, feed, tail, per_allele=show or log)
+    finally:
+        pipe.stop_feeders()      # (also when a feeder or the tail raised: the other feeders end with their current sample)
     if timing is not None:      # (what a run pays once -- database look-up tables, CU shares -- and what it pays per sample)
         timing["prologue_s"] = t_run - t_begin
         timing["samples_s"] = time.perf_counter() - t_run

@@ -136,12 +136,18 @@ class TypingPipeline:
                 self._fed(kk % self.depth)
                 e.typing_wait()
                 self.host_ms["wait_device"] += (time.perf_counter() - t0) * 1e3
+                # A handle is not thread-safe (include/mlst.h): with feeder threads the finished sample's results leave their
+                # pinned slot BEFORE the engine goes to its feeder for the next sample (the fetch on this thread ran
+                # beside reset / submit / enqueue on the feeder's -- disjoint fields in the normal case, a race in the error and
+                # profiling paths).  Without feeder threads the order stays: queue first, copy then.
+                got = e.typing_fetch(per_allele, waited=True) if self.feed_threads else None
                 nxt = next(it, _END)
                 if nxt is not _END:
                     self._launch(k, nxt, feed)
                     inflight.append((k, nxt))
                     k += 1
-                got = e.typing_fetch(per_allele, waited=True)
+                if got is None:
+                    got = e.typing_fetch(per_allele, waited=True)
             t1 = time.perf_counter()
             results.append(tail(job, *got))
             self.host_ms["tail"] += (time.perf_counter() - t1) * 1e3
