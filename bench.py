@@ -625,9 +625,10 @@ def end_to_end(w, args, torch, device):
     with ThreadPoolExecutor(max(1, min(64, os.cpu_count() or 1))) as ex:      # zlib releases the GIL
         parts = list(ex.map(bgzf_block, [raw[at:at + 65280] for at in range(0, len(raw), 65280)]))
     comp = np.frombuffer(b"".join(parts) + bgzf_block(b""), np.uint8)
-    # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks, here 16,384 of them = one pass of the inflate
-    # kernels, ~190 MB compressed): the copy of piece k + 1 crosses the link while piece k's text is parsed
-    per_piece = 16384
+    # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks, here 49,152 of them = one pass of the inflate
+    # kernels with k_inflate_tok2, ~570 MB compressed -- the file reader's chunk size): the copy of piece k + 1 and its inflate
+    # run beside the parse and pass 1 of piece k (three streams, mlst_submit_fastq_bgzf)
+    per_piece = int(os.environ.get("MLST_BENCH_BGZF_PIECE", "49152"))
     cuts = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
     pieces = [comp[int(cuts[a]):int(cuts[min(a + per_piece, len(parts))])] for a in range(0, len(parts), per_piece)]
     pieces[-1] = comp[int(cuts[(len(pieces) - 1) * per_piece]):]            # (with the end-of-file block)
@@ -670,6 +671,7 @@ def end_to_end(w, args, torch, device):
     t0 = time.perf_counter(); calls_q = run_packed(None); t_q = time.perf_counter() - t0
     out["fastq_text_packed_on_host_to_st"] = {"Mreads_per_s": round(n / t_q / 1e6, 1), "seconds": round(t_q, 4), "species_called": len(calls_q)}
     out["bgzip_to_st"] = {"reads": nz, "Mreads_per_s": round(nz / min(ts) / 1e6, 1), "compressed_bytes": int(comp.size), "zlib_level": 6, "seconds": round(min(ts), 4),
+                          "blocks_per_piece": per_piece, "pieces": len(pieces),
                           "species_called": len(calls)}
     del raw
     for key, kw in (("cli_folder_to_nfo", {}), ("cli_folder_bgzip_to_nfo", {"bgzf_parts": parts, "eof_block": bgzf_block(b"")})):

@@ -23,6 +23,11 @@ int mlst_selftest_inflate(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64
  * kernel_ms (optional) receives the duration of the inflate kernel alone (HIP events). */
 int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, uint8_t* out, uint64_t cap, uint64_t* produced, double* kernel_ms);
 
+/* The decoder of k_inflate_tok2 (csrc/inflate_canon.h: canonical limits, 800 bytes of state per stream) run on the HOST on one
+ * raw deflate stream, its tokens replayed into bytes.  *left_to_other_kernel = 1: the literal / length code of a block holds
+ * more symbols than the decoder's 192-entry table (the device leaves such a block to k_inflate); nothing is produced then. */
+int mlst_selftest_inflate_canon(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced, int* left_to_other_kernel);
+
 /* Diagnostics of the routed sieve (profiles/route_modes.py; no reference counterpart, not a data path).
  * mlst_get_route_trace: the first call switches the trace on; later calls wait for the stream and return, for the last
  * submission, out[0] = producer workgroups P, [1] = arena address, [2] = packed-row address, [3] = wall-clock kHz,

@@ -32,6 +32,7 @@
 #include "inflate_dev.h"
 #include "inflate_wave.h"
 #include "inflate_lane.h"
+#include "inflate_canon.h"
 #include "mlst_policy.h"
 
 typedef unsigned long long u64;
@@ -1181,6 +1182,31 @@ __global__ __launch_bounds__(64) void k_inflate_tok(const u8* __restrict__ comp,
     __shared__ mlst_inflate::Tables s_tb[64];
     __shared__ unsigned long s_win[(mlst_inflate::Bits::WIN / 8) * 64];       // WIN bytes of every lane's stream, lane-interleaved 8-byte words (inflate_dev.h: Bits::win)
     inflate_lane::tok_body(comp, comp + comp_bytes, blk, n_blk, err_base, tok, INFL_TOK_CAP, n_tok, err, s_tb, s_win);
+#endif
+}
+// phase 1 with 800 bytes of state per stream (csrc/inflate_canon.h): three waves per CU instead of one
+__global__ __launch_bounds__(64) void k_inflate_tok2(const u8* __restrict__ comp, u64 comp_bytes, const BgzfBlk* __restrict__ blk, u32 n_blk, u32 err_base, u32* __restrict__ tok,
+                                                     u32* __restrict__ n_tok, u32* __restrict__ err) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace inflate_canon;
+    __shared__ u32 s_w[W_TOTAL * 64];
+    const u32 lane = threadIdx.x & 63u;
+    for (u32 i0 = blockIdx.x * 64u; i0 < n_blk; i0 += gridDim.x * 64u) {
+        const u32 i = i0 + lane;
+        if (i >= n_blk) continue;
+        const BgzfBlk B = blk[i];
+        const u32 want = B.out_len;
+        if (want > inflate_lane::LIT_BASE) { n_tok[i] = (u32)inflate_lane::TOK_OVERFLOW; continue; }
+        MemLds m; m.base = (__attribute__((address_space(3))) u32*)s_w + lane;
+        Bits<SrcLds> b; b.src.win = (__attribute__((address_space(3))) u32*)s_w + W_WIN * 64u + lane; b.src.in = comp + B.in_off; b.src.buf_end = comp + comp_bytes;
+        b.src.win_at = 0; b.src.have = false; b.buf = 0; b.cnt = 0; b.pos = 0; b.n = B.in_len;
+        Tok o; o.tok = tok + (u64)i * INFL_TOK_CAP; o.nt = 0; o.cap = INFL_TOK_CAP; o.over = false;
+        u32 produced = 0;
+        int rc = tok_stream(m, b, o, want, &produced);
+        if (rc == mlst_inflate::OK && !o.over && produced != want) rc = mlst_inflate::E_SHORT;
+        if (rc != mlst_inflate::OK) { if (atomicCAS(&err[0], 0u, err_base + i + 1u) == 0u) err[1] = (u32)(-rc); n_tok[i] = 0; }
+        else n_tok[i] = o.over ? (u32)inflate_lane::TOK_OVERFLOW : o.nt;
+    }
 #endif
 }
 // nl (optional): newlines per 2^nl_shift bytes of the text buffer (cell = offset in `out` >> nl_shift; nl_shift >= 12), added up as the text is written
@@ -4580,7 +4606,8 @@ extern "C" int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, c
 // the Huffman codes into tokens, one workgroup per block turns tokens into bytes by pointer jumping in LDS), in passes of at
 // most INFL_PASS blocks (the token buffer holds 96 KB per block of a pass), with the blocks whose tokens did not fit left to
 // 1 = the one-wave-per-block kernel of csrc/inflate_wave.h.
-#define INFL_PASS 16384u
+#define INFL_PASS 16384u          /* blocks per pass with k_inflate_tok: one wave (64 blocks) per CU is all its 160 KB of tables allow */
+#define INFL_PASS2 49152u         /* with k_inflate_tok2: three waves per CU (the token buffer holds 96 KB per block of a pass: 4.7 GB) */
 // d_nl (optional; two-kernel path only): newline counts per FQ_BLOCK bytes of d_out, added up while the text is written (zeroed by the caller)
 static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padded, const BgzfBlk* d_blk, u32 n_blk, u8* d_out, u32* d_err, unsigned long long* d_st, hipStream_t st = nullptr, u32* d_nl = nullptr) {
     if (n_blk == 0) return MLST_OK;
@@ -4591,7 +4618,14 @@ static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padde
         hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n_blk + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk, n_blk, d_out, d_err, d_st, (const u32*)nullptr, 0u);
         return MLST_OK;
     }
-    const u32 pass = std::min(n_blk, INFL_PASS);
+    // Phase 1: k_inflate_tok (tables of 9 / 8 bits, 2.3 KB per stream: ONE wave of 64 blocks per CU, 0.58 us per symbol step) or
+    // k_inflate_tok2 (canonical limits, 800 B per stream: three waves per CU, 0.9 us per step).  Both are bound by the latency of a
+    // wave, so what counts is how many blocks are in flight: up to 16,384 blocks the first finishes in one turn (4.4 ms) and wins;
+    // a larger piece costs it a turn per 16,384 blocks (49,152 blocks: 13.2 ms) while the second still takes one (9 ms).
+    // MLST_INFLATE_TOK = 1 / 2 forces one of them; default: by the number of blocks.
+    const char* tok_e = getenv("MLST_INFLATE_TOK"); const int tok_env = tok_e ? atoi(tok_e) : 0;
+    const int tok_kind = tok_env == 1 || tok_env == 2 ? tok_env : (n_blk > 24576u ? 2 : 1);
+    const u32 pass = std::min(n_blk, tok_kind == 1 ? INFL_PASS : INFL_PASS2);
     if (h->cap_itok_blocks < pass) {
         HIPCHK(h, hipStreamSynchronize(st)); HIPCHK(h, hipStreamSynchronize(h->stream));
         hipFree(h->d_itok); hipFree(h->d_intok); h->d_itok = nullptr; h->d_intok = nullptr; h->cap_itok_blocks = 0;
@@ -4600,7 +4634,8 @@ static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padde
     }
     for (u32 at = 0; at < n_blk; at += pass) {
         const u32 n = std::min(pass, n_blk - at);
-        hipLaunchKernelGGL(k_inflate_tok, dim3((n + 63) / 64), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk + at, n, at, h->d_itok, h->d_intok, d_err);
+        if (tok_kind == 1) hipLaunchKernelGGL(k_inflate_tok, dim3((n + 63) / 64), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk + at, n, at, h->d_itok, h->d_intok, d_err);
+        else hipLaunchKernelGGL(k_inflate_tok2, dim3((n + 63) / 64), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk + at, n, at, h->d_itok, h->d_intok, d_err);
         hipLaunchKernelGGL(k_inflate_ptr, dim3(std::min(n, 4096u)), dim3(1024), 0, st, d_comp, d_blk + at, n, at, (const u32*)h->d_itok, (const u32*)h->d_intok, d_out, d_err, d_nl, 12u);
         hipLaunchKernelGGL(k_inflate, dim3((u32)std::min<u64>(((u64)n + INFLATE_NG - 1) / INFLATE_NG, 1u << 20)), dim3(64), 0, st, d_comp, comp_bytes_padded, d_blk + at, n, d_out, d_err, (unsigned long long*)nullptr, (const u32*)h->d_intok, at);
         if (d_nl) hipLaunchKernelGGL(k_nl_blocks, dim3(std::min(n, 2048u)), dim3(256), 0, st, d_blk + at, n, (const u32*)h->d_intok, (const u8*)d_out, d_nl, 12u);
@@ -4900,6 +4935,15 @@ extern "C" int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data,
     return rc;
 }
 
+// the decoder of k_inflate_tok2 (csrc/inflate_canon.h) run on the host, its tokens replayed into bytes: a test hook
+// (*left_to_other_kernel = 1: the block's literal / length code holds more symbols than the 192-entry table: k_inflate takes it)
+extern "C" int mlst_selftest_inflate_canon(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced, int* left_to_other_kernel) {
+    unsigned long long p = 0; bool over = false;
+    const int rc = inflate_canon::inflate_raw_host(in, n_in, out, cap, &p, &over);
+    if (produced) *produced = p;
+    if (left_to_other_kernel) *left_to_other_kernel = over ? 1 : 0;
+    return rc;
+}
 // the decoder of k_inflate run on the host: a test hook (tests/test_inflate.py compares it with zlib without a GPU)
 extern "C" int mlst_selftest_inflate(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced) {
     uint64_t p = 0; mlst_inflate::Tables tb; const int rc = mlst_inflate::inflate_raw(in, n_in, out, cap, &p, &tb);

@@ -90,6 +90,7 @@ def load_library(path: str | None = None):
         "mlst_submit_fastq": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
         "mlst_submit_fastq_bgzf": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mlst_selftest_inflate": (C.c_int, [u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "mlst_selftest_inflate_canon": (C.c_int, [u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
         "mlst_selftest_inflate_device": (C.c_int, [H, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
         "mlst_submit_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_int]),
         "mlst_pack_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, u32p, u8p, u16p, C.c_uint32, C.c_uint32]),
@@ -296,8 +297,9 @@ class Engine:
         release_buffers(ring)
         return total
 
-    def submit_fastq_bgzf_file(self, path: str, paired: bool = False, chunk_bytes: int = 256 << 20) -> int:
-        """A whole bgzip'd FASTQ file (see _submit_bgzf_pieces)."""
+    def submit_fastq_bgzf_file(self, path: str, paired: bool = False, chunk_bytes: int = 512 << 20) -> int:
+        """A whole bgzip'd FASTQ file (see _submit_bgzf_pieces).  Pieces of 512 MB compressed (~46 k BGZF blocks): one pass of the
+        inflate kernels with three waves per CU (k_inflate_tok2), and the piece behind it is copied and inflated meanwhile."""
         return self._submit_bgzf_pieces(path, 0, os.path.getsize(path), chunk_bytes, paired, True)
 
     def inflate_bgzf(self, data) -> bytes:

@@ -56,7 +56,7 @@ with ThreadPoolExecutor(max(1, min(64, os.cpu_count() or 1))) as ex:
     parts = list(ex.map(block, [(raw[at:at + 65280], LEVEL) for at in range(0, len(raw), 65280)]))
 comp = np.frombuffer(b"".join(parts) + block((b"", LEVEL)), np.uint8)
 print("compressed %d blocks in %.1f s: %.1f MB -> %.1f MB" % (len(parts), time.perf_counter() - t0, len(raw) / 1e6, comp.size / 1e6), file=sys.stderr, flush=True)
-per_piece = 16384
+per_piece = int(os.environ.get("PER_PIECE", "16384"))
 cuts = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
 pieces = [comp[int(cuts[a]):int(cuts[min(a + per_piece, len(parts))])] for a in range(0, len(parts), per_piece)]
 pieces[-1] = comp[int(cuts[(len(pieces) - 1) * per_piece]):]

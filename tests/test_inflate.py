@@ -22,6 +22,16 @@ def inflate(raw: bytes, cap: int):
     return rc, out[:int(n.value)].tobytes()
 
 
+def inflate_canon(raw: bytes, cap: int):
+    """csrc/inflate_canon.h (the decoder of k_inflate_tok2) on the host: -> (rc, bytes, left to the other kernel)"""
+    lib = engine.load_library()
+    src = np.frombuffer(raw, np.uint8) if raw else np.zeros(1, np.uint8)
+    out = np.zeros(max(cap, 1), np.uint8)
+    n, over = C.c_uint64(), C.c_int()
+    rc = lib.mlst_selftest_inflate_canon(src.ctypes.data_as(C.POINTER(C.c_uint8)), len(raw), out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n), C.byref(over))
+    return rc, out[:int(n.value)].tobytes(), bool(over.value)
+
+
 def deflate(data: bytes, level: int, strategy: int = zlib.Z_DEFAULT_STRATEGY) -> bytes:
     c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
     return c.compress(data) + c.flush()
@@ -40,6 +50,41 @@ def test_decoder_equals_zlib(level, strategy):
     for data in payloads():
         rc, got = inflate(deflate(data, level, strategy), len(data))
         assert rc == 0 and got == data
+
+
+@pytest.mark.parametrize("level,strategy", [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                                             (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)])
+def test_canonical_limit_decoder_equals_zlib(level, strategy):
+    """The decoder of k_inflate_tok2 (no look-up tables: 15 left-justified limits per code, 800 bytes of state per stream)
+    and the replay of its tokens.  A block whose literal / length code uses more than 192 symbols is left to the other kernel
+    (`over`): the fixed code (288 symbols) and random bytes do, FASTQ text never."""
+    for k, data in enumerate(payloads()):
+        rc, got, over = inflate_canon(deflate(data, level, strategy), len(data))
+        assert rc == 0
+        if over:
+            assert strategy == zlib.Z_FIXED or k in (1, 3) or level == 0 or len(data) < 200, (k, level, strategy)      # (tiny inputs are sent with the fixed code)
+        else:
+            assert got == data, (k, level, strategy)
+        if k == 4 and strategy != zlib.Z_FIXED:
+            assert not over
+
+
+def test_canonical_limit_decoder_rejects_damage():
+    rng = np.random.default_rng(12)
+    data = payloads()[4]
+    raw = deflate(data, 6)
+    assert inflate_canon(raw, len(data) - 1)[0] < 0
+    assert inflate_canon(raw[:len(raw) // 2], len(data))[0] < 0
+    for _ in range(300):
+        bad = bytearray(raw)
+        for _ in range(int(rng.integers(1, 6))):
+            bad[int(rng.integers(len(bad)))] = int(rng.integers(256))
+        rc, got, over = inflate_canon(bytes(bad), len(data))
+        assert rc <= 0 and len(got) <= len(data)
+        rc0, got0 = inflate(bytes(bad), len(data))
+        if rc == 0 and not over and rc0 == 0:
+            assert got == got0                           # (what both decoders accept, they decode alike)
+    assert inflate_canon(b"\x07", 10)[0] < 0
 
 
 def test_decoder_rejects_damage_without_reading_or_writing_out_of_bounds():
@@ -87,16 +132,19 @@ def _bgzf_raw(raw: bytes, data: bytes) -> bytes:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["2", "1"])
+@pytest.mark.parametrize("mode", ["2", "2c", "1"])
 def test_device_decoder_equals_zlib_on_every_block_kind(mode, monkeypatch):
     """The device decoders on the GPU -- mode 2: the two kernels of csrc/inflate_lane.h (one lane per block -> tokens, one
     workgroup per block -> bytes by pointer jumping; blocks of more than 24,576 symbols, here the Huffman-only ones, fall to the
-    other kernel); mode 1: the one-wave-per-block decoder of csrc/inflate_wave.h for every block -- on every
+    other kernel); 2c: the same with phase 1 by csrc/inflate_canon.h (k_inflate_tok2: canonical limits, three waves per CU --
+    the engine's choice for pieces of more than 24,576 blocks; blocks with the fixed code or more than 192 literal / length
+    symbols fall to the other kernel); mode 1: the one-wave-per-block decoder of csrc/inflate_wave.h for every block -- on every
     payload x level x strategy in ONE buffer of BGZF blocks (one launch), blocks at odd byte offsets, compared with the
     bytes that went in.  Includes stored blocks (level 0 and incompressible data), fixed codes, long codes (Huffman
     only), overlapping matches (runs), matches 32 K back, empty blocks, blocks of odd and of full (65,536 bytes) length."""
     from metamlst_amd.engine import Engine, MlstError
-    monkeypatch.setenv("MLST_INFLATE_MODE", mode)      # (read when an engine inflates for the first time)
+    monkeypatch.setenv("MLST_INFLATE_MODE", mode[0])      # (read when an engine inflates for the first time)
+    monkeypatch.setenv("MLST_INFLATE_TOK", "2" if mode == "2c" else "1")
     rng = np.random.default_rng(5)
     far = bytes(rng.integers(0, 256, 300, dtype=np.uint8))
     extra = [far + bytes(rng.integers(65, 70, 32300, dtype=np.uint8)) + far,        # a match at the far end of the window
