@@ -239,3 +239,95 @@ def test_pubmlst_shaped_database_with_skewed_loci_and_near_duplicate_loci():
             eng.close()
         finally:
             os.environ.pop("MLST_SIEVE", None)
+
+
+def test_cfg2_full_size_ten_million_reads_planted_st_and_additive_halves():
+    """BASELINE configs[1] at its full size: 10 M x 150 bp reads of one E. coli-like isolate made on the
+    GPU (bench.py's generator), 7 loci x 1,430 alleles, through the path the library picks (LDS sieve, the pair kernel for
+    loci of more than 512 alleles): the planted ST is called, and the statistics of the batch equal those of its halves
+    submitted one after the other.  (The oracle covers this database at 100 k reads in test_cfg1_...; the whole 10 M batch
+    against the oracle is profiles/check_batch.py --workload cfg2.)"""
+    import torch
+    sdb, idx = ecoli_full()
+    dev = torch.device("cuda", 0)
+    eng = Engine(0)
+    eng.load_reference(idx)
+    assert eng.sieve_info()["kind"] == "lds"
+    st_row = 11
+    g, _ = synth.make_genome(sdb, "ecoli", sdb.profiles["ecoli"][st_row], size=4_600_000)
+    n = 10_000_000
+    packed, qrows, lens, wpr, qstride = synth.synth_reads_gpu(eng, torch, dev, g, n, 150, seed=synth.SEED)
+    eng.reset_sample()
+    eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), n, wpr, qstride)
+    eng.typing_enqueue(penalty=100)
+    st, chd, letd = eng.typing_fetch()
+    assert int(st.counters[0]) > 5_000_000                     # ~9 k on-locus reads x 1,430 alleles
+    calls = st_calls(idx, mdb.metaMLST_db(sdb.path), eng, st, chd, letd, {"ecoli"})
+    assert calls == {"ecoli": st_row + 1}
+    half = (n // 2) & ~63
+    eng.reset_sample()
+    eng.submit_packed_device(packed.data_ptr(), qrows.data_ptr(), lens.data_ptr(), half, wpr, qstride)
+    eng.submit_packed_device(packed.data_ptr() + half * wpr * 4, qrows.data_ptr() + half * qstride, lens.data_ptr() + half * 2, n - half, wpr, qstride)
+    fx.assert_stats_equal(st, eng.stats(), counters=(0, 1, 4, 5, 6))
+    eng.close()
+
+
+def test_skewed_database_at_bench_size_both_extension_kernels_by_properties():
+    """The PubMLST-shaped database at the size bench.py runs it (alleles per locus 10 ... 10,000: loci up to 512 alleles take
+    the block-haplotype kernel, larger ones the pair kernel), 4 M reads of the six-genome metagenome made
+    on the GPU.  No oracle at this size (its index build is quadratic in the alleles of a locus): properties instead --
+    the two kernels forced onto EVERY locus in turn give the same statistics as the mixed default, the halves are
+    additive, and every locus that is not typed as planted has one of the two causes of the reference's scoring that
+    test_pubmlst_shaped_database_... names (near-duplicate locus / one-column neighbour with fewer records)."""
+    import torch
+    sdb = synth.make_skewed_db(os.path.join(_TMP, "skew_bench.db"), n_species=6, hi=10_000)
+    idx = load_index(sdb.path)
+    dev = torch.device("cuda", 0)
+    plan = synth.metagenome_plan(sdb, 6)
+    eng = Engine(0)
+    eng.load_reference(idx)
+    info = eng.extend_info()
+    packed, qrows, lens, wpr, qstride, n = synth.make_metagenome_gpu(eng, torch, dev, sdb, plan, 4_000_000, 2_000_000, seed=7)
+
+    def run(e, pieces):
+        e.reset_sample()
+        at = 0
+        for c in pieces:
+            e.submit_packed_device(packed.data_ptr() + at * wpr * 4, qrows.data_ptr() + at * qstride, lens.data_ptr() + at * 2, c, wpr, qstride)
+            at += c
+        return e.stats()
+
+    s0 = run(eng, [n])
+    half = (n // 2) & ~63
+    fx.assert_stats_equal(s0, run(eng, [half, n - half]), counters=(0, 1, 4, 5, 6))
+    assert 0 < info["loci"] < idx.n_loci                       # both kernels at work in the default
+    for env in ({"MLST_EXT_LDS_KB": "0"}, {"MLST_EXT_HAP_MAX": "100000", "MLST_EXT_LDS_KB": "150"}):      # every locus pair by pair / by block haplotypes
+        os.environ.update(env)
+        try:
+            e2 = Engine(0)
+            e2.load_reference(idx)
+            i2 = e2.extend_info()
+            assert (i2["loci"] == 0) if "MLST_EXT_HAP_MAX" not in env else (i2["loci"] > info["loci"])
+            fx.assert_stats_equal(s0, run(e2, [n]), counters=(0, 1, 4, 5, 6))
+            e2.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    chosen = pick_alleles_fast(idx, s0, 100)
+    dup = set(sdb.duplicates) | set(sdb.duplicates.values())
+    for sp, _, st_row in plan:
+        for (gene, _), al in zip(sdb.loci[sp], sdb.profiles[sp][st_row]):
+            l = idx.locus_index(sp, gene)
+            a = chosen.get(l)
+            if a is not None and int(idx.allele_no[a]) == int(al):
+                continue
+            if (sp, gene) in dup:
+                continue
+            lo = int(idx.locus_begin[l])
+            p = lo + int(np.nonzero(idx.allele_no[lo:lo + int(idx.locus_count[l])] == int(al))[0][0])
+            if a is None or s0.n_hits[p] < 50:                   # (a genome at the low end of the log-normal abundances: too few reads to type)
+                continue
+            sa, sb = idx.sequence(p), idx.sequence(a)
+            diff = [i for i in range(min(len(sa), len(sb))) if sa[i] != sb[i]]
+            assert len(sa) == len(sb) and 1 <= len(diff) <= 2 and all(i < 150 or i >= len(sa) - 150 for i in diff) and s0.n_hits[a] < s0.n_hits[p], (sp, gene, diff)
+    eng.close()

@@ -786,3 +786,61 @@ def test_replayed_typing_graph_with_foreign_copies_in_between():
         v = h.to(dev)
         torch.cuda.synchronize(dev)
         del t, u, v, h
+
+
+def test_four_engines_four_process_groups_both_repeat_paths_over_rccl():
+    """What bench.py --gpus N sets up per rank, in a group of one: FOUR engines, each with its own
+    dist.new_group() (its own RCCL communicator and stream) and its own StreamedShard, steps queued round-robin as the
+    pipelined loop does, and BOTH repair paths forced on every engine -- a counts buffer that is too small (the second half
+    runs again in the fixed layout) and a statistics layout that misses hit loci (exchanged again, fixed).  Every step of every
+    engine equals the plain calls; what is left untested before the 8-GPU run is a real peer."""
+    import torch
+    import torch.distributed as dist
+    from metamlst_amd.dist import StreamedShard
+    db, idx = fx.ecoli_small(80)
+    samples = [fx.isolate_reads(db, "ecoli", 3 + k, n_reads=7000 + 500 * k)[:3] for k in range(4)]
+    plain = Engine(0)
+    plain.load_reference(idx)
+    want = []
+    for fb, fq, off in samples:
+        plain.reset_sample()
+        plain.submit_reads(fb, fq, off)
+        s0 = plain.stats()
+        ch = pick_alleles_fast(idx, s0, 100)
+        want.append((s0, ch, {a: bytes(v) for a, v in plain.consensus(sorted(ch.values())).items()}))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29543", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    shards, engines = [], []
+    try:
+        groups = [dist.new_group(ranks=[0]) for _ in range(4)]
+        for k in range(4):
+            e = Engine(0)
+            e.load_reference(idx)
+            engines.append(e)
+            shards.append(StreamedShard(e, torch.device("cuda", 0), force_collectives=True, group=groups[k]))
+        assert len({id(g) for g in groups}) == 4
+        for step in range(6):
+            if step == 3:
+                for sh in shards:
+                    sh.cap_cols = 1024           # too small for the seven loci
+            if step == 4:
+                for sh in shards:
+                    sh._set_listed([0])          # misses six of the seven hit loci
+            for k in range(4):                   # all four queued before any is fetched: their collectives are in flight together
+                fb, fq, off = samples[(k + step) % 4]
+                shards[k].enqueue(lambda e=engines[k], fb=fb, fq=fq, off=off: (e.reset_sample(), e.submit_reads(fb, fq, off)))
+            for k in range(4):
+                st, chosen, letters = shards[k].fetch()
+                s0, ch, cons = want[(k + step) % 4]
+                fx.assert_stats_equal(st, s0)
+                assert chosen == ch and {a: bytes(v) for a, v in letters.items()} == cons, (step, k)
+        assert all(sh.repeats == 1 and sh.stats_repeats == 1 for sh in shards), [(sh.repeats, sh.stats_repeats) for sh in shards]
+    finally:
+        for sh in shards:
+            sh.close()
+        for e in engines:
+            e.close()
+        if created:
+            dist.destroy_process_group()
