@@ -2165,12 +2165,13 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
     const int tid = threadIdx.x, nthr = blockDim.x, nwv = blockDim.x >> 6;      // 64..1024 threads per work item
     for (int i = tid; i < 128; i += nthr) s_pentab[i] = E.pen_tab[i];
     u64 c_tot = 0, c_ign = 0;                     // block-level counters, flushed once at the end (thread 0)
-    u64 N;                                        // records of this submission, sorted by locus (k_ext_prep)
+    u64 N;                                        // records of this submission, in item order (k_ext_prep)
     { const u64 b0 = E.ctr->items_done, e0 = E.ctr->n_items < E.cap_items ? E.ctr->n_items : E.cap_items; N = e0 - b0; if (N > cap_xrec) N = cap_xrec; }
     // Work queue: items cost different amounts (mismatch density, allele count of the locus), so workgroups take the next
     // record from a counter instead of a fixed stride.  32 counters in separate lines; counter q hands out the records
-    // q B .. (q + 1) B - 1 in order (B = N / 32 rounded up): the records are sorted by locus, so the workgroups on one counter
-    // work through the same few loci and each meets runs of one locus.  Own counter first, then the others'.  Tickets are
+    // q B .. (q + 1) B - 1 in order (B = N / 32 rounded up).  (The records are in item order, i.e. in read order: NOT grouped by
+    // locus -- round 5 tried holding a workgroup's additions in LDS across items of one locus and found no runs to hold; with the
+    // additions switched off altogether k_extend is no faster on cfg2, profiles/round5/extend.md.)  Own counter first, then the others'.  Tickets are
     // drawn two records ahead: the one after the current is known when the current one starts and is fetched meanwhile.
     const u64 QB = (N + EXT_Q - 1) / EXT_Q;
     u32 myq = blockIdx.x % EXT_Q, tried = 0;      // thread 0 only: current queue, exhausted queues seen in a row

@@ -66,13 +66,13 @@ def main():
         t0 = time.time()
         orig_load = Engine.load_reference
 
-        def load_with_env(self, idx):
+        def load_with_env(self, idx, cache_path=None):
             v = [x for x in engines if x[1] is self][0][0]
             ev = env_of(v)
             old = {k: os.environ.get(k) for k in ev}
             os.environ.update(ev)
             try:
-                return orig_load(self, idx)
+                return orig_load(self, idx)      # (no file cache: every variant builds or takes the in-process index)
             finally:
                 for k, o in old.items():
                     if o is None:
