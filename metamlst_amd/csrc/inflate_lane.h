@@ -148,9 +148,13 @@ __device__ __attribute__((always_inline)) inline void tok_body(const u8* comp, c
 // this path holds at most LIT_BASE bytes), so a pointer that reaches a literal takes the byte with it and is final at once;
 // nothing is stored to or gathered from global memory before the end, where the text leaves the LDS in 16-byte stores, and
 // the newlines of every 2^nl_shift-byte cell of the text buffer are counted on the way (the FASTQ parser's first pass).
-__device__ __attribute__((always_inline)) inline u32 wave_incl_scan(u32 v) {
-    #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const u32 y = (u32)__shfl_up((int)v, o); if ((int)(threadIdx.x & 63u) >= o) v += y; }
+__device__ __attribute__((always_inline)) inline u32 wave_incl_scan(u32 v) {      // DPP lane moves: no trip through the LDS crossbar (__shfl_up was six of them per tile)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31
     return v;
 }
 __device__ __attribute__((always_inline)) inline u32 nl_count4(u32 w) {      // newlines among the four bytes of w
@@ -209,8 +213,10 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
             u64 todo = __ballot(done < len);
             while (todo) {
                 const int k = __ffsll((long long)todo) - 1; todo &= todo - 1;
-                const u32 tt = (u32)__shfl((int)t, k), tl = (u32)__shfl((int)len, k), td = (u32)__shfl((int)dst, k), t_done = (u32)__shfl((int)done, k);
-                const u32 t_nxt = (u32)__shfl((int)nxt, k);
+                // (k is wave-uniform: v_readlane, not __shfl -- five trips through the LDS crossbar per long token were most of the fill phase)
+                const u32 tt = (u32)__builtin_amdgcn_readlane((int)t, k), tl = (u32)__builtin_amdgcn_readlane((int)len, k), td = (u32)__builtin_amdgcn_readlane((int)dst, k),
+                          t_done = (u32)__builtin_amdgcn_readlane((int)done, k);
+                const u32 t_nxt = (u32)__builtin_amdgcn_readlane((int)nxt, k);
                 if ((tt >> 30) == TAG_MATCH) {
                     const u32 dist = (tt & 0x7FFFu) + 1u;
                     for (u32 j = t_done + lane; j < tl; j += 64) ptr[td + j] = (u16)(td + j - dist);
@@ -245,23 +251,24 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
         }
         for (int round = 0; round < 18; round++) {
             u32 next = 0;
-            for (u32 m = live; __ballot(m != 0); ) {                    // (every lane walks its own set bits, four pairs at a time: their LDS reads are independent)
-                u32 pj[4], w[4], r0[4], r1[4]; bool on[4];
+            constexpr int PJ = 4;      // pairs per turn (8 measured no faster: profiles/round5/inflate.md)
+            for (u32 m = live; __ballot(m != 0); ) {                    // (every lane walks its own set bits, PJ pairs at a time: their LDS reads are independent)
+                u32 pj[PJ], w[PJ], r0[PJ], r1[PJ]; bool on[PJ];
                 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < PJ; k++) {
                     on[k] = m != 0;
                     pj[k] = on[k] ? (u32)__ffs((int)m) - 1u : 0u;
                     m &= m - 1;
                 }
                 #pragma unroll
-                for (int k = 0; k < 4; k++) w[k] = on[k] ? ptr2[tid + pj[k] * NT] : (LIT_BASE | (LIT_BASE << 16));
+                for (int k = 0; k < PJ; k++) w[k] = on[k] ? ptr2[tid + pj[k] * NT] : (LIT_BASE | (LIT_BASE << 16));
                 #pragma unroll
-                for (int k = 0; k < 4; k++) {      // (a half that is a literal already reads slot 0 and keeps its value)
+                for (int k = 0; k < PJ; k++) {      // (a half that is a literal already reads slot 0 and keeps its value)
                     const u32 q0 = w[k] & 0xFFFFu, q1 = w[k] >> 16;
                     r0[k] = ptr[q0 < LIT_BASE ? q0 : 0u]; r1[k] = ptr[q1 < LIT_BASE ? q1 : 0u];
                 }
                 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < PJ; k++) {
                     const u32 q0 = w[k] & 0xFFFFu, q1 = w[k] >> 16;
                     const u32 n0 = q0 < LIT_BASE ? r0[k] : q0, n1 = q1 < LIT_BASE ? r1[k] : q1;
                     if (on[k]) {
