@@ -45,7 +45,7 @@ ALG_BYTES_BASES = 40      # 2-bit bases of a 150 bp read, rounded to the 10-word
 ALG_BYTES_SURVEY = 188    # 38 B 2-bit bases + 150 B Phred per 150 bp read (reported beside, never used for frac)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GINSTR = 930.0  # measured simple-op issue rate of the whole chip, G wave-instructions/s (profiles/round1/valu_rate2.txt)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "round4")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "round5")
 _KEEP_ALIVE: list = []
 
 
@@ -524,7 +524,7 @@ def rooflines(w, res, eng):
         tr = pmc.get(kernel, {}).get("hbm_bytes_per_launch")
         return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": int(tr * w.n_reads / pmc.get("reads_per_launch", w.n_reads)) if tr else None,
-                "traffic_source": ("profiles/round4/pmc_%s.json: rocprofv3 --pmc passes of this command (profiles/pmc_round2.sh), committed -- not measured by this run" % w.name) if tr else None,
+                "traffic_source": ("profiles/round5/pmc_%s.json: rocprofv3 --pmc passes of this command (profiles/pmc_round2.sh), committed -- not measured by this run" % w.name) if tr else None,
                 "alg_bytes_per_launch": int(alg), "alg_bytes_are": what, "alg_bytes_per_read": ALG_BYTES_BASES, "reads_per_launch": w.n_reads, "avg_launch_ms": round(ms, 4),
                 "launch_ms_spread": res.get("iso_launch_spread", {}).get(key),
                 "duration_source": "HIP events on the engine's stream around each of 20 serial launches, median (= rocprofv3 --kernel-trace average of --pipeline 1)",
@@ -556,7 +556,7 @@ def rooflines(w, res, eng):
         scale = pairs / max(1, pmc.get("k_extend", {}).get("pairs_per_launch", pairs))
         rext["achieved"] = round(valu * scale / (ext_ms * 1e-3) / 1e9, 1)
         rext["frac"] = round(rext["achieved"] / VALU_PEAK_GINSTR, 4)
-        rext["valu_count_source"] = "profiles/round4/pmc_%s.json (SQ_INSTS_VALU of a rocprofv3 --pmc pass, committed); the duration is this run's" % w.name
+        rext["valu_count_source"] = "profiles/round5/pmc_%s.json (SQ_INSTS_VALU of a rocprofv3 --pmc pass, committed); the duration is this run's" % w.name
     return roof, rext
 
 
@@ -625,13 +625,20 @@ def end_to_end(w, args, torch, device):
     with ThreadPoolExecutor(max(1, min(64, os.cpu_count() or 1))) as ex:      # zlib releases the GIL
         parts = list(ex.map(bgzf_block, [raw[at:at + 65280] for at in range(0, len(raw), 65280)]))
     comp = np.frombuffer(b"".join(parts) + bgzf_block(b""), np.uint8)
-    # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks, here 49,152 of them = one pass of the inflate
-    # kernels with k_inflate_tok2, ~570 MB compressed -- the file reader's chunk size): the copy of piece k + 1 and its inflate
-    # run beside the parse and pass 1 of piece k (three streams, mlst_submit_fastq_bgzf)
-    per_piece = int(os.environ.get("MLST_BENCH_BGZF_PIECE", "49152"))
+    # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks, here 32,768 of them ~ the file reader's 384 MB
+    # chunks, from page-locked buffers like the reader's): the copy of piece k + 1 and its inflate run beside the parse and
+    # pass 1 of piece k (three streams, mlst_submit_fastq_bgzf)
+    per_piece = int(os.environ.get("MLST_BENCH_BGZF_PIECE", "32768"))
     cuts = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
     pieces = [comp[int(cuts[a]):int(cuts[min(a + per_piece, len(parts))])] for a in range(0, len(parts), per_piece)]
     pieces[-1] = comp[int(cuts[(len(pieces) - 1) * per_piece]):]            # (with the end-of-file block)
+    from metamlst_amd.engine import pinned_array
+    pinned = []
+    for pc in pieces:      # (mlst_alloc_host: a copy from pageable memory is staged by the runtime on the calling thread, 10 ms per 560 MB during which nothing else is queued)
+        pb = pinned_array(int(pc.size))
+        pb[:pc.size] = pc
+        pinned.append(pb[:pc.size])
+    pieces = pinned
 
     def run_bgzf():
         eng.reset_sample()

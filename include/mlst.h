@@ -138,7 +138,13 @@ int mlst_submit_fastq_pair(mlst_handle* h, const uint8_t* text1, uint64_t n1, co
  * not verified (the inflated size is).  With n_consumed_out != NULL a non-final buffer may also end inside a block:
  * the call takes the whole blocks, reports their size, and the caller passes the rest again in front of the next
  * buffer (so a reader never has to walk the block headers itself).  Plain gzip has no block structure to parallelise:
- * inflate it on the host and use mlst_submit_fastq. */
+ * inflate it on the host and use mlst_submit_fastq.
+ * Three stages on three streams (round 5): a call queues the copy of ITS chunk and the inflate of it, then parses and submits
+ * the chunk of the call BEFORE it while the GPU inflates -- so the reads of a non-final chunk enter the statistics with the
+ * next call on this handle (whichever entry that is: every entry that looks at or adds to the sample's state finishes an open
+ * chunk first), n_reads_out counts the records COMPLETED by the call (their sum over a file is the file's record count), and a
+ * corrupt block is reported by the call that finishes its chunk.  `data` may be released when the call returns.
+ * MLST_BGZF_PIPE=0 restores the serial behaviour (copy, inflate, parse and submit inside the call). */
 int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out,
                            uint64_t* n_consumed_out);
 

@@ -25,6 +25,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <chrono>
 #include <unistd.h>
 
 #include "mlst.h"
@@ -3412,7 +3413,7 @@ struct mlst_handle {
     // of piece k (infl_stream) and the parse + pass 1 of piece k - 1 (the engine's stream) run side by side.  Two slots of
     // compressed bytes / block descriptors / error words used in turn; `bz_pend` is the piece whose text is being inflated
     // (or has been) and has not been parsed yet.
-    struct BzSlot { u8* d_comp = nullptr; u64 cap_comp = 0; void* d_blk = nullptr; u64 cap_blk = 0; hipEvent_t ev_copied = nullptr, ev_inflated = nullptr; u32* d_err = nullptr; u32* h_err = nullptr; };
+    struct BzSlot { u8* d_comp = nullptr; u64 cap_comp = 0; void* d_blk = nullptr; void* h_blk = nullptr; u64 cap_blk = 0; hipEvent_t ev_copied = nullptr, ev_inflated = nullptr; u32* d_err = nullptr; u32* h_err = nullptr; };
     BzSlot bz[2]; int bz_slot = 0, bz_mode = -1; hipStream_t infl_stream = nullptr;
     struct { bool on = false, counted = false; int slot = 0, tslot = 0, paired = 0; u64 text_bytes = 0; } bz_pend;
     u32 depth_cap = 0; u64* d_capbuf = nullptr; u64 cap_capcols = 0;      // depth-capped pile-up (mlst_set_depth_cap): lo, hi, thr (u64 each) and cnt (u32) per column
@@ -4769,7 +4770,7 @@ static int bz_flush(mlst_handle* h) { return h->bz_pend.on ? bz_finish(h, false,
 static void bz_free(mlst_handle* h) {
     if (h->infl_stream) hipStreamSynchronize(h->infl_stream);
     for (auto& B : h->bz) {
-        hipFree(B.d_comp); hipFree(B.d_blk); hipFree(B.d_err); if (B.h_err) hipHostFree(B.h_err);
+        hipFree(B.d_comp); hipFree(B.d_blk); hipFree(B.d_err); if (B.h_err) hipHostFree(B.h_err); if (B.h_blk) hipHostFree(B.h_blk);
         if (B.ev_copied) hipEventDestroy(B.ev_copied); if (B.ev_inflated) hipEventDestroy(B.ev_inflated);
         B = mlst_handle::BzSlot();
     }
@@ -4811,6 +4812,9 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
     if (text_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
     if (n_consumed_out) *n_consumed_out = n_bytes;
     if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
+    static const bool bz_trace = getenv("MLST_BGZF_TRACE") != nullptr;      // host-side time stamps of a call's steps (stderr)
+    auto bz_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double bt0 = bz_trace ? bz_now() : 0.0;
     if (piped) {
         uint64_t done = 0, n1 = 0;
         if (blks.empty()) {      // nothing new: the open piece (if any) is finished; a last call also types what the carry holds
@@ -4832,11 +4836,22 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
                             HIPCHK(h, dmalloc(&B.d_err, (u64)16)); HIPCHK(h, hipHostMalloc((void**)&B.h_err, 64, hipHostMallocDefault)); }
         // (the slot's last user, piece k - 2, has been finished: its inflate is over)
         if (B.cap_comp < n_bytes) { hipFree(B.d_comp); B.d_comp = nullptr; HIPCHK(h, dmalloc(&B.d_comp, n_bytes + n_bytes / 8 + 16)); B.cap_comp = n_bytes + n_bytes / 8; }
-        if (B.cap_blk < blks.size()) { hipFree(B.d_blk); B.d_blk = nullptr; BgzfBlk* pb = nullptr; HIPCHK(h, dmalloc(&pb, (u64)blks.size() + blks.size() / 8)); B.d_blk = pb; B.cap_blk = blks.size() + blks.size() / 8; }
+        if (B.cap_blk < blks.size()) {
+            hipFree(B.d_blk); B.d_blk = nullptr; if (B.h_blk) { hipHostFree(B.h_blk); B.h_blk = nullptr; }
+            const u64 cap = blks.size() + blks.size() / 8;
+            BgzfBlk* pb = nullptr; HIPCHK(h, dmalloc(&pb, cap)); B.d_blk = pb;
+            HIPCHK(h, hipHostMalloc(&B.h_blk, cap * sizeof(BgzfBlk), hipHostMallocDefault));
+            B.cap_blk = cap;
+        }
         { int rc = next_text_slot(h, text_bytes + text_bytes / 16); if (rc) return rc; }
         const int tslot = h->fq_slot;
+        const double btc0 = bz_trace ? bz_now() : 0.0;
         HIPCHK(h, hipMemcpyAsync(B.d_comp, data, n_bytes, hipMemcpyHostToDevice, h->copy_stream));
-        HIPCHK(h, hipMemcpyAsync(B.d_blk, blks.data(), blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->copy_stream));
+        if (bz_trace) fprintf(stderr, "  hipMemcpyAsync of %.1f MB returned after %.3f ms (%.3f ms into the queueing)\n", n_bytes / 1e6, bz_now() - btc0, btc0 - bt0);
+        // (the block list through page-locked memory: a copy from the vector's pageable memory is staged by the runtime on the
+        // calling thread, BEHIND the copy queued in front of it on this stream -- the call sat out the whole 10 ms of a 560 MB piece there)
+        memcpy(B.h_blk, blks.data(), blks.size() * sizeof(BgzfBlk));
+        HIPCHK(h, hipMemcpyAsync(B.d_blk, B.h_blk, blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->copy_stream));
         HIPCHK(h, hipEventRecord(B.ev_copied, h->copy_stream));
         HIPCHK(h, hipStreamWaitEvent(h->infl_stream, B.ev_copied, 0));
         HIPCHK(h, hipStreamWaitEvent(h->infl_stream, h->ev_packed[tslot], 0));      // the text slot's last reader (an event never recorded counts as complete)
@@ -4850,10 +4865,15 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
         HIPCHK(h, hipEventRecord(B.ev_inflated, h->infl_stream));
         // piece k - 1 while the GPU inflates piece k
         int rc = MLST_OK;
+        const double bt1 = bz_trace ? bz_now() : 0.0;
         if (h->bz_pend.on) { rc = bz_finish(h, false, &n1); done += n1; }
+        const double bt2 = bz_trace ? bz_now() : 0.0;
         h->bz_pend.on = true; h->bz_pend.counted = counted; h->bz_pend.slot = sl; h->bz_pend.tslot = tslot; h->bz_pend.paired = paired; h->bz_pend.text_bytes = text_bytes - text_at;
         if (!rc && final_chunk) { rc = bz_finish(h, true, &n1); done += n1; }
+        const double bt3 = bz_trace ? bz_now() : 0.0;
         const hipError_t ce = hipStreamSynchronize(h->copy_stream);      // blks / data may be released by the caller after this
+        if (bz_trace) fprintf(stderr, "bgzf call at %.3f: headers + queueing %.3f ms, piece before %.3f ms, own piece (final) %.3f ms, wait for the copy %.3f ms\n",
+                              bt0, bt1 - bt0, bt2 - bt1, bt3 - bt2, bz_now() - bt3);
         if (rc) { if (h->infl_stream) hipStreamSynchronize(h->infl_stream); h->bz_pend.on = false; return rc; }
         HIPCHK(h, ce);
         if (n_reads_out) *n_reads_out = done;

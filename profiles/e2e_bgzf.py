@@ -60,6 +60,14 @@ per_piece = int(os.environ.get("PER_PIECE", "16384"))
 cuts = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
 pieces = [comp[int(cuts[a]):int(cuts[min(a + per_piece, len(parts))])] for a in range(0, len(parts), per_piece)]
 pieces[-1] = comp[int(cuts[(len(pieces) - 1) * per_piece]):]
+if os.environ.get("PINNED"):      # page-locked source buffers, as the file reader's (engine.pinned_array): one DMA transfer per piece
+    from metamlst_amd.engine import pinned_array
+    pinned = []
+    for pc in pieces:
+        b_ = pinned_array(pc.size)
+        b_[:pc.size] = pc
+        pinned.append(b_[:pc.size])
+    pieces = pinned
 
 out = {"reads": N, "text_bytes": len(raw), "bgzf_bytes": int(comp.size), "level": LEVEL, "pieces": len(pieces)}
 ref = None
