@@ -625,10 +625,11 @@ def end_to_end(w, args, torch, device):
     with ThreadPoolExecutor(max(1, min(64, os.cpu_count() or 1))) as ex:      # zlib releases the GIL
         parts = list(ex.map(bgzf_block, [raw[at:at + 65280] for at in range(0, len(raw), 65280)]))
     comp = np.frombuffer(b"".join(parts) + bgzf_block(b""), np.uint8)
-    # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks, here 32,768 of them ~ the file reader's 384 MB
-    # chunks, from page-locked buffers like the reader's): the copy of piece k + 1 and its inflate run beside the parse and
-    # pass 1 of piece k (three streams, mlst_submit_fastq_bgzf)
-    per_piece = int(os.environ.get("MLST_BENCH_BGZF_PIECE", "32768"))
+    # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks from page-locked buffers), here 16,384 blocks a
+    # piece = one turn of k_inflate_tok: the copy of piece k + 1 and its inflate run beside the parse and pass 1 of piece k (three
+    # streams, mlst_submit_fastq_bgzf).  This leg's 24 M reads are 7 such pieces; pieces of 32,768 / 49,152 blocks (k_inflate_tok2,
+    # the file reader's 384 MB chunks) give 290 here and pay on longer inputs: 48 M reads 389 against 356 (profiles/round5/inflate.md)
+    per_piece = int(os.environ.get("MLST_BENCH_BGZF_PIECE", "16384"))
     cuts = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
     pieces = [comp[int(cuts[a]):int(cuts[min(a + per_piece, len(parts))])] for a in range(0, len(parts), per_piece)]
     pieces[-1] = comp[int(cuts[(len(pieces) - 1) * per_piece]):]            # (with the end-of-file block)

@@ -4626,7 +4626,7 @@ static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padde
     // a larger piece costs it a turn per 16,384 blocks (49,152 blocks: 13.2 ms) while the second still takes one (9 ms).
     // MLST_INFLATE_TOK = 1 / 2 forces one of them; default: by the number of blocks.
     const char* tok_e = getenv("MLST_INFLATE_TOK"); const int tok_env = tok_e ? atoi(tok_e) : 0;
-    const int tok_kind = tok_env == 1 || tok_env == 2 ? tok_env : (n_blk > 24576u ? 2 : 1);
+    const int tok_kind = tok_env == 1 || tok_env == 2 ? tok_env : (n_blk > 18432u ? 2 : 1);      // (24,576 blocks: 1.5 turns of the first = 8.8 ms, one of the second ~7.5)
     const u32 pass = std::min(n_blk, tok_kind == 1 ? INFL_PASS : INFL_PASS2);
     if (h->cap_itok_blocks < pass) {
         HIPCHK(h, hipStreamSynchronize(st)); HIPCHK(h, hipStreamSynchronize(h->stream));
