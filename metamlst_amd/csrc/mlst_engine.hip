@@ -946,6 +946,12 @@ __device__ inline void rt_examine_one(u64 e, const u32* __restrict__ packed, u64
     const u32 tile = R.emitted[(u64)p * (R.tiles_max + 1) + 1 + jt];
     const u64 rr = ((u64)tile * NWP + wv) * 64 + ln;
     if (rr >= n_reads) return;
+    // experiments of round 5 (MLST_RT_DEBUG, profiles/round5/sieve.md): 4 = every second entry is dropped unexamined (TIMING ONLY,
+    // candidates are lost: what the examination would cost if a check on the entry's 33 hash bits alone removed the filter's false
+    // positives first); 8 = the read becomes a candidate without its row being fetched (results unchanged -- k_seed looks every
+    // seed of a candidate up exactly -- but k_seed sees every parked read: what leaving the examination out would cost there)
+    if ((R.dbg & 4u) && (((u32)e ^ (u32)(e >> 7)) & 1u)) return;
+    if (R.dbg & 8u) { atomicOr(&R.flags.p[rr >> 5], 1u << (rr & 31)); return; }
     // a read on a locus arrives here nine times, from nine owners: once its flag is up the other eight need no row (640
     // bytes each).  A stale look (the flag words are written by atomics of other XCDs) only costs the fetch it would have saved.
     if (CHECK_FLAG && ((__hip_atomic_load(&R.flags.p[rr >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (rr & 31)) & 1u)) return;

@@ -111,6 +111,8 @@ def main():
     ref = None
     for v, e, _ in engines:
         info = e.extend_info()
+        ev_run = {k_: v_ for k_, v_ in env_of(v).items() if k_ in ("MLST_RT_DEBUG",)}      # switches read at submission time
+        os.environ.update(ev_run)
         if os.environ.get("MLST_X_SKIP") and hasattr(e.lib, "mlst_debug_ext_skip"):
             e.lib.mlst_debug_ext_skip(int(os.environ["MLST_X_SKIP"]))
         e.reset_sample()
@@ -138,6 +140,8 @@ def main():
                 ms, k = e.kernel_time(name)
                 more[name].append(ms)
         e.set_profiling(0)
+        for k_ in ev_run:
+            os.environ.pop(k_, None)
         trace = None
         if hasattr(e.lib, "mlst_debug_ext_trace"):      # profiling build (-DMLST_EXT_TRACE): cycles per phase, summed over waves
             import ctypes as C
