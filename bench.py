@@ -73,7 +73,7 @@ def parse_args():
     ap.add_argument("--stagger-ms", type=float, default=None,
                     help="time between the first submissions of a block (default: 0.75 ms when the engines have their own CU shares, else 0)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg2 block and the end-to-end rates")
-    ap.add_argument("--e2e-reads", type=int, default=24_000_000, help="reads of the end-to-end (host FASTQ text -> ST) measurements (cfg2's legs: its 10 M)")
+    ap.add_argument("--e2e-reads", type=int, default=48_000_000, help="reads of the end-to-end (host FASTQ text -> ST) measurements (cfg2's legs: its 10 M); 24 M until round 5")
     ap.add_argument("--calibrate", action="store_true",
                     help="before the timed region copy the Phred rows 3x with torch (a known-size wide coalesced stream) "
                          "so a rocprofv3 --pmc FETCH_SIZE pass of this command can be calibrated")
@@ -625,11 +625,11 @@ def end_to_end(w, args, torch, device):
     with ThreadPoolExecutor(max(1, min(64, os.cpu_count() or 1))) as ex:      # zlib releases the GIL
         parts = list(ex.map(bgzf_block, [raw[at:at + 65280] for at in range(0, len(raw), 65280)]))
     comp = np.frombuffer(b"".join(parts) + bgzf_block(b""), np.uint8)
-    # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks from page-locked buffers), here 16,384 blocks a
-    # piece = one turn of k_inflate_tok: the copy of piece k + 1 and its inflate run beside the parse and pass 1 of piece k (three
-    # streams, mlst_submit_fastq_bgzf).  This leg's 24 M reads are 7 such pieces; pieces of 32,768 / 49,152 blocks (k_inflate_tok2,
-    # the file reader's 384 MB chunks) give 290 here and pay on longer inputs: 48 M reads 389 against 356 (profiles/round5/inflate.md)
-    per_piece = int(os.environ.get("MLST_BENCH_BGZF_PIECE", "16384"))
+    # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks from page-locked buffers): the copy of piece k + 1
+    # and its inflate run beside the parse and pass 1 of piece k (three streams, mlst_submit_fastq_bgzf).  Pieces of 49,152 blocks
+    # (one turn of k_inflate_tok2) where the input has several of them, else of 16,384 (one turn of k_inflate_tok): on 24 M reads
+    # 16,384 / 32,768 / 49,152 blocks give 312 / 290 / 294-340 Mreads/s, on 48 M reads 356 / - / 380-390 (profiles/round5/inflate.md)
+    per_piece = int(os.environ.get("MLST_BENCH_BGZF_PIECE", "49152" if nz >= 40_000_000 else "16384"))
     cuts = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
     pieces = [comp[int(cuts[a]):int(cuts[min(a + per_piece, len(parts))])] for a in range(0, len(parts), per_piece)]
     pieces[-1] = comp[int(cuts[(len(pieces) - 1) * per_piece]):]            # (with the end-of-file block)

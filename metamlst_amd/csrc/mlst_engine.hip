@@ -4791,6 +4791,62 @@ static int bz_stream(mlst_handle* h) {
     return MLST_OK;
 }
 
+// One piece through the three stages: its copy and inflate are queued, the piece before it is finished meanwhile (and, for the last
+// piece of a stream, the piece itself).  blks: the piece's blocks, in_off relative to `data`, out_off from FQ_HEAD on.
+static int bz_piece(mlst_handle* h, const uint8_t* data, u64 n_bytes, const std::vector<BgzfBlk>& blks, u64 text_end, int paired, bool final_piece, uint64_t* done) {
+    static const bool bz_trace = getenv("MLST_BGZF_TRACE") != nullptr;      // host-side time stamps of a piece's steps (stderr)
+    auto bz_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double bt0 = bz_trace ? bz_now() : 0.0;
+    uint64_t n1 = 0;
+    { int rc = bz_stream(h); if (rc) return rc; }
+    if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    const int sl = h->bz_slot ^= 1;
+    mlst_handle::BzSlot& B = h->bz[sl];
+    if (!B.ev_copied) { HIPCHK(h, hipEventCreateWithFlags(&B.ev_copied, hipEventDisableTiming)); HIPCHK(h, hipEventCreateWithFlags(&B.ev_inflated, hipEventDisableTiming));
+                        HIPCHK(h, dmalloc(&B.d_err, (u64)16)); HIPCHK(h, hipHostMalloc((void**)&B.h_err, 64, hipHostMallocDefault)); }
+    // (the slot's last user, piece k - 2, has been finished: its inflate is over)
+    if (B.cap_comp < n_bytes) { hipFree(B.d_comp); B.d_comp = nullptr; HIPCHK(h, dmalloc(&B.d_comp, n_bytes + n_bytes / 8 + 16)); B.cap_comp = n_bytes + n_bytes / 8; }
+    if (B.cap_blk < blks.size()) {
+        hipFree(B.d_blk); B.d_blk = nullptr; if (B.h_blk) { hipHostFree(B.h_blk); B.h_blk = nullptr; }
+        const u64 cap = blks.size() + blks.size() / 8;
+        BgzfBlk* pb = nullptr; HIPCHK(h, dmalloc(&pb, cap)); B.d_blk = pb;
+        HIPCHK(h, hipHostMalloc(&B.h_blk, cap * sizeof(BgzfBlk), hipHostMallocDefault));
+        B.cap_blk = cap;
+    }
+    { int rc = next_text_slot(h, text_end + text_end / 16); if (rc) return rc; }
+    const int tslot = h->fq_slot;
+    HIPCHK(h, hipMemcpyAsync(B.d_comp, data, n_bytes, hipMemcpyHostToDevice, h->copy_stream));
+    // (the block list through page-locked memory: a copy from the vector's pageable memory is staged by the runtime on the
+    // calling thread, BEHIND the copy queued in front of it on this stream -- the call sat out the whole 10 ms of a 560 MB piece there)
+    memcpy(B.h_blk, blks.data(), blks.size() * sizeof(BgzfBlk));
+    HIPCHK(h, hipMemcpyAsync(B.d_blk, B.h_blk, blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(h, hipEventRecord(B.ev_copied, h->copy_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->infl_stream, B.ev_copied, 0));
+    HIPCHK(h, hipStreamWaitEvent(h->infl_stream, h->ev_packed[tslot], 0));      // the text slot's last reader (an event never recorded counts as complete)
+    HIPCHK(h, hipMemsetAsync(B.d_err, 0, 64, h->infl_stream));
+    if (!h->inflate_mode) { const char* e = getenv("MLST_INFLATE_MODE"); h->inflate_mode = e ? atoi(e) : 2; if (h->inflate_mode != 1 && h->inflate_mode != 2) h->inflate_mode = 2; }
+    const bool counted = h->inflate_mode == 2 && !getenv("MLST_BGZF_NOCOUNT");      // the two-kernel inflate counts the newlines of the text it writes
+    if (counted) HIPCHK(h, hipMemsetAsync(h->d_fq_nl[tslot], 0, (text_end / FQ_BLOCK + 2) * 4, h->infl_stream));
+    { int rc = launch_inflate(h, B.d_comp, (u64)B.cap_comp + 16, (const BgzfBlk*)B.d_blk, (u32)blks.size(), h->d_fq_slot[tslot], B.d_err, nullptr, h->infl_stream,
+                              counted ? h->d_fq_nl[tslot] : nullptr); if (rc) return rc; }
+    HIPCHK(h, hipMemcpyAsync(B.h_err, B.d_err, 8, hipMemcpyDeviceToHost, h->infl_stream));
+    HIPCHK(h, hipEventRecord(B.ev_inflated, h->infl_stream));
+    // piece k - 1 while the GPU inflates piece k
+    int rc = MLST_OK;
+    const double bt1 = bz_trace ? bz_now() : 0.0;
+    if (h->bz_pend.on) { rc = bz_finish(h, false, &n1); *done += n1; }
+    const double bt2 = bz_trace ? bz_now() : 0.0;
+    h->bz_pend.on = true; h->bz_pend.counted = counted; h->bz_pend.slot = sl; h->bz_pend.tslot = tslot; h->bz_pend.paired = paired; h->bz_pend.text_bytes = text_end - FQ_HEAD;
+    if (!rc && final_piece) { rc = bz_finish(h, true, &n1); *done += n1; }
+    const double bt3 = bz_trace ? bz_now() : 0.0;
+    const hipError_t ce = hipStreamSynchronize(h->copy_stream);      // blks / data may be released by the caller after this
+    if (bz_trace) fprintf(stderr, "bgzf piece of %zu blocks at %.3f: queueing %.3f ms, piece before %.3f ms, own piece (final) %.3f ms, wait for the copy %.3f ms\n",
+                          blks.size(), bt0, bt1 - bt0, bt2 - bt1, bt3 - bt2, bz_now() - bt3);
+    if (rc) { if (h->infl_stream) hipStreamSynchronize(h->infl_stream); h->bz_pend.on = false; return rc; }
+    HIPCHK(h, ce);
+    return MLST_OK;
+}
+
 extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint64_t n_bytes, int final_chunk, int paired, uint64_t* n_reads_out,
                                       uint64_t* n_consumed_out) {
     if (!h || !h->have_state) return fail(h, MLST_E_INVALID, "no reference loaded");
@@ -4801,6 +4857,7 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
     hipSetDevice(h->device);
     const bool piped = bz_mode(h) != 0;
     std::vector<BgzfBlk> blks;
+    std::vector<u64> blk_start;                                   // (piped) where every listed block begins in `data`
     const u64 text_at = piped ? FQ_HEAD : h->fq_carry_len;      // where the first block's text goes in its slot
     u64 text_bytes = text_at;
     for (u64 off = 0; off < n_bytes; ) {
@@ -4812,15 +4869,12 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
             return fail(h, MLST_E_INVALID, "not a whole BGZF block at byte %llu of the chunk", (unsigned long long)off);
         }
         if (isize > 65536) return fail(h, MLST_E_INVALID, "BGZF block at byte %llu claims %u bytes of data", (unsigned long long)off, isize);
-        if (isize) { BgzfBlk b; b.in_off = off + coff; b.in_len = (u32)clen; b.out_off = text_bytes; b.out_len = isize; blks.push_back(b); text_bytes += isize; }
+        if (isize) { BgzfBlk b; b.in_off = off + coff; b.in_len = (u32)clen; b.out_off = text_bytes; b.out_len = isize; blks.push_back(b); if (piped) blk_start.push_back(off); text_bytes += isize; }
         off += total;
     }
     if (text_bytes >= (1ull << 40)) return fail(h, MLST_E_LIMIT, "FASTQ chunk too large");
     if (n_consumed_out) *n_consumed_out = n_bytes;
     if (!h->d_fq_meta) HIPCHK(h, dmalloc(&h->d_fq_meta, (u64)4));
-    static const bool bz_trace = getenv("MLST_BGZF_TRACE") != nullptr;      // host-side time stamps of a call's steps (stderr)
-    auto bz_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double bt0 = bz_trace ? bz_now() : 0.0;
     if (piped) {
         uint64_t done = 0, n1 = 0;
         if (blks.empty()) {      // nothing new: the open piece (if any) is finished; a last call also types what the carry holds
@@ -4834,54 +4888,31 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
             if (n_reads_out) *n_reads_out = done;
             return MLST_OK;
         }
-        { int rc = bz_stream(h); if (rc) return rc; }
-        if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-        const int sl = h->bz_slot ^= 1;
-        mlst_handle::BzSlot& B = h->bz[sl];
-        if (!B.ev_copied) { HIPCHK(h, hipEventCreateWithFlags(&B.ev_copied, hipEventDisableTiming)); HIPCHK(h, hipEventCreateWithFlags(&B.ev_inflated, hipEventDisableTiming));
-                            HIPCHK(h, dmalloc(&B.d_err, (u64)16)); HIPCHK(h, hipHostMalloc((void**)&B.h_err, 64, hipHostMallocDefault)); }
-        // (the slot's last user, piece k - 2, has been finished: its inflate is over)
-        if (B.cap_comp < n_bytes) { hipFree(B.d_comp); B.d_comp = nullptr; HIPCHK(h, dmalloc(&B.d_comp, n_bytes + n_bytes / 8 + 16)); B.cap_comp = n_bytes + n_bytes / 8; }
-        if (B.cap_blk < blks.size()) {
-            hipFree(B.d_blk); B.d_blk = nullptr; if (B.h_blk) { hipHostFree(B.h_blk); B.h_blk = nullptr; }
-            const u64 cap = blks.size() + blks.size() / 8;
-            BgzfBlk* pb = nullptr; HIPCHK(h, dmalloc(&pb, cap)); B.d_blk = pb;
-            HIPCHK(h, hipHostMalloc(&B.h_blk, cap * sizeof(BgzfBlk), hipHostMallocDefault));
-            B.cap_blk = cap;
+        // The chunk goes through the pipeline in pieces.  What the three streams cannot hide is the FIRST piece's copy + inflate (nothing
+        // to parse beside them yet) and the LAST piece's parse + pass 1 (nothing inflating beside them any more): so a chunk that
+        // meets an empty pipeline leads with a piece of 16,384 blocks (one turn of k_inflate_tok), a last chunk ends with one of
+        // 8,192, and what lies between goes in pieces of up to 49,152 (one turn of k_inflate_tok2).  MLST_BGZF_SPLIT=0: the chunk as one piece.
+        static const bool split = [] { const char* e = getenv("MLST_BGZF_SPLIT"); return !(e && e[0] == '0'); }();
+        const size_t nb = blks.size();
+        std::vector<size_t> cuts; cuts.push_back(0);
+        if (split) {
+            size_t lo = 0, hi = nb;
+            if (!h->bz_pend.on && nb > 24576) { lo = 16384; cuts.push_back(lo); }
+            const size_t tail = (final_chunk && hi - lo > 16384) ? 8192 : 0;
+            while (hi - tail - lo > INFL_PASS2) { lo += INFL_PASS2; cuts.push_back(lo); }
+            if (tail) cuts.push_back(hi - tail);
         }
-        { int rc = next_text_slot(h, text_bytes + text_bytes / 16); if (rc) return rc; }
-        const int tslot = h->fq_slot;
-        const double btc0 = bz_trace ? bz_now() : 0.0;
-        HIPCHK(h, hipMemcpyAsync(B.d_comp, data, n_bytes, hipMemcpyHostToDevice, h->copy_stream));
-        if (bz_trace) fprintf(stderr, "  hipMemcpyAsync of %.1f MB returned after %.3f ms (%.3f ms into the queueing)\n", n_bytes / 1e6, bz_now() - btc0, btc0 - bt0);
-        // (the block list through page-locked memory: a copy from the vector's pageable memory is staged by the runtime on the
-        // calling thread, BEHIND the copy queued in front of it on this stream -- the call sat out the whole 10 ms of a 560 MB piece there)
-        memcpy(B.h_blk, blks.data(), blks.size() * sizeof(BgzfBlk));
-        HIPCHK(h, hipMemcpyAsync(B.d_blk, B.h_blk, blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->copy_stream));
-        HIPCHK(h, hipEventRecord(B.ev_copied, h->copy_stream));
-        HIPCHK(h, hipStreamWaitEvent(h->infl_stream, B.ev_copied, 0));
-        HIPCHK(h, hipStreamWaitEvent(h->infl_stream, h->ev_packed[tslot], 0));      // the text slot's last reader (an event never recorded counts as complete)
-        HIPCHK(h, hipMemsetAsync(B.d_err, 0, 64, h->infl_stream));
-        if (!h->inflate_mode) { const char* e = getenv("MLST_INFLATE_MODE"); h->inflate_mode = e ? atoi(e) : 2; if (h->inflate_mode != 1 && h->inflate_mode != 2) h->inflate_mode = 2; }
-        const bool counted = h->inflate_mode == 2 && !getenv("MLST_BGZF_NOCOUNT");      // the two-kernel inflate counts the newlines of the text it writes
-        if (counted) HIPCHK(h, hipMemsetAsync(h->d_fq_nl[tslot], 0, (text_bytes / FQ_BLOCK + 2) * 4, h->infl_stream));
-        { int rc = launch_inflate(h, B.d_comp, (u64)B.cap_comp + 16, (const BgzfBlk*)B.d_blk, (u32)blks.size(), h->d_fq_slot[tslot], B.d_err, nullptr, h->infl_stream,
-                                  counted ? h->d_fq_nl[tslot] : nullptr); if (rc) return rc; }
-        HIPCHK(h, hipMemcpyAsync(B.h_err, B.d_err, 8, hipMemcpyDeviceToHost, h->infl_stream));
-        HIPCHK(h, hipEventRecord(B.ev_inflated, h->infl_stream));
-        // piece k - 1 while the GPU inflates piece k
-        int rc = MLST_OK;
-        const double bt1 = bz_trace ? bz_now() : 0.0;
-        if (h->bz_pend.on) { rc = bz_finish(h, false, &n1); done += n1; }
-        const double bt2 = bz_trace ? bz_now() : 0.0;
-        h->bz_pend.on = true; h->bz_pend.counted = counted; h->bz_pend.slot = sl; h->bz_pend.tslot = tslot; h->bz_pend.paired = paired; h->bz_pend.text_bytes = text_bytes - text_at;
-        if (!rc && final_chunk) { rc = bz_finish(h, true, &n1); done += n1; }
-        const double bt3 = bz_trace ? bz_now() : 0.0;
-        const hipError_t ce = hipStreamSynchronize(h->copy_stream);      // blks / data may be released by the caller after this
-        if (bz_trace) fprintf(stderr, "bgzf call at %.3f: headers + queueing %.3f ms, piece before %.3f ms, own piece (final) %.3f ms, wait for the copy %.3f ms\n",
-                              bt0, bt1 - bt0, bt2 - bt1, bt3 - bt2, bz_now() - bt3);
-        if (rc) { if (h->infl_stream) hipStreamSynchronize(h->infl_stream); h->bz_pend.on = false; return rc; }
-        HIPCHK(h, ce);
+        cuts.push_back(nb);
+        for (size_t c = 0; c + 1 < cuts.size(); c++) {
+            const size_t b0 = cuts[c], b1 = cuts[c + 1];
+            const u64 lo = b0 ? blk_start[b0] : 0, hi = b1 < nb ? blk_start[b1] : n_bytes;
+            std::vector<BgzfBlk> sub(blks.begin() + b0, blks.begin() + b1);
+            const u64 t0 = sub[0].out_off - FQ_HEAD;
+            for (auto& q : sub) { q.in_off -= lo; q.out_off -= t0; }
+            const u64 text_end = sub.back().out_off + sub.back().out_len;
+            const int rc = bz_piece(h, data + lo, hi - lo, sub, text_end, paired, final_chunk != 0 && b1 == nb, &done);
+            if (rc) return rc;
+        }
         if (n_reads_out) *n_reads_out = done;
         return MLST_OK;
     }
