@@ -4199,9 +4199,12 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr, u64 n_read
     if (prod > n_tiles) prod = (u32)(n_tiles ? n_tiles : 1);
     // tiles are handed out dynamically: a workgroup may take up to half as many again as its even share (the spread seen
     // is +-20 %); the capacities below (list of tiles, regions) are sized for that and a workgroup stops asking at the bound
-    const u64 tiles_max = (n_tiles + prod - 1) / prod * 3 / 2 + 8;
+    u64 tiles_max = (n_tiles + prod - 1) / prod * 3 / 2 + 8;
     // expected entries per (owner, tile): tile * seeds / 256 + dummies (~10 % of nw) + ~2 of padding; 25 % and a constant on top
     u64 cap = (u64)((double)tiles_max * ((double)tile / 256.0 * (wpr - 1) + 0.15 * nw + 2.0) * 1.25) + 256; cap = (cap + 31) & ~31ull;      // regions start on 128-byte boundaries, whole 64-byte chunks are written
+    // A layout that is large enough stays (round 5): the capacities are upper bounds, and a submission of fewer reads than the one
+    // before -- the pieces of a bgzip'd file differ in size -- used to re-allocate (a device-wide synchronisation) for its smaller one.
+    if (h->rt_prod == prod && h->rt_nw == nw && h->rt_cap >= cap && h->rt_tiles_max >= tiles_max) { cap = h->rt_cap; tiles_max = h->rt_tiles_max; }
     if (cap >= (1ull << 31) || tiles_max > 0xFFFFull || (u64)RT_OWNERS * prod * (cap / 16) >= (1ull << 32)) return fail(h, MLST_E_LIMIT, "batch too large for the routed sieve (%llu tiles per producer workgroup)", (unsigned long long)tiles_max);
     const u64 need = (u64)RT_OWNERS * prod * cap;
     if (h->cap_rt_arena < need || h->rt_prod != prod || h->rt_cap != (u32)cap) {
