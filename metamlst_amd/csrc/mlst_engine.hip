@@ -258,20 +258,33 @@ __device__ inline void pack_group(const u8* __restrict__ bases, const u8* __rest
                 #pragma unroll
                 for (int k = 0; k < 16; k++) { const u32 p = w * 16 + k; const bool in = p < n; cs[k] = in ? bases[so + p] : (u8)'A'; cq[k] = in ? quals[qo + p] : (u8)33; }
             }
+            // sixteen bases and qualities, four at a time in 32-bit words (round 5; a compare chain per character before: ~350
+            // instructions per word).  Bytes beyond the read are 'A' / '!' here (see above) and come out as zeros, as before.
             u32 anyn = 0, qw[4] = {0, 0, 0, 0};
             #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const u32 p = w * 16 + k;
-                if (p < n) {
-                    const u8 c = cs[k] & 0xDF;               // upper case
-                    u32 b, isn = 0;
-                    if (c == 'A') b = 0; else if (c == 'C') b = 1; else if (c == 'G') b = 2; else if (c == 'T') b = 3; else { b = 0; isn = 1; }
-                    word |= b << (2 * k);
-                    int q = (int)cq[k] - 33; q = q < 0 ? 0 : (q > 127 ? 127 : q);
-                    qw[k >> 2] |= ((u32)q | (isn << 7)) << (8 * (k & 3));
-                    anyn |= isn;
+            for (int j = 0; j < 4; j++) {
+                u32 b4, q4; __builtin_memcpy(&b4, cs + 4 * j, 4); __builtin_memcpy(&q4, cq + 4 * j, 4);
+                const u32 y = (b4 >> 1) & 0x03030303u, y0 = y & 0x01010101u, y1 = (y >> 1) & 0x01010101u;      // bits 1-2 of a letter: A 0, C 1, T 2, G 3 (either case)
+                u32 code = y ^ y1;                                                                       // A 0, C 1, G 2, T 3
+                const u32 expect = 0x41414141u + y0 * 2u + y1 * 0x13u - (y0 & y1) * 0x0Fu;                  // the upper-case letter those bits stand for
+                const u32 diff = (b4 & 0xDFDFDFDFu) ^ expect;                                              // non-zero byte: not one of ACGT
+                const u32 isn = ((diff | ((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;
+                code &= ~(isn * 3u);                                                                      // (packed as A)
+                word |= ((code * 0x01041040u) >> 24) << (8 * j);                                          // four 2-bit codes -> one byte
+                // Phred = character - 33, kept in 0..127
+                u32 qv;
+                const u32 lowc = (q4 | 0x80808080u) - 0x21212121u;                                         // bit 7 of a byte survives iff its character is >= 33
+                const u32 okl = ((lowc & 0x80808080u) >> 7) | ((q4 & 0x80808080u) >> 7);                    // 1: character >= 33
+                if (okl == 0x01010101u && !(q4 & 0x80808080u)) qv = q4 - 0x21212121u;                      // the usual case: 33..127 everywhere
+                else {
+                    qv = 0;
+                    #pragma unroll
+                    for (int k = 0; k < 4; k++) { int q = (int)((q4 >> (8 * k)) & 0xFFu) - 33; q = q < 0 ? 0 : (q > 127 ? 127 : q); qv |= (u32)q << (8 * k); }
                 }
+                qw[j] = qv | (isn << 7);
+                anyn |= isn;
             }
+            anyn = anyn ? 1u : 0u;
             #pragma unroll
             for (int j = 0; j < 4; j++) if (w * 16 + 4 * j < qstride) reinterpret_cast<u32*>(qrows + r * qstride)[w * 4 + j] = qw[j];     // qstride is a multiple of 4
             if (anyn) atomicOr(&s_anyn[i >> 5], 1u << (i & 31));      // LDS
