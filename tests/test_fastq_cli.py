@@ -365,3 +365,75 @@ def test_page_locked_buffers_feed_the_parser_like_ordinary_memory(tmp_path):
     del pin, ring
     gc.collect()
     eng.close()
+
+
+@pytest.mark.gpu
+def test_bgzf_chunks_of_tens_of_thousands_of_blocks_are_cut_by_the_library():
+    """Round 5: mlst_submit_fastq_bgzf sends a chunk through its three stages in PIECES it chooses itself -- 16,384 blocks into
+    an empty pipeline, 8,192 at the end of a stream, up to 49,152 between (phase 1 by k_inflate_tok2 above 18,432) -- and pieces
+    of one stream overlap: the parse of piece k - 1 runs beside the inflate of piece k, a partial record travels from piece to
+    piece.  40,000 small BGZF blocks (blocks may be any size) whose boundaries fall inside records, as ONE final chunk, as
+    two chunks, through the file reader, with the pipeline and the cuts switched off: the statistics of the text path every time,
+    and the records a call reports add up to the file's."""
+    import subprocess
+    import sys
+    from bam_writer import _bgzf_block
+    from metamlst_amd.engine import Engine
+    db, idx = fx.ecoli_small(60)
+    rng = np.random.default_rng(19)
+    g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][2], size=60_000)
+    recs = []
+    for k in range(52_000):
+        L = int(rng.choice([150, 150, 150, 75]))
+        at = int(rng.integers(0, len(g) - L))
+        recs.append(b"@r%d\n" % k + g[at:at + L].tobytes() + b"\n+\n" + bytes((rng.integers(2, 42, size=L)).astype(np.uint8) + 33) + b"\n")
+    text = b"".join(recs)
+    n_blocks = 40_000
+    step = len(text) // n_blocks + 1
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:
+        blocks = list(ex.map(_bgzf_block, [text[at:at + step] for at in range(0, len(text), step)]))
+    assert 39_000 < len(blocks) <= n_blocks
+    whole = b"".join(blocks) + _bgzf_block(b"")
+    eng = Engine(0)
+    eng.load_reference(idx)
+    assert eng.submit_fastq(text) == len(recs)
+    want = eng.stats()
+    # one final chunk: head of 16,384 + a middle piece + a tail of 8,192
+    eng.reset_sample()
+    assert eng.submit_fastq_bgzf(whole, final=True) == len(recs)
+    fx.assert_stats_equal(eng.stats(), want)
+    # two chunks cut between blocks (inside a record): the first meets an empty pipeline, the second is final
+    cut = sum(len(b) for b in blocks[:27_001])
+    eng.reset_sample()
+    n = eng.submit_fastq_bgzf(whole[:cut], final=False)
+    assert 0 < n < len(recs)                      # (the records of the first chunk's last piece arrive with the next call)
+    n += eng.submit_fastq_bgzf(whole[cut:], final=True)
+    assert n == len(recs)
+    fx.assert_stats_equal(eng.stats(), want)
+    # an open piece is finished by whatever looks at the sample next (its records are then in the statistics, not in a call's count)
+    eng.reset_sample()
+    n = eng.submit_fastq_bgzf(whole[:cut], final=False)
+    partial = eng.stats()
+    assert int(want.counters[0]) * 0.5 < int(partial.counters[0]) < int(want.counters[0])
+    n += eng.submit_fastq_bgzf(whole[cut:], final=True)
+    assert n < len(recs)
+    fx.assert_stats_equal(eng.stats(), want)
+    # the file reader (pieces cut anywhere, the library says how much it took)
+    d = tempfile.mkdtemp()
+    path = d + "/many.fastq.gz"
+    open(path, "wb").write(whole)
+    for chunk_bytes in (1 << 30, 5_000_001):
+        eng.reset_sample()
+        assert eng.submit_fastq_bgzf_file(path, chunk_bytes=chunk_bytes) == len(recs)
+        fx.assert_stats_equal(eng.stats(), want)
+    eng.close()
+    # the switches: no cuts, no pipeline, phase 1 forced either way (read when the library is first used: a process each)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from metamlst_amd.engine import Engine; from metamlst_amd.index import load_index;"
+            "idx = load_index(%r, cache=False); e = Engine(0); e.load_reference(idx); n = e.submit_fastq_bgzf_file(%r); s = e.stats();"
+            "print(n, int(s.sum_score.sum()), int(s.n_hits.sum()), int(s.counters[0]), int(s.counters[1]))" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), db.path, path))
+    ref = "%d %d %d %d %d" % (len(recs), int(want.sum_score.sum()), int(want.n_hits.sum()), int(want.counters[0]), int(want.counters[1]))
+    for env in ({"MLST_BGZF_SPLIT": "0"}, {"MLST_BGZF_PIPE": "0"}, {"MLST_INFLATE_TOK": "1"}, {"MLST_INFLATE_TOK": "2"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert r.stdout.strip().splitlines()[-1] == ref, (env, r.stdout, ref)
