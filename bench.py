@@ -141,6 +141,7 @@ def build_workload(name, args, eng_factory, torch, device, rank, n_batches, tmp)
     w.t_index_host = time.time() - t0
     t0 = time.time()
     w.engines = [eng_factory() for _ in range(n_batches)]
+    w.eng_factory = eng_factory
     ref_cache = w.sdb.path + ".mlstref"         # the built host index on disk, next to the database (mlst_set_reference_cache)
     for e in w.engines:
         e.load_reference(w.idx, cache_path=ref_cache)      # the host index is built once per process (cached inside the library) and stored
@@ -691,7 +692,7 @@ def end_to_end(w, args, torch, device):
     return out
 
 
-def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=2 << 20, bgzf_parts=None, eof_block=b""):
+def folder_leg(w, text_host, n, rec, n_files=16, reads_per_file=2 << 20, bgzf_parts=None, eof_block=b"", n_engines=6):
     """The product command on a folder of samples (`cli type folder/` = multigpu.type_many_samples: files -> reader thread -> GPU
     parser -> the pipelined loop of metamlst_amd/pipeline.py on the workload's engines -> one .nfo file per sample;
     /root/reference/metamlst-merge.py:93-107 reads that folder).  FASTQ text files in memory-backed storage, so what is
@@ -700,6 +701,17 @@ def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=2 << 20, bgzf_par
     from metamlst_amd.multigpu import type_many_samples
     from metamlst_amd.typing import TypingArgs
     reads_per_file = int(os.environ.get("MLST_FOLDER_READS", reads_per_file))      # (ad-hoc runs: larger samples)
+    n_files = int(os.environ.get("MLST_FOLDER_SAMPLES", n_files))
+    # the command's own number of engines (cli.py: MLST_PIPELINE_DEPTH, six) on halves of the device (multigpu.type_many_samples);
+    # the headline's four stay as they are, the others are made here once
+    n_engines = int(os.environ.get("MLST_PIPELINE_DEPTH", n_engines))
+    if not hasattr(w, "folder_engines"):
+        w.folder_engines = list(w.engines)
+    while len(w.folder_engines) < n_engines:
+        e = w.eng_factory()
+        e.load_reference(w.idx)
+        w.folder_engines.append(e)
+    engines = w.folder_engines[:max(1, n_engines)]
     per = min(reads_per_file, n // n_files)
     if bgzf_parts is not None:      # whole BGZF blocks of 65,280 bytes of text: a sample = a run of them (its last record may be cut: the parser drops nothing, the reader completes it from the next block -- so samples are cut at block AND record boundaries: 65,280 x k bytes with k a multiple of rec / gcd)
         import math
@@ -736,7 +748,7 @@ def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=2 << 20, bgzf_par
                 prof = cProfile.Profile(); prof.enable()
             t0 = time.perf_counter()
             tm = {}
-            rc = type_many_samples(w.engines, w.idx, w.database, TypingArgs(quiet=True), files, 0, 1, od, False, 256 << 20, timing=tm)
+            rc = type_many_samples(engines, w.idx, w.database, TypingArgs(quiet=True), files, 0, 1, od, False, 256 << 20, timing=tm)
             ts.append((time.perf_counter() - t0, tm))
             if prof is not None:
                 import pstats
@@ -747,11 +759,11 @@ def folder_leg(w, text_host, n, rec, n_files=8, reads_per_file=2 << 20, bgzf_par
         lines = sum(open(os.path.join(od, x)).read().count("\n") for x in written)
     finally:
         shutil.rmtree(root, ignore_errors=True)
-        for e in w.engines:      # (type_many_samples puts the engines on their CU shares)
+        for e in engines:      # (type_many_samples puts the engines on their CU shares)
             e.synchronize()
             e.set_cu_partition(0, 1)
     t, tm = min(ts, key=lambda x: x[0])
-    return {"samples": n_files, "reads_per_sample": per, "input": "FASTQ text" if bgzf_parts is None else "bgzip (level 6), inflated on the GPU", "engines": len(w.engines), "seconds": round(t, 4),
+    return {"samples": n_files, "reads_per_sample": per, "input": "FASTQ text" if bgzf_parts is None else "bgzip (level 6), inflated on the GPU", "engines": len(engines), "cu_shares": tm.get("cu_partitions"), "seconds": round(t, 4),
             "prologue_s": round(tm["prologue_s"], 4), "samples_s": round(tm["samples_s"], 4), "ms_per_sample": round(tm["samples_s"] / n_files * 1e3, 3),
             "Mreads_per_s": round(n_files * per / tm["samples_s"] / 1e6, 1), "Mreads_per_s_with_prologue": round(n_files * per / t / 1e6, 1),
             "nfo_files": len(written), "species_lines": lines,

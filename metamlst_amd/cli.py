@@ -178,7 +178,10 @@ def run_type(a, argv=None) -> int:
     engines = [eng]
     if many:      # the pipelined loop (metamlst_amd/pipeline.py): a few engines take turns on this rank's samples
         n_mine = (len(samples) + world - 1) // world
-        for _ in range(max(0, min(int(os.environ.get("MLST_PIPELINE_DEPTH", "4")), n_mine) - 1)):
+        # six engines: a sample of a few million reads is a chain of short device stages (copy, inflate, parse, pass 1, allele choice,
+        # pile-up: 10-15 ms end to end, most of it latency) -- 16 bgzip'd samples of 2 M reads: 4 / 6 / 8 engines = 265 / 300 / 290 Mreads/s
+        # (profiles/round5/inflate.md 6)
+        for _ in range(max(0, min(int(os.environ.get("MLST_PIPELINE_DEPTH", "6")), n_mine) - 1)):
             e2 = Engine(a.device, prm)
             e2.load_reference(idx)      # (the host index is cached inside the library: an upload, not a build)
             if a.depth_cap:

@@ -5387,6 +5387,7 @@ extern "C" int mlst_set_cu_partition(mlst_handle* h, uint32_t part, uint32_t n_p
     if (!h) return MLST_E_INVALID;
     if (n_parts == 0 || part >= n_parts) return fail(h, MLST_E_INVALID, "CU partition %u of %u", part, n_parts);
     if (n_parts == 1 && h->cu_split == 1) return MLST_OK;      // the whole device already: keep the stream (a fresh one may share a hardware queue with another engine's)
+    if (h->cu_split == (int)n_parts && h->cu_part == (int)part && h->own_stream) return MLST_OK;      // this share already (a second run over the same engines: a masked stream costs ~5 ms to make)
     hipSetDevice(h->device);
     { int rc_ = bz_flush(h); if (rc_) return rc_; }
     drain_events(h);

@@ -229,7 +229,11 @@ def type_many_samples(engines, idx, database, targs, samples: list[list[str]], r
     owner = deal_samples(sizes, world)
     jobs = [(i, files) for i, files in enumerate(samples) if owner[i] == rank]
     pipe = TypingPipeline(engines if isinstance(engines, (list, tuple)) else [engines], penalty=targs.penalty, feed_threads=True)
-    parts = int(os.environ.get("MLST_CU_PARTITIONS", "0")) or TypingPipeline.default_partitions(pipe.depth)
+    # CU shares: HALVES of the device here (the resident 50 M-read batches of bench.py's headline gain most from quarters, 2.6 ms of
+    # kernels per step; a file sample of a few million reads is a chain of short kernels whose latency counts, and on a quarter of
+    # the CUs each takes up to four times as long -- 16 bgzip'd samples of 2 M reads on six engines: 1 / 2 / 4 shares = 215 / 300 / 275
+    # Mreads/s, profiles/round5/inflate.md 6)
+    parts = int(os.environ.get("MLST_CU_PARTITIONS", "0")) or min(2, TypingPipeline.default_partitions(pipe.depth))
     if parts > 1:
         pipe.place(parts)
         pipe.stagger_s = 0.75e-3
@@ -263,6 +267,7 @@ def type_many_samples(engines, idx, database, targs, samples: list[list[str]], r
         timing["prologue_s"] = t_run - t_begin
         timing["samples_s"] = time.perf_counter() - t_run
         timing["host_ms"] = dict(pipe.host_ms)
+        timing["cu_partitions"] = pipe.partitions
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world if rank == 0 else None

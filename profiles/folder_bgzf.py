@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """`cli type folder/` on bgzip'd samples in memory-backed storage, with a host-side trace of who waits for what:
-    python profiles/folder_bgzf.py [samples] [reads per sample] [engines]"""
+    python profiles/folder_bgzf.py [samples] [reads per sample] [engines] [text]"""
 import json
 import os
 import struct
@@ -36,6 +36,7 @@ def block(data):
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 PER = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 NE = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+TEXT = len(sys.argv) > 4 and sys.argv[4] == "text"      # plain FASTQ text files instead (the other folder leg of bench.py)
 d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 sdb = synth.make_ecoli_db(d + "/e.db", alleles_per_locus=300, n_profiles=50)
 idx = load_index(sdb.path)
@@ -57,6 +58,11 @@ with ThreadPoolExecutor(max(1, min(64, os.cpu_count() or 1))) as ex:
         for k in range(9):
             rows[:, 10 - k] = 48 + (num // 10 ** k) % 10
         rows[:, 12 + L] = 10; rows[:, 13 + L] = ord("+"); rows[:, 14 + L] = 10; rows[:, 15 + 2 * L] = 10
+        if TEXT:
+            f = "%s/s%02d.fastq" % (d, s)
+            rows.tofile(f)
+            files.append([f])
+            continue
         raw = rows.tobytes()
         parts = list(ex.map(block, [raw[at:at + 65280] for at in range(0, len(raw), 65280)]))
         f = "%s/s%02d.fastq.gz" % (d, s)
@@ -85,7 +91,7 @@ def wrap(obj, name, label):
 
 if os.environ.get("TRACE"):
     wrap(fastq, "_pread_into", "read")
-    for nm in ("submit_fastq_bgzf_file", "typing_enqueue", "typing_wait", "typing_fetch", "reset_sample"):
+    for nm in ("submit_fastq_bgzf_file", "submit_fastq", "typing_enqueue", "typing_wait", "typing_fetch", "reset_sample"):
         wrap(eng_mod.Engine, nm, nm)
 
 engines = make_engines(idx, 0, NE)
