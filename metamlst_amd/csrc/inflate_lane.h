@@ -179,34 +179,48 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
         const unsigned long long tr0 = __builtin_readcyclecounter();
 #endif
         if (tid < 20) s_nl[tid] = 0;
-        // ---- fill: tiles of NT tokens, their output offsets by a scan, pointers (or literal bytes) written per token
-        u32 base = 0; bool bad = false;
-        u32 t_next = tid < nt ? T[tid] : 0u;                             // (the next tile's tokens are on their way while this one is worked on)
-        for (u32 t0 = 0; t0 < nt; t0 += NT) {
-            const u32 ti = t0 + tid;
+        // ---- fill: every wave takes a contiguous run of the tokens.  Pass A adds up the run's output bytes (one barrier for all
+        // sixteen sums), pass B walks the run again -- the tokens come from L2 the second time -- with a scan inside the wave and
+        // writes the pointers (or literal bytes).  (Until round 5 the workgroup went through the tokens in tiles of NT with two
+        // barriers per tile: 44 barriers per block, 68 k cycles of the kernel's 140 k.)
+        const u32 per_wave = ((nt + (u32)NT - 1u) / (u32)NT) * 64u;
+        const u32 w_lo = wave * per_wave < nt ? wave * per_wave : nt, w_hi = w_lo + per_wave < nt ? w_lo + per_wave : nt;
+        auto tok_len = [](u32 t) -> u32 {
+            const u32 tag = t >> 30;
+            return tag == TAG_MATCH ? ((t >> 16) & 0xFFu) + 3u : (tag == TAG_RAW ? (t & 0xFFFFu) : (tag == TAG_LIT ? 1u : 0u));
+        };
+        bool bad = false;
+        {
+            u32 sum = 0;
+            for (u32 ti = w_lo + lane; ti < w_hi; ti += 64u) sum += tok_len(T[ti]);
+            sum = wave_incl_scan(sum);
+            if (lane == 63) s_part[wave] = sum;
+        }
+        __syncthreads();
+        u32 base = 0, all = 0;
+        for (u32 w = 0; w < (u32)NW; w++) { const u32 v = s_part[w]; all += v; if (w < wave) base += v; }
+        u32 t_next = w_lo + lane < w_hi ? T[w_lo + lane] : 0u;            // (the next 64 tokens are on their way while these are worked on)
+        for (u32 t0 = w_lo; t0 < w_hi; t0 += 64u) {
+            const u32 ti = t0 + lane;
             u32 t = 0, len = 0, tag = TAG_OPERAND;
             const u32 t_cur = t_next;
-            t_next = ti + NT < nt ? T[ti + NT] : 0u;
-            if (ti < nt) {
-                t = t_cur; tag = t >> 30;
-                len = tag == TAG_MATCH ? ((t >> 16) & 0xFFu) + 3u : (tag == TAG_RAW ? (t & 0xFFFFu) : (tag == TAG_LIT ? 1u : 0u));
-            }
+            t_next = ti + 64u < w_hi ? T[ti + 64u] : 0u;
+            if (ti < w_hi) { t = t_cur; tag = t >> 30; len = tok_len(t); }
             const u32 inc = wave_incl_scan(len);
-            if (lane == 63) s_part[wave] = inc;
-            __syncthreads();
-            u32 before = base;
-            for (u32 w = 0; w < wave; w++) before += s_part[w];
-            u32 tile_total = 0;
-            for (u32 w = 0; w < (u32)NW; w++) tile_total += s_part[w];
-            const u32 dst = before + inc - len;
+            const u32 dst = base + inc - len;
             // per token: the first bytes by its own lane, the rest of a long one by the whole wave
             u32 done = 0;
             if (len && dst + len <= total) {
                 if (tag == TAG_MATCH) {
                     const u32 dist = (t & 0x7FFFu) + 1u;
-                    const u32 n0 = len < 32u ? len : 32u;      // (longer ones -- quality runs -- are finished by the whole wave below)
+                    const u32 n0 = len < 16u ? len : 16u;      // (longer ones -- quality runs -- are finished by the whole wave below; 8 / 16 / 24 / 32: fill 16.5 / 13.7 / 14.4 / 15.0)
                     if (dist > dst) { done = len; bad = true; if (atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_DISTANCE); }
-                    else { for (u32 k = 0; k < n0; k++) ptr[dst + k] = (u16)(dst + k - dist); done = n0; }
+                    else {
+                        // (a match that overlaps itself -- a run of one quality value: dist 1, up to 258 long -- is left to the wave whole:
+                        // its bytes repeat the `dist` bytes in front of it and every one of them is pointed INTO that period, one link
+                        // instead of len / dist; per lane that is a wrap test per byte, measured slower: profiles/round5/inflate.md 3)
+                        if (dist >= len) { for (u32 k = 0; k < n0; k++) ptr[dst + k] = (u16)(dst + k - dist); done = n0; }
+                    }
                 } else if (tag == TAG_LIT) { ptr[dst] = (u16)(LIT_BASE | (t & 0xFFu)); done = 1; }
             } else if (len) { done = len; bad = true; if (atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_OUTPUT); }
             const u32 nxt = (tag == TAG_RAW && ti + 1 < nt) ? T[ti + 1] : 0u;      // (the operand of a stored run)
@@ -219,7 +233,14 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
                 const u32 t_nxt = (u32)__builtin_amdgcn_readlane((int)nxt, k);
                 if ((tt >> 30) == TAG_MATCH) {
                     const u32 dist = (tt & 0x7FFFu) + 1u;
-                    for (u32 j = t_done + lane; j < tl; j += 64) ptr[td + j] = (u16)(td + j - dist);
+                    if (dist < tl) {      // periodic (see above): j mod dist by the reciprocal (j < 65,536, dist < 65,536: one correction step either way is enough)
+                        const float rd = 1.0f / (float)dist;
+                        for (u32 j = t_done + lane; j < tl; j += 64) {
+                            int r = (int)j - (int)((u32)((float)j * rd) * dist);
+                            r += r < 0 ? (int)dist : 0; r -= r >= (int)dist ? (int)dist : 0;
+                            ptr[td + j] = (u16)(td - dist + (u32)r);
+                        }
+                    } else for (u32 j = t_done + lane; j < tl; j += 64) ptr[td + j] = (u16)(td + j - dist);
                 } else {      // stored run: its bytes straight from the compressed buffer
                     const u32 src = t_nxt & 0x3FFFFFFFu;
                     if ((t_nxt >> 30) == TAG_OPERAND && (u64)src + tl <= (u64)B.in_len)
@@ -227,9 +248,10 @@ __device__ __attribute__((always_inline)) inline void ptr_body(const u8* comp, c
                     else { bad = true; if (lane == 0 && atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_STORED); }
                 }
             }
-            base += tile_total;
-            __syncthreads();
+            base += (u32)__builtin_amdgcn_readlane((int)inc, 63);
         }
+        __syncthreads();
+        base = all;
         if (base != total) bad = true;
         // a block with an inconsistent token (flagged above) is not jumped or written out: its pointers may be stale
         if (__syncthreads_or(bad)) { if (tid == 0 && atomicCAS(&err[0], 0u, err_base + b + 1u) == 0u) err[1] = (u32)(-mlst_inflate::E_SHORT); continue; }

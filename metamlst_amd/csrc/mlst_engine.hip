@@ -5392,8 +5392,8 @@ extern "C" int mlst_set_cu_partition(mlst_handle* h, uint32_t part, uint32_t n_p
     { int rc_ = bz_flush(h); if (rc_) return rc_; }
     drain_events(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    hipDeviceProp_t prop; HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
-    const u32 n_cu = (u32)prop.multiProcessorCount;
+    int n_cu_i = 0; HIPCHK(h, hipDeviceGetAttribute(&n_cu_i, hipDeviceAttributeMultiprocessorCount, h->device));      // (hipGetDeviceProperties takes milliseconds)
+    const u32 n_cu = (u32)n_cu_i;
     if (n_parts > n_cu) return fail(h, MLST_E_INVALID, "more CU partitions (%u) than CUs (%u)", n_parts, n_cu);
     hipStream_t ns = nullptr;
     if (n_parts == 1) HIPCHK(h, hipStreamCreate(&ns));
