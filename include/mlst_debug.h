@@ -28,6 +28,12 @@ int mlst_selftest_inflate_device(mlst_handle* h, const uint8_t* data, uint64_t n
  * more symbols than the decoder's 192-entry table (the device leaves such a block to k_inflate); nothing is produced then. */
 int mlst_selftest_inflate_canon(const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t cap, uint64_t* produced, int* left_to_other_kernel);
 
+/* The BGZF blocks of a chunk as mlst_submit_fastq_bgzf lists them (host code only, no device): blocks with data, the bytes they
+ * inflate to, and -- a chunk of 32 MB or more is walked by four threads, three of them from a block start they find behind their
+ * quarter mark -- how many of the four lists counted (a list counts only where the chain of the one before it lands on its first
+ * block).  MLST_E_INVALID where the serial walk meets something that is not a whole block.  tests/test_inflate.py. */
+int mlst_debug_bgzf_walk(const uint8_t* data, uint64_t n_bytes, uint64_t* n_blocks, uint64_t* text_bytes, int* lists_taken);
+
 /* Diagnostics of the routed sieve (profiles/route_modes.py; no reference counterpart, not a data path).
  * mlst_get_route_trace: the first call switches the trace on; later calls wait for the stream and return, for the last
  * submission, out[0] = producer workgroups P, [1] = arena address, [2] = packed-row address, [3] = wall-clock kHz,

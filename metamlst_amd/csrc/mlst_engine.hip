@@ -3432,8 +3432,14 @@ struct mlst_handle {
     // of piece k (infl_stream) and the parse + pass 1 of piece k - 1 (the engine's stream) run side by side.  Two slots of
     // compressed bytes / block descriptors / error words used in turn; `bz_pend` is the piece whose text is being inflated
     // (or has been) and has not been parsed yet.
-    struct BzSlot { u8* d_comp = nullptr; u64 cap_comp = 0; void* d_blk = nullptr; void* h_blk = nullptr; u64 cap_blk = 0; hipEvent_t ev_copied = nullptr, ev_inflated = nullptr; u32* d_err = nullptr; u32* h_err = nullptr; };
+    struct BzSlot { void* d_blk = nullptr; void* h_blk = nullptr; u64 cap_blk = 0; hipEvent_t ev_copied = nullptr, ev_inflated = nullptr; u32* d_err = nullptr; u32* h_err = nullptr; };
     BzSlot bz[2]; int bz_slot = 0, bz_mode = -1; hipStream_t infl_stream = nullptr;
+    // the compressed bytes of a CHUNK (one call of mlst_submit_fastq_bgzf), two buffers used in turn: the copy is queued in BZ_SUB parts
+    // before the chunk's block headers are walked (a cache miss per block: 8 ms for 49,152 blocks, now beside the copy), a piece's
+    // inflate waits for the part that holds its last byte; ev_used: the last inflate that read the buffer
+    enum { BZ_SUB = 8 };
+    struct BzChunk { u8* d = nullptr; u64 cap = 0; hipEvent_t ev[BZ_SUB] = {}; u64 upto[BZ_SUB] = {}; int n_ev = 0; hipEvent_t ev_used = nullptr; bool used = false; };
+    BzChunk bzc[2]; int bz_chunk = 0;
     struct { bool on = false, counted = false; int slot = 0, tslot = 0, paired = 0; u64 text_bytes = 0; } bz_pend;
     u32 depth_cap = 0; u64* d_capbuf = nullptr; u64 cap_capcols = 0;      // depth-capped pile-up (mlst_set_depth_cap): lo, hi, thr (u64 each) and cnt (u32) per column
     u32* d_counts = nullptr; u64 cap_counts = 0;
@@ -4229,14 +4235,16 @@ static int ensure_route_buffers(mlst_handle* h, u64 n_reads, u32 wpr, u64 n_read
     const u64 need_e = (u64)prod * (tiles_max + 1);
     if (h->cap_rt_emitted < need_e) { hipStreamSynchronize(h->stream); hipFree(h->d_rt_emitted); h->d_rt_emitted = nullptr; HIPCHK(h, dmalloc(&h->d_rt_emitted, need_e)); h->cap_rt_emitted = need_e; }
     h->rt_tiles_max = (u32)tiles_max; h->rt_nw = nw;
-    if (h->rt_trace_on && !h->d_rt_trace) { hipStreamSynchronize(h->stream); HIPCHK(h, dmalloc(&h->d_rt_trace, (u64)(RT_MAXP + RT_OWNERS) * 4)); HIPCHK(h, hipMemset(h->d_rt_trace, 0, (u64)(RT_MAXP + RT_OWNERS) * 32)); }
+    if (h->rt_trace_on && !h->d_rt_trace) { hipStreamSynchronize(h->stream); HIPCHK(h, dmalloc(&h->d_rt_trace, (u64)(RT_MAXP + RT_OWNERS) * 4)); HIPCHK(h, hipMemsetAsync(h->d_rt_trace, 0, (u64)(RT_MAXP + RT_OWNERS) * 32, h->stream)); }
     // ~0.6 % of the entries pass the filter (1.5 x the reads' real hits + 0.4 % of chance): room for a quarter of the reads,
     // beyond which the consumer examines in place
     const u64 need_p = std::max<u64>(n_reads / 4, 1ull << 16);
     if (h->cap_rt_parked < need_p) { hipStreamSynchronize(h->stream); hipFree(h->d_rt_parked); h->d_rt_parked = nullptr; HIPCHK(h, dmalloc(&h->d_rt_parked, need_p)); h->cap_rt_parked = need_p; }
     const u64 n_flag_words = ((n_reads_flags > n_reads ? n_reads_flags : n_reads) + 31) >> 5;
     if (h->cap_bin_flags < n_flag_words) { hipStreamSynchronize(h->stream); hipFree(h->d_bin_flags); h->d_bin_flags = nullptr; HIPCHK(h, dmalloc(&h->d_bin_flags, n_flag_words)); h->cap_bin_flags = n_flag_words;
-                                            HIPCHK(h, hipMemset(h->d_bin_flags, 0, n_flag_words * 4)); }
+                                            // (on the engine's stream, not hipMemset: the legacy stream waits for every blocking stream, and ANOTHER engine of the
+                                            // process may be capturing its graph on one right now -- "would make the legacy stream depend on a capturing blocking stream")
+                                            HIPCHK(h, hipMemsetAsync(h->d_bin_flags, 0, n_flag_words * 4, h->stream)); }
     return MLST_OK;
 }
 
@@ -4735,6 +4743,7 @@ extern "C" int mlst_submit_fastq_pair(mlst_handle* h, const uint8_t* text1, uint
     return fastq_pipeline(h, total, 1, true, n_reads_out, n1 + pad);
 }
 
+struct BzHdr { u64 off; u32 total, coff, clen, isize; };      // one BGZF block of a chunk: where it starts, its size, where its deflate data lies, the bytes it inflates to
 // BGZF framing (SAM spec 4.1): gzip member with an extra subfield 'B','C' holding the block size - 1; deflate data; CRC32, ISIZE
 static bool bgzf_block(const u8* p, u64 left, u64& total, u64& cdata_off, u64& cdata_len, u32& isize) {
     if (left < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
@@ -4752,6 +4761,79 @@ static bool bgzf_block(const u8* p, u64 left, u64& total, u64& cdata_off, u64& c
     cdata_off = 12ull + xlen; cdata_len = total - cdata_off - 8;
     isize = (u32)p[total - 4] | ((u32)p[total - 3] << 8) | ((u32)p[total - 2] << 16) | ((u32)p[total - 1] << 24);
     return true;
+}
+
+// The walk over a chunk's block headers is a chain of cache (and TLB) misses, ~190 ns per block (the next header's place is in this
+// one): a chunk of 32 MB or more is walked by four threads, each from a block start it FINDS behind its quarter mark (the header's
+// fixed bytes, parsed, and the block behind it parsed too); a list is taken only where the chain of the list before it lands exactly
+// on its first block -- so a false start (header bytes inside deflate data) costs the time, never the result -- and the caller's
+// serial loop goes on from `walked`, where the accepted lists end (all errors are its).  lists_taken: how many of the four counted.
+static void bgzf_walk_parallel(const u8* data, u64 n_bytes, std::vector<BzHdr>& hdr, u64& walked, int* lists_taken) {
+    hdr.clear(); walked = 0; if (lists_taken) *lists_taken = 0;
+    static const bool one = [] { const char* e = getenv("MLST_BGZF_WALK"); return e && e[0] == '1'; }();      // MLST_BGZF_WALK=1: the serial walk (A/B)
+    if (n_bytes < (32ull << 20) || one) return;
+    enum { WT = 4 };
+    std::vector<BzHdr> part[WT]; u64 stop[WT] = {0}, cand[WT] = {0}; bool have[WT] = {false};
+    auto work = [&](int k) {
+        u64 from = 0;
+        if (k) {
+            const u64 s0 = n_bytes * (u64)k / WT, s1 = std::min<u64>(s0 + 131072, n_bytes - 18);
+            bool ok = false;
+            for (u64 q = s0; q < s1 && !ok; q++) {
+                if (data[q] != 0x1f || data[q + 1] != 0x8b || data[q + 2] != 8 || !(data[q + 3] & 4)) continue;
+                u64 t, co, cl; u32 is;
+                if (!bgzf_block(data + q, n_bytes - q, t, co, cl, is)) continue;
+                u64 t2, co2, cl2; u32 is2;
+                if (q + t != n_bytes && !bgzf_block(data + q + t, n_bytes - q - t, t2, co2, cl2, is2)) continue;
+                from = q; ok = true;
+            }
+            if (!ok) return;
+            cand[k] = from; have[k] = true;
+        }
+        const u64 limit = k + 1 < WT ? std::min<u64>(n_bytes * (u64)(k + 1) / WT + 262144, n_bytes) : n_bytes;
+        part[k].reserve((size_t)((limit - from) / 8192 + 64));
+        u64 off = from;
+        while (off < limit) {
+            u64 t, co, cl; u32 is;
+            if (!bgzf_block(data + off, n_bytes - off, t, co, cl, is)) break;
+            part[k].push_back(BzHdr{off, (u32)t, (u32)co, (u32)cl, is});
+            off += t;
+        }
+        stop[k] = off;
+    };
+    std::thread th[WT - 1];
+    for (int k = 1; k < WT; k++) th[k - 1] = std::thread(work, k);
+    work(0);
+    for (auto& t : th) t.join();
+    hdr.swap(part[0]); walked = stop[0];
+    int taken = 1;
+    for (int k = 1; k < WT; k++) {
+        if (!have[k]) break;
+        size_t i = hdr.size();
+        while (i > 0 && hdr[i - 1].off > cand[k]) i--;
+        if (i == 0 || hdr[i - 1].off != cand[k]) break;      // the chain does not pass through the start this thread found: its list is dropped, and those behind it
+        hdr.resize(i - 1);
+        hdr.insert(hdr.end(), part[k].begin(), part[k].end());
+        walked = stop[k]; taken++;
+    }
+    if (lists_taken) *lists_taken = taken;
+}
+// test hook (include/mlst_debug.h): the blocks of a chunk as mlst_submit_fastq_bgzf lists them -- count, text bytes, how many of the four threads' lists counted
+extern "C" int mlst_debug_bgzf_walk(const uint8_t* data, uint64_t n_bytes, uint64_t* n_blocks, uint64_t* text_bytes, int* lists_taken) {
+    if (!data || !n_blocks || !text_bytes) return MLST_E_INVALID;
+    std::vector<BzHdr> hdr; u64 walked = 0;
+    bgzf_walk_parallel(data, n_bytes, hdr, walked, lists_taken);
+    u64 nb = 0, tb = 0; size_t hi_ = 0;
+    for (u64 off = 0; off < n_bytes; ) {
+        u64 total, coff, clen; u32 isize;
+        if (hi_ < hdr.size()) { const BzHdr& q = hdr[hi_++]; off = q.off; total = q.total; isize = q.isize; }
+        else if (off < walked) { off = walked; continue; }
+        else if (!bgzf_block(data + off, n_bytes - off, total, coff, clen, isize)) return MLST_E_INVALID;
+        if (isize) { nb++; tb += isize; }
+        off += total;
+    }
+    *n_blocks = nb; *text_bytes = tb;
+    return MLST_OK;
 }
 
 // ---- BGZF input, three stages on three streams (round 5).  Until round 4 a piece went copy -> inflate -> parse -> pass 1 on ONE
@@ -4792,9 +4874,16 @@ static int bz_flush(mlst_handle* h) { return h->bz_pend.on ? bz_finish(h, false,
 static void bz_free(mlst_handle* h) {
     if (h->infl_stream) hipStreamSynchronize(h->infl_stream);
     for (auto& B : h->bz) {
-        hipFree(B.d_comp); hipFree(B.d_blk); hipFree(B.d_err); if (B.h_err) hipHostFree(B.h_err); if (B.h_blk) hipHostFree(B.h_blk);
+        hipFree(B.d_blk); hipFree(B.d_err); if (B.h_err) hipHostFree(B.h_err); if (B.h_blk) hipHostFree(B.h_blk);
         if (B.ev_copied) hipEventDestroy(B.ev_copied); if (B.ev_inflated) hipEventDestroy(B.ev_inflated);
         B = mlst_handle::BzSlot();
+    }
+    if (h->copy_stream) hipStreamSynchronize(h->copy_stream);
+    for (auto& C : h->bzc) {
+        hipFree(C.d);
+        for (auto& e : C.ev) if (e) hipEventDestroy(e);
+        if (C.ev_used) hipEventDestroy(C.ev_used);
+        C = mlst_handle::BzChunk();
     }
     if (h->infl_stream) { hipStreamDestroy(h->infl_stream); h->infl_stream = nullptr; }
     h->bz_pend.on = false;
@@ -4809,19 +4898,16 @@ static int bz_stream(mlst_handle* h) {
 
 // One piece through the three stages: its copy and inflate are queued, the piece before it is finished meanwhile (and, for the last
 // piece of a stream, the piece itself).  blks: the piece's blocks, in_off relative to `data`, out_off from FQ_HEAD on.
-static int bz_piece(mlst_handle* h, const uint8_t* data, u64 n_bytes, const std::vector<BgzfBlk>& blks, u64 text_end, int paired, bool final_piece, uint64_t* done) {
+static int bz_piece(mlst_handle* h, mlst_handle::BzChunk& C, u64 lo, u64 hi, const std::vector<BgzfBlk>& blks, u64 text_end, int paired, bool final_piece, uint64_t* done) {
     static const bool bz_trace = getenv("MLST_BGZF_TRACE") != nullptr;      // host-side time stamps of a piece's steps (stderr)
     auto bz_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double bt0 = bz_trace ? bz_now() : 0.0;
     uint64_t n1 = 0;
-    { int rc = bz_stream(h); if (rc) return rc; }
-    if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     const int sl = h->bz_slot ^= 1;
     mlst_handle::BzSlot& B = h->bz[sl];
     if (!B.ev_copied) { HIPCHK(h, hipEventCreateWithFlags(&B.ev_copied, hipEventDisableTiming)); HIPCHK(h, hipEventCreateWithFlags(&B.ev_inflated, hipEventDisableTiming));
                         HIPCHK(h, dmalloc(&B.d_err, (u64)16)); HIPCHK(h, hipHostMalloc((void**)&B.h_err, 64, hipHostMallocDefault)); }
     // (the slot's last user, piece k - 2, has been finished: its inflate is over)
-    if (B.cap_comp < n_bytes) { hipFree(B.d_comp); B.d_comp = nullptr; HIPCHK(h, dmalloc(&B.d_comp, n_bytes + n_bytes / 8 + 16)); B.cap_comp = n_bytes + n_bytes / 8; }
     if (B.cap_blk < blks.size()) {
         hipFree(B.d_blk); B.d_blk = nullptr; if (B.h_blk) { hipHostFree(B.h_blk); B.h_blk = nullptr; }
         const u64 cap = blks.size() + blks.size() / 8;
@@ -4831,22 +4917,22 @@ static int bz_piece(mlst_handle* h, const uint8_t* data, u64 n_bytes, const std:
     }
     { int rc = next_text_slot(h, text_end + text_end / 16); if (rc) return rc; }
     const int tslot = h->fq_slot;
-    HIPCHK(h, hipMemcpyAsync(B.d_comp, data, n_bytes, hipMemcpyHostToDevice, h->copy_stream));
-    // (the block list through page-locked memory: a copy from the vector's pageable memory is staged by the runtime on the
-    // calling thread, BEHIND the copy queued in front of it on this stream -- the call sat out the whole 10 ms of a 560 MB piece there)
+    // (the block list through page-locked memory: a copy from the vector's pageable memory is staged by the runtime on the calling
+    // thread; and on the INFLATE stream, in front of the kernels that read it -- the copy stream is busy with the chunk's bytes)
     memcpy(B.h_blk, blks.data(), blks.size() * sizeof(BgzfBlk));
-    HIPCHK(h, hipMemcpyAsync(B.d_blk, B.h_blk, blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(h, hipEventRecord(B.ev_copied, h->copy_stream));
-    HIPCHK(h, hipStreamWaitEvent(h->infl_stream, B.ev_copied, 0));
+    HIPCHK(h, hipMemcpyAsync(B.d_blk, B.h_blk, blks.size() * sizeof(BgzfBlk), hipMemcpyHostToDevice, h->infl_stream));
+    { int k = 0; while (k + 1 < C.n_ev && C.upto[k] < hi) k++;                // the part of the chunk's copy that holds the piece's last byte (parts are queued in order)
+      HIPCHK(h, hipStreamWaitEvent(h->infl_stream, C.ev[k], 0)); }
     HIPCHK(h, hipStreamWaitEvent(h->infl_stream, h->ev_packed[tslot], 0));      // the text slot's last reader (an event never recorded counts as complete)
     HIPCHK(h, hipMemsetAsync(B.d_err, 0, 64, h->infl_stream));
     if (!h->inflate_mode) { const char* e = getenv("MLST_INFLATE_MODE"); h->inflate_mode = e ? atoi(e) : 2; if (h->inflate_mode != 1 && h->inflate_mode != 2) h->inflate_mode = 2; }
     const bool counted = h->inflate_mode == 2 && !getenv("MLST_BGZF_NOCOUNT");      // the two-kernel inflate counts the newlines of the text it writes
     if (counted) HIPCHK(h, hipMemsetAsync(h->d_fq_nl[tslot], 0, (text_end / FQ_BLOCK + 2) * 4, h->infl_stream));
-    { int rc = launch_inflate(h, B.d_comp, (u64)B.cap_comp + 16, (const BgzfBlk*)B.d_blk, (u32)blks.size(), h->d_fq_slot[tslot], B.d_err, nullptr, h->infl_stream,
+    { int rc = launch_inflate(h, C.d + lo, C.cap + 16 - lo, (const BgzfBlk*)B.d_blk, (u32)blks.size(), h->d_fq_slot[tslot], B.d_err, nullptr, h->infl_stream,
                               counted ? h->d_fq_nl[tslot] : nullptr); if (rc) return rc; }
     HIPCHK(h, hipMemcpyAsync(B.h_err, B.d_err, 8, hipMemcpyDeviceToHost, h->infl_stream));
     HIPCHK(h, hipEventRecord(B.ev_inflated, h->infl_stream));
+    HIPCHK(h, hipEventRecord(C.ev_used, h->infl_stream)); C.used = true;
     // piece k - 1 while the GPU inflates piece k
     int rc = MLST_OK;
     const double bt1 = bz_trace ? bz_now() : 0.0;
@@ -4854,12 +4940,9 @@ static int bz_piece(mlst_handle* h, const uint8_t* data, u64 n_bytes, const std:
     const double bt2 = bz_trace ? bz_now() : 0.0;
     h->bz_pend.on = true; h->bz_pend.counted = counted; h->bz_pend.slot = sl; h->bz_pend.tslot = tslot; h->bz_pend.paired = paired; h->bz_pend.text_bytes = text_end - FQ_HEAD;
     if (!rc && final_piece) { rc = bz_finish(h, true, &n1); *done += n1; }
-    const double bt3 = bz_trace ? bz_now() : 0.0;
-    const hipError_t ce = hipStreamSynchronize(h->copy_stream);      // blks / data may be released by the caller after this
-    if (bz_trace) fprintf(stderr, "bgzf piece of %zu blocks at %.3f: queueing %.3f ms, piece before %.3f ms, own piece (final) %.3f ms, wait for the copy %.3f ms\n",
-                          blks.size(), bt0, bt1 - bt0, bt2 - bt1, bt3 - bt2, bz_now() - bt3);
+    if (bz_trace) fprintf(stderr, "bgzf piece of %zu blocks at %.3f: queueing %.3f ms, piece before %.3f ms, own piece (final) %.3f ms\n",
+                          blks.size(), bt0, bt1 - bt0, bt2 - bt1, bz_now() - bt2);
     if (rc) { if (h->infl_stream) hipStreamSynchronize(h->infl_stream); h->bz_pend.on = false; return rc; }
-    HIPCHK(h, ce);
     return MLST_OK;
 }
 
@@ -4872,13 +4955,47 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
     if (n_bytes >= (1ull << 36)) return fail(h, MLST_E_LIMIT, "BGZF chunk too large");
     hipSetDevice(h->device);
     const bool piped = bz_mode(h) != 0;
+    static const bool bz_trace = getenv("MLST_BGZF_TRACE") != nullptr;
+    auto bz_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double ct0 = bz_trace ? bz_now() : 0.0;
+    // (piped) the chunk's bytes are on their way before its block headers are looked at: the walk below is a chain of cache misses,
+    // one per block (the next header's place is in this one), 8 ms for 49,152 blocks -- time the inflate stream sat idle for
+    mlst_handle::BzChunk* C = nullptr;
+    if (piped && n_bytes) {
+        { int rc = bz_stream(h); if (rc) return rc; }
+        if (!h->copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        C = &h->bzc[h->bz_chunk ^= 1];
+        if (!C->ev_used) { HIPCHK(h, hipEventCreateWithFlags(&C->ev_used, hipEventDisableTiming)); for (auto& e : C->ev) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+        if (C->cap < n_bytes) {
+            if (C->used) HIPCHK(h, hipEventSynchronize(C->ev_used));
+            hipFree(C->d); C->d = nullptr; C->cap = 0;
+            HIPCHK(h, dmalloc(&C->d, n_bytes + n_bytes / 8 + 32)); C->cap = n_bytes + n_bytes / 8;
+        }
+        if (C->used) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, C->ev_used, 0));      // the buffer's last reader (the chunk before the last: finished long ago, unless a sample was dropped half way)
+        const int n_sub = n_bytes >= (64ull << 20) ? (int)mlst_handle::BZ_SUB : 1;
+        u64 at = 0;
+        for (int k = 0; k < n_sub; k++) {
+            const u64 end = k + 1 == n_sub ? n_bytes : ((n_bytes * (u64)(k + 1) / (u64)n_sub) & ~(u64)4095);
+            HIPCHK(h, hipMemcpyAsync(C->d + at, data + at, end - at, hipMemcpyHostToDevice, h->copy_stream));
+            HIPCHK(h, hipEventRecord(C->ev[k], h->copy_stream));
+            C->upto[k] = end; at = end;
+        }
+        C->n_ev = n_sub;
+    }
+    // (an error return below leaves the copy running: the caller's buffer is read until the copy stream is idle -- waited for here)
+    struct CopyGuard { mlst_handle* h; bool on; ~CopyGuard() { if (on && h->copy_stream) hipStreamSynchronize(h->copy_stream); } } copy_guard{h, C != nullptr};
     std::vector<BgzfBlk> blks;
     std::vector<u64> blk_start;                                   // (piped) where every listed block begins in `data`
     const u64 text_at = piped ? FQ_HEAD : h->fq_carry_len;      // where the first block's text goes in its slot
     u64 text_bytes = text_at;
+    std::vector<BzHdr> hdr; u64 walked = 0;
+    bgzf_walk_parallel(data, n_bytes, hdr, walked, nullptr);
+    size_t hi_ = 0;      // (headers of `hdr` first, then block by block from `walked`)
     for (u64 off = 0; off < n_bytes; ) {
         u64 total, coff, clen; u32 isize;
-        if (!bgzf_block(data + off, n_bytes - off, total, coff, clen, isize)) {
+        if (hi_ < hdr.size()) { const BzHdr& q = hdr[hi_++]; off = q.off; total = q.total; coff = q.coff; clen = q.clen; isize = q.isize; }
+        else if (off < walked) { off = walked; continue; }
+        else if (!bgzf_block(data + off, n_bytes - off, total, coff, clen, isize)) {
             // a block cut off by the end of the buffer is left to the caller when it asked how much was taken (and more is to come)
             const bool cut = n_bytes - off < 18 || (data[off] == 0x1f && data[off + 1] == 0x8b && data[off + 2] == 8 && (data[off + 3] & 4));
             if (n_consumed_out && !final_chunk && cut) { n_bytes = off; break; }
@@ -4926,10 +5043,14 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
             const u64 t0 = sub[0].out_off - FQ_HEAD;
             for (auto& q : sub) { q.in_off -= lo; q.out_off -= t0; }
             const u64 text_end = sub.back().out_off + sub.back().out_len;
-            const int rc = bz_piece(h, data + lo, hi - lo, sub, text_end, paired, final_chunk != 0 && b1 == nb, &done);
+            const int rc = bz_piece(h, *C, lo, hi, sub, text_end, paired, final_chunk != 0 && b1 == nb, &done);
             if (rc) return rc;
         }
         if (n_reads_out) *n_reads_out = done;
+        const double ct1 = bz_trace ? bz_now() : 0.0;
+        copy_guard.on = false;
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));      // `data` may be released by the caller after this
+        if (bz_trace) fprintf(stderr, "bgzf chunk of %zu blocks at %.3f: %.3f ms in the call, of which %.3f ms waiting for the copy at its end\n", nb, ct0, bz_now() - ct0, bz_now() - ct1);
         return MLST_OK;
     }
     if (text_bytes == 0) return MLST_OK;
@@ -5407,6 +5528,10 @@ extern "C" int mlst_set_cu_partition(mlst_handle* h, uint32_t part, uint32_t n_p
         HIPCHK(h, hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
     }
     const bool was_own = h->stream == h->own_stream;
+    // (events last recorded on the stream that goes away go with it: hipStreamWaitEvent looks the recording stream of an event up --
+    // for capture bookkeeping -- and that of a destroyed stream is a dangling pointer: "dependency created on uncaptured work in
+    // another stream" from the inflate stream's wait for ev_packed, once in a dozen bench runs.  They are complete: the stream was waited for.)
+    for (auto& e : h->ev_packed) if (e) { hipEventDestroy(e); e = nullptr; }
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     h->own_stream = ns;
     if (was_own) h->stream = ns;

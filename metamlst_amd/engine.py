@@ -91,6 +91,7 @@ def load_library(path: str | None = None):
         "mlst_submit_fastq_bgzf": (C.c_int, [H, u8p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mlst_selftest_inflate": (C.c_int, [u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64)]),
         "mlst_selftest_inflate_canon": (C.c_int, [u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+        "mlst_debug_bgzf_walk": (C.c_int, [u8p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
         "mlst_selftest_inflate_device": (C.c_int, [H, u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
         "mlst_submit_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, C.c_uint32, C.c_int]),
         "mlst_pack_reads_device": (C.c_int, [H, u8p, u8p, u64p, C.c_uint64, u32p, u8p, u16p, C.c_uint32, C.c_uint32]),

@@ -437,3 +437,59 @@ def test_bgzf_chunks_of_tens_of_thousands_of_blocks_are_cut_by_the_library():
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
         assert r.returncode == 0, r.stderr[-1500:]
         assert r.stdout.strip().splitlines()[-1] == ref, (env, r.stdout, ref)
+
+
+@pytest.mark.gpu
+def test_bgzf_chunks_of_tens_of_megabytes_are_walked_by_four_threads_and_false_block_starts_cost_nothing():
+    """A chunk of 32 MB or more has its block headers walked by four threads, three of them from a block start they FIND
+    behind their quarter mark; a list counts only where the chain of the one before lands on its first block.  Stored BGZF
+    blocks (level 0: 36 MB for 36 MB of text) (a) as they are -- every thread finds a true start -- and (b) with the bytes of
+    two chained BGZF headers in every record's name line, so that every thread but the first starts from a false one: the
+    text path's statistics both times, as one chunk, through the file reader in pieces cut anywhere, and without the pipeline."""
+    import struct
+    import zlib
+    from metamlst_amd.engine import Engine
+    db, idx = fx.ecoli_small(60)
+    rng = np.random.default_rng(23)
+    g, _ = synth.make_genome(db, "ecoli", db.profiles["ecoli"][1], size=60_000)
+    fake = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x27\x00"      # a BGZF header that claims 40 bytes
+    trap = fake + b"x" * 22 + fake + b"y" * 22                                          # ... and 40 bytes on the next one
+    pool = []
+    for k in range(3000):
+        at = int(rng.integers(0, len(g) - 150))
+        pool.append(g[at:at + 150].tobytes() + b"\n+\n" + bytes((rng.integers(2, 42, size=150)).astype(np.uint8) + 33) + b"\n")
+
+    def stored_block(data: bytes) -> bytes:
+        c = zlib.compressobj(0, zlib.DEFLATED, -15)
+        comp = c.compress(data) + c.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
+                + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+    eng = Engine(0)
+    eng.load_reference(idx)
+    for name_extra, n_rec in ((b"", 115_000), (trap, 92_000)):
+        text = b"".join(b"@r%d " % k + name_extra + b"\n" + pool[k % len(pool)] for k in range(n_rec))
+        whole = b"".join(stored_block(text[at:at + 65280]) for at in range(0, len(text), 65280)) + stored_block(b"")
+        assert len(whole) > (34 << 20)
+        eng.reset_sample()
+        assert eng.submit_fastq(text) == n_rec
+        want = eng.stats()
+        eng.reset_sample()
+        assert eng.submit_fastq_bgzf(whole, final=True) == n_rec
+        fx.assert_stats_equal(eng.stats(), want)
+        d = tempfile.mkdtemp()
+        path = d + "/big.fastq.gz"
+        open(path, "wb").write(whole)
+        eng.reset_sample()
+        assert eng.submit_fastq_bgzf_file(path, chunk_bytes=33_000_001) == n_rec      # (chunks end inside blocks: the library says how much it took)
+        fx.assert_stats_equal(eng.stats(), want)
+        os.environ["MLST_BGZF_PIPE"] = "0"
+        try:
+            e2 = Engine(0)
+            e2.load_reference(idx)
+            assert e2.submit_fastq_bgzf(whole, final=True) == n_rec
+            fx.assert_stats_equal(e2.stats(), want)
+            e2.close()
+        finally:
+            del os.environ["MLST_BGZF_PIPE"]
+    eng.close()

@@ -182,3 +182,53 @@ def test_device_decoder_equals_zlib_on_every_block_kind(mode, monkeypatch):
     with pytest.raises(MlstError):
         eng.inflate_bgzf(_bgzf_raw(raw[:len(raw) // 2], fq))
     eng.close()
+
+
+def test_block_headers_of_a_large_chunk_are_walked_by_four_threads():
+    """mlst_submit_fastq_bgzf lists the blocks of a chunk of 32 MB or more with four threads (a header costs a cache miss and says
+    where the next one is); a thread's list counts only where the chain of the one before it lands on the block start the thread
+    found.  Host code: stored blocks (41 MB), (a) as they are: all four lists count; (b) with two chained BGZF headers
+    planted in the data behind every quarter mark: the three threads that start there find them, their lists are dropped, the count
+    is that of the serial walk; (c) a chunk cut inside its last block: not a whole block, as the serial walk says."""
+    import struct
+    lib = engine.load_library()
+
+    def stored_block(data: bytes) -> bytes:
+        c = zlib.compressobj(0, zlib.DEFLATED, -15)
+        comp = c.compress(data) + c.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
+                + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+    def walk(buf: bytes):
+        a = np.frombuffer(buf, np.uint8)
+        nb, tb, taken = C.c_uint64(), C.c_uint64(), C.c_int()
+        rc = lib.mlst_debug_bgzf_walk(a.ctypes.data_as(C.POINTER(C.c_uint8)), len(buf), C.byref(nb), C.byref(tb), C.byref(taken))
+        return rc, int(nb.value), int(tb.value), int(taken.value)
+
+    rng = np.random.default_rng(31)
+    payload = bytes(rng.integers(32, 127, 60_000, dtype=np.uint8))
+    n = 700
+    plain = b"".join(stored_block(payload[:59_000 + (k % 900)]) for k in range(n)) + stored_block(b"")
+    assert len(plain) > (36 << 20)
+    want_text = sum(59_000 + (k % 900) for k in range(n))
+    assert walk(plain) == (0, n, want_text, 4)
+    assert walk(plain[:20 << 20])[3] == 0                                  # (a small chunk: the serial walk alone)
+    fake = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x27\x00"
+    trap = fake + b"x" * 22 + fake + b"y" * 22
+    # the traps go INTO the stored data right behind every quarter mark of the final buffer: build, find the marks, rebuild
+    blocks = [bytearray(payload[:59_000 + (k % 900)]) for k in range(n)]
+    sizes = [len(stored_block(bytes(b))) for b in blocks]
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    total = int(starts[-1]) + len(stored_block(b""))
+    for q in (1, 2, 3):
+        mark = total * q // 4
+        k = int(np.searchsorted(starts, mark, side="right")) - 1          # the block that holds the mark
+        inside = mark - int(starts[k]) - 23                                 # (18 bytes of header + 5 of the stored block's own in front of the data)
+        at = max(inside, 0) + 40
+        assert at + len(trap) < len(blocks[k]) - 100
+        blocks[k][at:at + len(trap)] = trap
+    trapped = b"".join(stored_block(bytes(b)) for b in blocks) + stored_block(b"")
+    assert len(trapped) == total
+    rc, nb, tb, taken = walk(trapped)
+    assert (rc, nb, tb) == (0, n, want_text) and taken == 1
+    assert walk(plain[:-40])[0] != 0 and walk(plain[:len(plain) - 28 - 30_000])[0] != 0
