@@ -627,10 +627,11 @@ def end_to_end(w, args, torch, device):
         parts = list(ex.map(bgzf_block, [raw[at:at + 65280] for at in range(0, len(raw), 65280)]))
     comp = np.frombuffer(b"".join(parts) + bgzf_block(b""), np.uint8)
     # fed the way a file is (Engine.submit_fastq_bgzf_file: pieces of whole blocks from page-locked buffers): the copy of piece k + 1
-    # and its inflate run beside the parse and pass 1 of piece k (three streams, mlst_submit_fastq_bgzf).  Pieces of 49,152 blocks
-    # (one turn of k_inflate_tok2) where the input has several of them, else of 16,384 (one turn of k_inflate_tok): on 24 M reads
-    # 16,384 / 32,768 / 49,152 blocks give 312 / 290 / 294-340 Mreads/s, on 48 M reads 356 / - / 380-390 (profiles/round5/inflate.md)
-    per_piece = int(os.environ.get("MLST_BENCH_BGZF_PIECE", "49152" if nz >= 40_000_000 else "16384"))
+    # and its inflate run beside the parse and pass 1 of piece k (three streams, mlst_submit_fastq_bgzf).  Pieces of 65,536 blocks
+    # (one turn of k_inflate_tok2 with its four waves per CU) where the input has several of them, else of 16,384 (one turn of
+    # k_inflate_tok): on 24 M reads 16,384 / 32,768 / 49,152 blocks gave 312 / 290 / 294-340 Mreads/s, on 48 M reads 356 / - / 380-390
+    # with three waves per CU; 49,152 / 65,536 with four: 485 / 495 on a small database (profiles/round5/inflate.md)
+    per_piece = int(os.environ.get("MLST_BENCH_BGZF_PIECE", "65536" if nz >= 40_000_000 else "16384"))
     cuts = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
     pieces = [comp[int(cuts[a]):int(cuts[min(a + per_piece, len(parts))])] for a in range(0, len(parts), per_piece)]
     pieces[-1] = comp[int(cuts[(len(pieces) - 1) * per_piece]):]            # (with the end-of-file block)

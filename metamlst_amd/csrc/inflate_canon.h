@@ -1,4 +1,4 @@
-// inflate_canon.h -- phase 1 of the two-kernel inflate with 800 bytes of state per stream (round 5).
+// inflate_canon.h -- phase 1 of the two-kernel inflate with 576 bytes of state per stream (round 5; 800 in its first version).
 //
 // inflate_lane.h's k_inflate_tok decodes one BGZF block per LANE with look-up tables of 9 / 8 bits: 2.3 KB per stream, 64
 // streams = one wave fill a CU's LDS, and the kernel is bound by the latency of that ONE wave per CU (three SIMDs of four
@@ -7,8 +7,8 @@
 // significant) with 15 left-justified LIMITS -- limit[l] = (first code of length l + codes of length l) << (15 - l), non-
 // decreasing in l -- by counting the limits that P has reached (length = 1 + count; no table look-up, no long-code walk, one
 // straight line for every lane), the symbol index is base[length] + (P >> (15 - length)), and the symbols sit in code order.
-// Per stream: two codes x (16 limits + 16 bases) x 2 B, 192 + 32 symbols x 2 B, the code lengths of a block as nibbles
-// (160 B, only while its tables are built) and a 64-byte window of the stream: 200 words.  Three waves per CU instead of one.
+// Per stream: two codes x (16 limits + 16 bases) x 2 B, 192 + 32 symbols x 1 B, the code lengths of a block as nibbles
+// (160 B, only while its tables are built) and a 64-byte window of the stream: 144 words.  Four waves per CU instead of one.
 // A block whose literal / length code has more than 192 symbols in use (text never does; binary data may) is flagged like a
 // block with too many tokens and left to inflate_wave.h's kernel.
 //
@@ -28,8 +28,13 @@ typedef unsigned short u16;
 typedef unsigned char u8;
 
 enum : u32 { NSYM_L = 192, NSYM_D = 32, WIN = 64 };
-enum : u32 { W_LIM_L = 0, W_BASE_L = 8, W_SYM_L = 16, W_LIM_D = W_SYM_L + NSYM_L / 2, W_BASE_D = W_LIM_D + 8, W_SYM_D = W_BASE_D + 8,
-             W_LEN = W_SYM_D + NSYM_D / 2, W_WIN = W_LEN + 40, W_TOTAL = W_WIN + WIN / 4 };      // 32-bit words: 200 = 800 bytes
+// Symbols are kept as BYTES (second half of round 5; 16 bits each before: 800 bytes per stream, three waves per CU): a literal below
+// 224 as itself, the end-of-block and length symbols 256 .. 287 as 224 .. 255; a block that uses a literal of 224 or more (text
+// never does) is left to the other kernel like one with more than NSYM_L symbols.  144 words = 576 bytes per stream: FOUR waves per
+// CU, one per SIMD.
+enum : u32 { SYM_ESC = 224 };
+enum : u32 { W_LIM_L = 0, W_BASE_L = 8, W_SYM_L = 16, W_LIM_D = W_SYM_L + NSYM_L / 4, W_BASE_D = W_LIM_D + 8, W_SYM_D = W_BASE_D + 8,
+             W_LEN = W_SYM_D + NSYM_D / 4, W_WIN = W_LEN + 40, W_TOTAL = W_WIN + WIN / 4 };      // 32-bit words: 144 = 576 bytes
 enum : u32 { TAG_LIT = 0u, TAG_RAW = 1u, TAG_MATCH = 2u, TAG_OPERAND = 3u };      // token tags of inflate_lane.h
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -47,6 +52,10 @@ static inline u32 canon_brev32_(u32 x) {
 template <class M> MLST_HD inline u32 ld16(const M& m, u32 arr, u32 i) { return (m.ld(arr + (i >> 1)) >> (16u * (i & 1u))) & 0xFFFFu; }
 template <class M> MLST_HD inline void st16(M& m, u32 arr, u32 i, u32 v) {
     const u32 d = arr + (i >> 1), sh = 16u * (i & 1u); m.st(d, (m.ld(d) & ~(0xFFFFu << sh)) | ((v & 0xFFFFu) << sh));
+}
+template <class M> MLST_HD inline u32 ld8(const M& m, u32 arr, u32 i) { return (m.ld(arr + (i >> 2)) >> (8u * (i & 3u))) & 0xFFu; }
+template <class M> MLST_HD inline void st8(M& m, u32 arr, u32 i, u32 v) {
+    const u32 d = arr + (i >> 2), sh = 8u * (i & 3u); m.st(d, (m.ld(d) & ~(0xFFu << sh)) | ((v & 0xFFu) << sh));
 }
 template <class M> MLST_HD inline u32 ldn(const M& m, u32 i) { return (m.ld(W_LEN + (i >> 3)) >> (4u * (i & 7u))) & 15u; }
 template <class M> MLST_HD inline void stn(M& m, u32 i, u32 v) {
@@ -74,7 +83,11 @@ MLST_HD inline int build(M& m, const u32 w_lim, const u32 w_base, const u32 w_sy
     if (offs > cap) over = true;
     if (!neg) for (u32 s = 0; s < n; s++) {
         const u32 l = ldn(m, start + s);
-        if (l) { const u32 j = ld16(m, w_base, l); st16(m, w_base, l, j + 1u); if (j < cap) st16(m, w_sym, j, s); }
+        if (l) {
+            const u32 j = ld16(m, w_base, l); st16(m, w_base, l, j + 1u);
+            if (s >= SYM_ESC && s < 256u) over = true;                               // a literal the byte encoding has no room for
+            if (j < cap) st8(m, w_sym, j, s < 256u ? s : s - 256u + SYM_ESC);
+        }
     }
     u32 first = 0; offs = 0;
     #pragma unroll
@@ -100,7 +113,8 @@ MLST_HD inline int decode_l(const M& m, const u32 (&L)[8], const u32 w_base, con
     const bool none = P >= (L[7] >> 16);               // beyond the last code of 15 bits: an incomplete code's gap
     const u32 idx = (ld16(m, w_base, (u32)len) + (P >> (15u - (u32)len))) & 0xFFFFu;
     const bool bad = none || idx >= cap;
-    const u32 sym = ld16(m, w_sym, bad ? 0u : idx);
+    const u32 v = ld8(m, w_sym, bad ? 0u : idx);
+    const u32 sym = v + (v >= SYM_ESC ? 256u - SYM_ESC : 0u);
     return bad ? (int)mlst_inflate::E_SYMBOL : (int)sym;
 }
 template <class M>

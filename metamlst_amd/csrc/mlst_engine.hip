@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(64) void k_inflate_tok(const u8* __restrict__ comp,
     inflate_lane::tok_body(comp, comp + comp_bytes, blk, n_blk, err_base, tok, INFL_TOK_CAP, n_tok, err, s_tb, s_win);
 #endif
 }
-// phase 1 with 800 bytes of state per stream (csrc/inflate_canon.h): three waves per CU instead of one
+// phase 1 with 576 bytes of state per stream (csrc/inflate_canon.h): four waves per CU, one per SIMD, instead of one
 __global__ __launch_bounds__(64) void k_inflate_tok2(const u8* __restrict__ comp, u64 comp_bytes, const BgzfBlk* __restrict__ blk, u32 n_blk, u32 err_base, u32* __restrict__ tok,
                                                      u32* __restrict__ n_tok, u32* __restrict__ err) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -4639,7 +4639,7 @@ extern "C" int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, c
 // most INFL_PASS blocks (the token buffer holds 96 KB per block of a pass), with the blocks whose tokens did not fit left to
 // 1 = the one-wave-per-block kernel of csrc/inflate_wave.h.
 #define INFL_PASS 16384u          /* blocks per pass with k_inflate_tok: one wave (64 blocks) per CU is all its 160 KB of tables allow */
-#define INFL_PASS2 49152u         /* with k_inflate_tok2: three waves per CU (the token buffer holds 96 KB per block of a pass: 4.7 GB) */
+#define INFL_PASS2 65536u         /* with k_inflate_tok2: four waves per CU (the token buffer holds 96 KB per block of a pass: 6.3 GB) */
 // d_nl (optional; two-kernel path only): newline counts per FQ_BLOCK bytes of d_out, added up while the text is written (zeroed by the caller)
 static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padded, const BgzfBlk* d_blk, u32 n_blk, u8* d_out, u32* d_err, unsigned long long* d_st, hipStream_t st = nullptr, u32* d_nl = nullptr) {
     if (n_blk == 0) return MLST_OK;
@@ -4651,9 +4651,9 @@ static int launch_inflate(mlst_handle* h, const u8* d_comp, u64 comp_bytes_padde
         return MLST_OK;
     }
     // Phase 1: k_inflate_tok (tables of 9 / 8 bits, 2.3 KB per stream: ONE wave of 64 blocks per CU, 0.58 us per symbol step) or
-    // k_inflate_tok2 (canonical limits, 800 B per stream: three waves per CU, 0.9 us per step).  Both are bound by the latency of a
+    // k_inflate_tok2 (canonical limits, 576 B per stream: four waves per CU, 0.9 us per step).  Both are bound by the latency of a
     // wave, so what counts is how many blocks are in flight: up to 16,384 blocks the first finishes in one turn (4.4 ms) and wins;
-    // a larger piece costs it a turn per 16,384 blocks (49,152 blocks: 13.2 ms) while the second still takes one (9 ms).
+    // a larger piece costs it a turn per 16,384 blocks (49,152 blocks: 13.2 ms) while the second still takes one (9 ms, up to 65,536 blocks).
     // MLST_INFLATE_TOK = 1 / 2 forces one of them; default: by the number of blocks.
     const char* tok_e = getenv("MLST_INFLATE_TOK"); const int tok_env = tok_e ? atoi(tok_e) : 0;
     const int tok_kind = tok_env == 1 || tok_env == 2 ? tok_env : (n_blk > 18432u ? 2 : 1);      // (24,576 blocks: 1.5 turns of the first = 8.8 ms, one of the second ~7.5)
@@ -5024,7 +5024,7 @@ extern "C" int mlst_submit_fastq_bgzf(mlst_handle* h, const uint8_t* data, uint6
         // The chunk goes through the pipeline in pieces.  What the three streams cannot hide is the FIRST piece's copy + inflate (nothing
         // to parse beside them yet) and the LAST piece's parse + pass 1 (nothing inflating beside them any more): so a chunk that
         // meets an empty pipeline leads with a piece of 16,384 blocks (one turn of k_inflate_tok), a last chunk ends with one of
-        // 8,192, and what lies between goes in pieces of up to 49,152 (one turn of k_inflate_tok2).  MLST_BGZF_SPLIT=0: the chunk as one piece.
+        // 8,192, and what lies between goes in pieces of up to 65,536 (one turn of k_inflate_tok2).  MLST_BGZF_SPLIT=0: the chunk as one piece.
         static const bool split = [] { const char* e = getenv("MLST_BGZF_SPLIT"); return !(e && e[0] == '0'); }();
         const size_t nb = blks.size();
         std::vector<size_t> cuts; cuts.push_back(0);

@@ -298,10 +298,11 @@ class Engine:
         release_buffers(ring)
         return total
 
-    def submit_fastq_bgzf_file(self, path: str, paired: bool = False, chunk_bytes: int = 384 << 20) -> int:
-        """A whole bgzip'd FASTQ file (see _submit_bgzf_pieces).  Pieces of 384 MB compressed (~33 k BGZF blocks): one pass of the
-        inflate kernels with two to three waves per CU (k_inflate_tok2), and the piece behind it is copied and inflated meanwhile;
-        larger pieces inflate a little faster per block but leave a file of a few GB with too few pieces to overlap."""
+    def submit_fastq_bgzf_file(self, path: str, paired: bool = False, chunk_bytes: int = (512 << 20) - (1 << 18)) -> int:
+        """A whole bgzip'd FASTQ file (see _submit_bgzf_pieces).  Chunks of just under 512 MB compressed (~44 k BGZF blocks; with the
+        reader's margin a chunk fills a 512 MB page-locked buffer, four of them per walk): one pass of the inflate kernels with
+        three waves per CU (k_inflate_tok2 holds four: 65,536 blocks a turn), and the chunk behind it is copied and inflated
+        meanwhile; the library cuts a first chunk's head and a last chunk's tail off as pieces of their own (mlst_submit_fastq_bgzf)."""
         return self._submit_bgzf_pieces(path, 0, os.path.getsize(path), chunk_bytes, paired, True)
 
     def inflate_bgzf(self, data) -> bytes:
