@@ -106,9 +106,20 @@ template <class M>
 MLST_HD inline int decode_l(const M& m, const u32 (&L)[8], const u32 w_base, const u32 w_sym, const u32 cap, const u32 P, int& len) {
     // count of the limits P has reached, without a compare: limit - (P + 1) is negative exactly then, and the sign bits add up
     // (a compare per limit went through VCC: compare, hazard nop, select, add)
-    u32 c = 0; const u32 p1 = P + 1u;
+    const u32 p1 = P + 1u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (device: two limits per instruction -- the words hold them as 16-bit pairs: packed subtract, packed shift, packed add.  All 16
+    // limits go through; limit[0] = 0 always counts (p1 >= 1) and limit[15]'s turn is the `none` test below: both taken off again.)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 pp = {(unsigned short)p1, (unsigned short)p1};
+    us2 acc = {0, 0};
     #pragma unroll
+    for (u32 j = 0; j < 8; j++) { const us2 d = __builtin_bit_cast(us2, L[j]) - pp; acc += d >> (unsigned short)15; }
+    const u32 c = (u32)acc.x + (u32)acc.y - 1u - ((((L[7] >> 16) - p1) >> 31) & 1u);
+#else
+    u32 c = 0;
     for (u32 l = 1; l < 15; l++) c += (((L[l >> 1] >> (16u * (l & 1u))) & 0xFFFFu) - p1) >> 31;
+#endif
     len = 1 + (int)c;
     const bool none = P >= (L[7] >> 16);               // beyond the last code of 15 bits: an incomplete code's gap
     const u32 idx = (ld16(m, w_base, (u32)len) + (P >> (15u - (u32)len))) & 0xFFFFu;
