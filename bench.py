@@ -979,7 +979,7 @@ def main():
            "world_size_reported_by_backend": (dist.get_world_size() if world > 1 else 1), "literal_parity_bowtie2": None}
     # ---- secondary block: cfg2 (configs[1]) in the same run, N = 1 only
     if world == 1 and not args.no_secondary and args.workload == "cfg3":
-        for e in w.engines:
+        for e in list(w.engines) + list(getattr(w, "folder_engines", []))[len(w.engines):]:      # (the folder legs made two more)
             e.close()
         del w.batches
         torch.cuda.empty_cache()
@@ -998,7 +998,7 @@ def main():
     # ---- the same step on a PubMLST-shaped database (alleles per locus 10 ... 10,000): what the real database's skew does to it
     skewed = None
     if world == 1 and not args.no_secondary and args.workload == "cfg3":
-        for e in w2.engines:
+        for e in list(w2.engines) + list(getattr(w2, "folder_engines", []))[len(w2.engines):]:
             e.close()
         del w2.batches
         torch.cuda.empty_cache()
