@@ -4423,9 +4423,10 @@ extern "C" int mlst_submit_reads(mlst_handle* h, const uint8_t* bases, const uin
     }
     hipStreamSynchronize(h->stream);     // the previous batch may still read the staging buffers
     std::vector<u64> rel(n_reads + 1); for (u64 r = 0; r <= n_reads; r++) rel[r] = off[r] - off[0];
-    HIPCHK(h, hipMemcpy(h->d_in_bases, bases + off[0], nbytes, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->d_in_quals, quals + off[0], nbytes, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(h->d_in_off, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpyAsync(h->d_in_bases, bases + off[0], nbytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_in_quals, quals + off[0], nbytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_in_off, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // (`rel` and the caller's arrays are read until here; on the engine's stream, not the legacy one: DESIGN.md 4a)
     return mlst_submit_reads_device(h, h->d_in_bases, h->d_in_quals, (const uint64_t*)h->d_in_off, n_reads, max_len, paired);
 }
 
@@ -4512,9 +4513,11 @@ static int fastq_pipeline(mlst_handle* h, u64 n_bytes, int paired, bool whole, u
     {   // k_fq_records wrote the lengths into d_lens; growing the pack buffers must keep them
         std::vector<u16> keep;
         if (h->cap_packed_words < packed_words(n_reads, wpr) + 4 || h->cap_qrow_bytes < n_reads * qstride) {
-            keep.resize(n_reads); HIPCHK(h, hipMemcpy(keep.data(), h->d_lens, n_reads * 2, hipMemcpyDeviceToHost));
+            // (copies on the engine's stream, not hipMemcpy: the legacy stream waits for every blocking stream, and another engine of the
+            // process -- the folder mode runs six, a feeder thread each -- may be capturing its graph on one: DESIGN.md 4a)
+            keep.resize(n_reads); HIPCHK(h, hipMemcpyAsync(keep.data(), h->d_lens, n_reads * 2, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
             rc = ensure_pack_buffers(h, n_reads, wpr, qstride); if (rc) return rc;
-            HIPCHK(h, hipMemcpy(h->d_lens, keep.data(), n_reads * 2, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpyAsync(h->d_lens, keep.data(), n_reads * 2, hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream));
         }
     }
     hipLaunchKernelGGL(k_pack_text, dim3(grid_for((n_reads + 63) / 64, 1, 8192)), dim3(256), 0, h->stream, h->d_fq_text, h->d_fq_soff, h->d_fq_qoff,
@@ -4624,7 +4627,7 @@ extern "C" int mlst_submit_packed_host(mlst_handle* h, const uint32_t* packed, c
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n_cand > n_reads) n_cand = n_reads;
     std::vector<u32> cand(n_cand ? n_cand : 1);
-    if (n_cand) HIPCHK(h, hipMemcpy(cand.data(), h->d_cand, n_cand * 4, hipMemcpyDeviceToHost));
+    if (n_cand) { HIPCHK(h, hipMemcpyAsync(cand.data(), h->d_cand, n_cand * 4, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipStreamSynchronize(h->stream)); }
     const u64 qbytes = n_cand * qstride;
     if (h->cap_hostq < qbytes) { if (h->h_qc) hipHostFree(h->h_qc); h->h_qc = nullptr; HIPCHK(h, hipHostMalloc((void**)&h->h_qc, qbytes + 64, hipHostMallocDefault)); h->cap_hostq = qbytes + 64; }
     if (h->cap_qc < qbytes) { hipFree(h->d_qc); h->d_qc = nullptr; HIPCHK(h, dmalloc(&h->d_qc, qbytes + 64)); h->cap_qc = qbytes + 64; }
