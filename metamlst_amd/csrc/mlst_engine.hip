@@ -2546,7 +2546,8 @@ __device__ __forceinline__ void extend_body(const EngineDev* __restrict__ Ep, co
 
 // Two instantiations: reads up to 160 bases (five 32-base blocks) and up to MLST_MAX_READ_LEN.
 __global__ __launch_bounds__(1024) void k_extend_160(const EngineDev* __restrict__ Ep, KParams P, u32 lds_recs, u32 acc_cap, const u32* __restrict__ xrec, u64 cap_xrec) { extend_body<5>(Ep, P, lds_recs, acc_cap, xrec, cap_xrec); }
-__global__ __launch_bounds__(1024) void k_extend_320(const EngineDev* __restrict__ Ep, KParams P, u32 lds_recs, u32 acc_cap, const u32* __restrict__ xrec, u64 cap_xrec) { extend_body<RW / 2>(Ep, P, lds_recs, acc_cap, xrec, cap_xrec); }
+// (at most 512 threads per workgroup for the long instantiation: with 1,024 the compiler has 128 registers per lane and spilled five of them -- 48 B of scratch)
+__global__ __launch_bounds__(512) void k_extend_320(const EngineDev* __restrict__ Ep, KParams P, u32 lds_recs, u32 acc_cap, const u32* __restrict__ xrec, u64 cap_xrec) { extend_body<RW / 2>(Ep, P, lds_recs, acc_cap, xrec, cap_xrec); }
 
 template <int CTRL, int ROW_MASK = 0xF> __device__ inline int dpp_i32(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
@@ -4348,7 +4349,7 @@ static int submit_impl(mlst_handle* h, const uint32_t* d_packed, const uint8_t* 
       { Prof pf(h, 2);     // register arrays sized for the batch's read words: 160 bp and 320 bp instantiations
         const int thr = h->ext_threads, blocks = h->ext_blocks;
         if (wpr <= 10) hipLaunchKernelGGL(k_extend_160, dim3(blocks), dim3(thr), ext_lds_bytes(h, 0), h->stream, h->d_E, h->kp, h->ext_lds_recs[0], h->ext_acc_cap, h->d_xrec[0], h->cap_xrec[0]);
-        else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(thr), ext_lds_bytes(h, 1), h->stream, h->d_E, h->kp, h->ext_lds_recs[1], h->ext_acc_cap, h->d_xrec[1], h->cap_xrec[1]); }
+        else hipLaunchKernelGGL(k_extend_320, dim3(blocks), dim3(std::min(thr, 512)), ext_lds_bytes(h, 1), h->stream, h->d_E, h->kp, h->ext_lds_recs[1], h->ext_acc_cap, h->d_xrec[1], h->cap_xrec[1]); }
     }
     if (h->pair_loci) { Prof pf(h, 2);      // the loci the haplotype kernel does not take
       const int thr = h->extp_threads, blocks = h->extp_blocks;
