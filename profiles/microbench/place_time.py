@@ -15,3 +15,12 @@ for r in range(3):
         t0 = time.perf_counter(); e.synchronize(); t1 = time.perf_counter(); e.set_cu_partition(k % 2, 2); t2 = time.perf_counter()
         print("run %d engine %d: sync %.2f ms, set_cu_partition %.2f ms" % (r, k, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
     for e in engines: e.set_cu_partition(0, 1)
+# the same from six threads at once (does the runtime make CU-masked streams side by side?)
+from concurrent.futures import ThreadPoolExecutor
+for r in range(3):
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(6) as ex:
+        list(ex.map(lambda ke: ke[1].set_cu_partition(ke[0] % 2, 2), enumerate(engines)))
+    t1 = time.perf_counter()
+    print("run %d: six engines placed from six threads in %.2f ms" % (r, (t1 - t0) * 1e3))
+    for e in engines: e.set_cu_partition(0, 1)
